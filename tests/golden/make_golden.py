@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the MR_env.step()/MR_simulator hot path.
+
+Runs ONLY in the build container (needs /root/reference, numpy, scipy).  The
+reference's own files are imported unmodified from where they lie; nothing of
+them is copied.  What is committed is data: inputs and the reference's outputs.
+
+  ref_sim.npz   MR_simulator.Simulator driven directly (no stand-ins at all):
+                positions + the RK45 object's carried state (t, h_abs, f) and
+                Simulator.state_prime after every step.          (G1..G5)
+  ref_noise.npz Simulator runs with noise_var > 0 where every value returned by
+                numpy.random.normal is recorded in draw order ("tape").  The
+                oracle replays the tape, which pins its noise plumbing (draw
+                order, stage weights, error control, constructor draws) against
+                the real reference even though MT19937 itself is not restated.  (G8)
+  ref_env.npz   MR_env.MR_Env episodes and utils.run_sim output.  `gym`,
+                `turtle` and `tkinter` are not installed in this image, so
+                MR_env.py is imported against the minimal stand-ins below; the
+                only stand-in behaviour that reaches a result is
+                Box.contains (numeric bounds check) and Box.sample -- the
+                out-of-bounds termination is therefore documented as
+                "parity unpinned (gym absent)" in DESIGN.md.     (G6, G7)
+
+Usage:  python tests/golden/make_golden.py   (writes next to this file)
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True  # /root/reference is read-only
+
+import numpy as np
+
+REF = os.environ.get("MRSIM_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+import MR_simulator  # noqa: E402  (reference, unmodified)
+
+
+# --------------------------------------------------------------------------
+# action tables (inputs)
+# --------------------------------------------------------------------------
+def actions_straight(T=1000):
+    a = np.zeros((T, 2))
+    a[:, 0] = 4.0
+    a[:, 1] = np.pi / 4
+    return a
+
+
+def actions_ramp(T=1000, freq=4.0):
+    """The alpha-ramp test profile of the reference's main.py:39-50."""
+    a = np.zeros((T, 2))
+    a[0:200, 1] = np.linspace(0, np.pi / 2, 200)
+    a[200:400, 1] = np.linspace(np.pi / 2, -np.pi / 2, 200)
+    a[400:600, 1] = np.linspace(-np.pi / 2, 0, 200)
+    a[600:800, 1] = np.linspace(0, np.pi / 8, 200)
+    a[800:, 1] = np.linspace(np.pi / 8, -np.pi, 200)
+    a[:, 0] = freq
+    return a
+
+
+def actions_figure8(T=1000):
+    """v = (cos th, cos 2th), f = 4|v|, alpha = atan2."""
+    th = 2 * np.pi * np.arange(T) / T
+    vx, vy = np.cos(th), np.cos(2 * th)
+    a = np.zeros((T, 2))
+    a[:, 0] = 4.0 * np.hypot(vx, vy)
+    a[:, 1] = np.arctan2(vy, vx)
+    return a
+
+
+def actions_random(T, rng, idle_frac=0.1, wide=False):
+    a = np.zeros((T, 2))
+    if wide:  # DDPG actor range, RL/MR_ddpg.py:136-137,345 (never clipped by the env)
+        a[:, 0] = rng.uniform(-20, 20, T)
+        a[:, 1] = rng.uniform(-2 * np.pi, 2 * np.pi, T)
+    else:
+        a[:, 0] = rng.uniform(0, 20, T)
+        a[:, 1] = rng.uniform(0, 2 * np.pi, T)
+    idle = rng.uniform(size=T) < idle_frac
+    a[idle] = 0.0
+    return a
+
+
+# --------------------------------------------------------------------------
+# drive the reference Simulator
+# --------------------------------------------------------------------------
+def run_simulator(actions, init, a0, noise_var, mismatched, mismatch_at_reset=False):
+    """MR_env.reset order (MR_env.py:179-183): noise_var, a0, reset_start_pos, then is_mismatched."""
+    s = MR_simulator.Simulator()
+    s.is_mismatched = bool(mismatch_at_reset)
+    s.noise_var = noise_var
+    s.a0 = a0
+    s.reset_start_pos(np.asarray(init, dtype=np.float64))
+    s.is_mismatched = bool(mismatched)
+    T = len(actions)
+    out = dict(
+        pos=np.zeros((T, 2)), t=np.zeros(T), h_abs=np.zeros(T), f=np.zeros((T, 2)),
+        state_prime=np.zeros((T, 2)),
+        reset_h_abs=np.float64(s.integrator.h_abs), reset_f=np.array(s.integrator.f, dtype=np.float64),
+        reset_state_prime=np.array(s.state_prime, dtype=np.float64),
+    )
+    for k, (f_t, al) in enumerate(actions):
+        out["pos"][k] = s.step(f_t, al)
+        out["t"][k] = s.integrator.t
+        out["h_abs"][k] = s.integrator.h_abs
+        out["f"][k] = s.integrator.f
+        out["state_prime"][k] = s.state_prime
+    return out
+
+
+def gen_sim():
+    rng = np.random.default_rng(20261004)
+    cases = {}
+
+    def add(name, actions, init, a0, mismatched=False, mismatch_at_reset=False):
+        r = run_simulator(actions, init, a0, 0.0, mismatched, mismatch_at_reset)
+        cases[name] = dict(actions=actions, init=np.asarray(init, float), a0=a0,
+                           mismatched=int(mismatched), mismatch_at_reset=int(mismatch_at_reset), **r)
+
+    add("g1_straight", actions_straight(), [0.0, 0.0], 1.0)
+    add("g2_ramp", actions_ramp(), [0.0, 0.0], 1.5)
+    add("g3_figure8", actions_figure8(), [0.0, 0.0], 1.0)
+    add("g4_rand_far", actions_random(2000, rng), [110.0, 115.0], 1.0)
+    add("g4_rand_origin", actions_random(2000, rng), [0.0, 0.0], 1.0)
+    add("g4_rand_near", actions_random(2000, rng), [0.5, -0.2], 1.0)
+    add("g4_rand_wide", actions_random(2000, rng, wide=True), [104.25, 118.5], 1.0)
+    add("g4_rand_neg", actions_random(2000, rng, wide=True), [-300.0, 4000.0], 0.7)
+    add("g5_mis_const", np.tile([[4.0, 0.3]], (1000, 1)), [0.0, 0.0], 1.5, mismatched=True)
+    add("g5_mis_ramp", actions_ramp(), [0.0, 0.0], 1.5, mismatched=True)
+    add("g5_mis_rand", actions_random(2000, rng), [110.0, 115.0], 1.0, mismatched=True)
+    add("g5_mis_reused", actions_random(500, rng), [3.0, -2.0], 1.0, mismatched=True, mismatch_at_reset=True)
+
+    flat = {}
+    for name, d in cases.items():
+        for k, v in d.items():
+            flat[f"{name}/{k}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, "ref_sim.npz"), **flat)
+    print("ref_sim.npz:", ", ".join(cases))
+
+
+# --------------------------------------------------------------------------
+# noisy runs with a recorded tape of the reference's own normal draws
+# --------------------------------------------------------------------------
+class _Tape:
+    def __init__(self):
+        self.vals = []
+        self._orig = np.random.normal
+
+    def __enter__(self):
+        def rec(loc=0.0, scale=1.0, size=None):
+            v = self._orig(loc, scale, size)
+            self.vals.extend(np.atleast_1d(v).tolist())
+            return v
+        np.random.normal = rec
+        return self
+
+    def __exit__(self, *a):
+        np.random.normal = self._orig
+
+
+def gen_noise():
+    rng = np.random.default_rng(77)
+    flat = {}
+    specs = [
+        ("n_far_s1", actions_random(400, rng, wide=True), [110.0, 115.0], 1.0, 1.0, False),
+        ("n_far_s05", actions_random(400, rng), [101.5, 119.0], 1.0, 0.5, False),
+        ("n_origin_s05", actions_ramp()[:400], [0.0, 0.0], 1.5, 0.5, False),
+        ("n_near_s1", actions_random(400, rng), [0.3, 0.1], 1.0, 1.0, False),
+        ("n_mis_s05", actions_random(400, rng), [110.0, 115.0], 1.0, 0.5, True),
+        ("n_mis_origin_s1", actions_ramp()[:300], [0.0, 0.0], 1.5, 1.0, True),
+    ]
+    for i, (name, actions, init, a0, sigma, mis) in enumerate(specs):
+        np.random.seed(1000 + i)
+        with _Tape() as tape:
+            r = run_simulator(actions, init, a0, sigma, mis)
+        d = dict(actions=actions, init=np.asarray(init, float), a0=a0, sigma=sigma,
+                 mismatched=int(mis), tape=np.asarray(tape.vals), **r)
+        for k, v in d.items():
+            flat[f"{name}/{k}"] = np.asarray(v)
+        print(f"  {name}: {len(tape.vals)} draws over {len(actions)} steps "
+              f"({len(tape.vals) / len(actions):.2f}/step)")
+    np.savez_compressed(os.path.join(HERE, "ref_noise.npz"), **flat)
+    print("ref_noise.npz written")
+
+
+# --------------------------------------------------------------------------
+# MR_Env / run_sim (needs stand-ins for the absent gym / turtle / tkinter)
+# --------------------------------------------------------------------------
+def _install_standins():
+    gym = types.ModuleType("gym")
+
+    class Env:  # gym.Env is only used as a base class (MR_env.py:21)
+        pass
+
+    class Box:  # numeric bounds check + uniform float32 sample; nothing else is used
+        def __init__(self, low, high, dtype=np.float32):
+            self.low = np.asarray(low, dtype=dtype)
+            self.high = np.asarray(high, dtype=dtype)
+            self.shape = self.low.shape
+            self.dtype = np.dtype(dtype)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return bool(x.shape == self.shape and np.all(x >= self.low) and np.all(x <= self.high))
+
+        def sample(self):
+            return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Box = Box
+    gym.Env, gym.spaces = Env, spaces
+    sys.modules["gym"], sys.modules["gym.spaces"] = gym, spaces
+    for name in ("turtle", "tkinter"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = types.ModuleType(name)
+
+
+def gen_env():
+    _install_standins()
+    import contextlib
+    import io
+    import MR_env  # noqa: E402 (reference, unmodified)
+    import utils   # noqa: E402 (reference, unmodified) -- run_sim
+
+    rng = np.random.default_rng(4242)
+    flat = {}
+
+    def episode(name, init, actions, a0=1.0, noise_var=0.0, mismatched=False, stop_on_done=False):
+        env = MR_env.MR_Env()
+        with contextlib.redirect_stdout(io.StringIO()):  # reset() prints (MR_env.py:175-176)
+            obs0 = env.reset(init=np.asarray(init, dtype=np.float64), noise_var=noise_var, a0=a0,
+                             is_mismatched=mismatched)
+        T = len(actions)
+        obs = np.zeros((T, 5)); rew = np.zeros(T); done = np.zeros(T, dtype=np.uint8)
+        sp = np.zeros((T, 2)); lp = np.zeros((T, 2)); cnt = np.zeros(T, dtype=np.int32)
+        calc = np.zeros(T)
+        n = T
+        for k, a in enumerate(actions):
+            with contextlib.redirect_stdout(io.StringIO()):
+                o, r, d, info = env.step(a)
+                calc[k] = env.calculate_reward(o)  # defined-but-uncalled reward, MR_env.py:118-134
+            obs[k], rew[k], done[k] = o, r, d
+            sp[k], lp[k], cnt[k] = env.state_prime, env.last_pos, env.counter
+            if d and stop_on_done:
+                n = k + 1
+                break
+        for key, v in dict(init=np.asarray(init, float), actions=np.asarray(actions), a0=a0,
+                           mismatched=int(mismatched), obs0=obs0, obs=obs[:n], rew=rew[:n],
+                           done=done[:n], state_prime=sp[:n], last_pos=lp[:n], counter=cnt[:n],
+                           calc_reward=calc[:n]).items():
+            flat[f"{name}/{key}"] = np.asarray(v)
+        print(f"  {name}: {n} steps, first done at "
+              f"{(int(np.argmax(done[:n])) + 1) if done[:n].any() else None}")
+
+    # G6a: DDPG-shaped episode (random wide actions, start in [100,120]^2): times out at step 51
+    episode("g6_timeout", [112.5, 103.25], actions_random(60, rng, idle_frac=0.0, wide=True))
+    # G6b: goal reach: start (40,0), f=20, alpha=pi -> d<30 at step 17
+    episode("g6_goal", [40.0, 0.0], np.tile([[20.0, np.pi]], (25, 1)))
+    # G6c: out of bounds: start just inside x=5000, drive +x
+    episode("g6_oob", [4999.0, 10.0], np.tile([[20.0, 0.0]], (12, 1)))
+    # G6d: mismatched episode
+    episode("g6_mis", [110.0, 115.0], actions_random(55, rng), a0=1.5, mismatched=True)
+
+    # G7: run_sim tuple (utils.py:43-61), ignores done
+    for name, actions, init, a0, mis in [
+        ("g7_runsim_ramp", actions_ramp()[:300], [0.0, 0.0], 1.5, False),
+        ("g7_runsim_mis", actions_figure8()[:300], [0.0, 0.0], 1.0, True),
+    ]:
+        a3 = np.zeros((len(actions), 3)); a3[:, :2] = actions; a3[:, 2] = np.arange(len(actions)) * 0.030
+        with contextlib.redirect_stdout(io.StringIO()):
+            X, Y, alpha, time, freq = utils.run_sim(a3, init_pos=np.asarray(init, float), noise_var=0.0,
+                                                    a0=a0, is_mismatched=mis)
+        for key, v in dict(actions=a3, init=np.asarray(init, float), a0=a0, mismatched=int(mis),
+                           X=X, Y=Y, alpha=alpha, time=time, freq=freq).items():
+            flat[f"{name}/{key}"] = np.asarray(v)
+        print(f"  {name}: {len(X)} steps")
+    np.savez_compressed(os.path.join(HERE, "ref_env.npz"), **flat)
+    print("ref_env.npz written")
+
+
+if __name__ == "__main__":
+    import scipy
+    print(f"numpy {np.__version__}, scipy {scipy.__version__}, reference at {REF}")
+    gen_sim()
+    gen_noise()
+    gen_env()
