@@ -1,0 +1,156 @@
+/*
+ * mrsim.h -- C ABI of libmrsim.so: the MI355X (gfx950) implementation of the
+ * MR_env.step() / MR_simulator hot path of SuhailSama/MR_RL for N environments.
+ *
+ * The reference has no FFI / plugin boundary on this path: it is a pure Python
+ * class API (class MR_Env(gym.Env), MR_env.py:21).  These entry points are what a
+ * ctypes binding placed in the reference's MR_env.py would bind (INTEGRATION.md
+ * shows that stub); each one names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a DEVICE pointer owned by the
+ *     caller (e.g. torch tensors' data_ptr()) unless the name ends in _host;
+ *   - the library allocates no persistent device memory and keeps no globals;
+ *   - `stream` is a hipStream_t (0 = the null stream); calls are asynchronous;
+ *   - every entry point returns MRSIM_OK (0) or a negative MRSIM_E* code, no
+ *     exceptions cross the boundary; mrsim_strerror() names a code;
+ *   - the RNG is stateless: (seed, global env id, step_idx) are arguments, so
+ *     a shard [env_id0, env_id0+n) produces the same trajectories on any rank.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     returns MRSIM_ENODEVICE.
+ */
+#ifndef MRSIM_H
+#define MRSIM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRSIM_ABI_VERSION 1
+
+enum {
+    MRSIM_OK = 0,
+    MRSIM_EINVAL = -1,    /* bad argument (null pointer, n < 0, unknown enum)            */
+    MRSIM_ENODEVICE = -2, /* no HIP device / wrong architecture                           */
+    MRSIM_ELAUNCH = -3,   /* hipLaunchKernel / HIP runtime error                          */
+    MRSIM_EALIGN = -4,    /* a buffer is not 16-byte aligned                              */
+    MRSIM_ERANGE = -5     /* n or env ids exceed 2^32                                     */
+};
+
+enum { MRSIM_INT_RK45 = 0, MRSIM_INT_EULER = 1, MRSIM_INT_RK4 = 2 };
+enum { MRSIM_REW_CONSTANT10 = 0, MRSIM_REW_GOAL = 1 };
+enum { MRSIM_OBS_AOS = 0 /* [N][5] */, MRSIM_OBS_SOA = 1 /* [5][N] */ };
+
+/* Tunables of the reference path, with the place each one lives in the reference. */
+typedef struct MrsimParams {
+    double time_span;      /* Simulator.time_span = 0.030            MR_simulator.py:12        */
+    double rtol;           /* time_span/number_iterations = 3e-4      MR_simulator.py:13,91     */
+    double atol;           /* 1e-4                                    MR_simulator.py:91        */
+    double a0;             /* Simulator.a0 (reset kwarg)              MR_env.py:168,180         */
+    double sigma;          /* Simulator.noise_var (a std-dev)         MR_env.py:167,179         */
+    double min_dist2goal;  /* 30                                      MR_env.py:63              */
+    double obs_low[5];     /* observation_space                       MR_env.py:37-39           */
+    double obs_high[5];
+    double init_low[2];    /* init_space                              MR_env.py:40-42           */
+    double init_high[2];
+    double act_low[2];     /* range of the on-device random policy (DDPG actor range,          */
+    double act_high[2];    /*   RL/MR_ddpg.py:136-137,345: [-20,20] x [-2pi,2pi])               */
+    int32_t mismatched;    /* Simulator.is_mismatched                 MR_env.py:169,183         */
+    int32_t integrator;    /* MRSIM_INT_*; RK45 = the reference (SciPy RK45 semantics)          */
+    int32_t substeps;      /* Euler / RK4 sub-steps per env step (BASELINE configs 2, 3)        */
+    int32_t reward_mode;   /* CONSTANT10 = MR_env.py:89; GOAL = calculate_reward MR_env.py:118  */
+    int32_t max_timesteps; /* 50                                      MR_env.py:62              */
+    int32_t auto_reset;    /* same-step auto reset (extension; 0 = reference behaviour)         */
+    int32_t goal_K;        /* goal/trajectory table [K][T][2] f32; NULL table = goal (0,0)      */
+    int32_t goal_T;        /*   = MR_Env.init_goal, MR_env.py:57                                */
+    int32_t obs_layout;    /* MRSIM_OBS_*                                                       */
+    int32_t reserved;
+} MrsimParams;
+
+/* Per-env persistent state in HBM, caller-owned.  16-byte records so that every
+ * lane moves one dwordx4 per array.
+ *   pos[n]  = {x, y} fp64           Simulator.last_state == integrator.y  (MR_simulator.py:45)
+ *   aux[n]  = {f0x, f0y, hq, cnt}   the live RK45 object's carried state: integrator.f
+ *             (f32, f32, f32, i32)  (first stage of the NEXT step -- the stale-stage
+ *                                   quirk), hq = integrator.h_abs / time_span,
+ *                                   cnt = MR_Env.counter (MR_env.py:61,80)
+ *   ep_ret[n] fp32                  running episode return (extension)                 */
+typedef struct MrsimState {
+    double* pos;
+    float* aux;
+    float* ep_ret;
+} MrsimState;
+
+/* Inputs / outputs of one step.  Optional pointers may be NULL. */
+typedef struct MrsimStepIO {
+    const float* actions;    /* [n][2] {f_t, alpha_t}  (MR_env.py:81-82).  NULL: draw the     */
+                             /*   random policy in-kernel (uniform in act_low..act_high)      */
+    float* actions_out;      /* optional [n][2]: the actions actually applied                 */
+    const float* goal_table; /* optional [K][T][2]                                            */
+    float* obs;              /* [n][5] or [5][n]: x, y, goal_x, goal_y, dist  (MR_env.py:100) */
+    float* rew;              /* [n]                                           (MR_env.py:89)  */
+    uint8_t* done;           /* [n]                                           (MR_env.py:136) */
+    float* state_prime;      /* optional [n][2]: Simulator.state_prime (MR_simulator.py:87)   */
+    float* final_obs;        /* optional, layout of obs: terminal obs where done && auto_reset */
+    float* final_ret;        /* optional [n]: episode return where done                       */
+    int32_t* final_len;      /* optional [n]: episode length where done                       */
+    int32_t* status;         /* optional [1]: OR-ed per-env flags; bit0 = RK45 attempt guard  */
+                             /*   tripped (the reference would raise "failed solver")         */
+} MrsimStepIO;
+
+int mrsim_abi_version(void);
+const char* mrsim_strerror(int code);
+
+/* MR_Env.__init__ constants + MR_Env.reset defaults (MR_env.py:34-45,56-63,164-170). */
+int mrsim_default_params(MrsimParams* p);
+
+/* MR_Env.reset(init, noise_var, a0, is_mismatched) for the envs whose mask byte is non-zero
+ * (mask NULL = all) -- MR_env.py:164-201 -> Simulator.reset_start_pos MR_simulator.py:21-34.
+ * init_xy: optional [n][2] fp64 start positions; NULL = init_space.sample() (MR_env.py:173).
+ * ctor_mismatched: law used by the RK45 constructor's two RHS evaluations inside reset
+ *   (0 on a fresh env: MR_env.py:181-183 sets is_mismatched AFTER reset_start_pos).
+ * obs: reset observation, layout per params (may be NULL). */
+int mrsim_reset(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
+                const uint8_t* mask, const double* init_xy, const float* goal_table, float* obs,
+                int32_t ctor_mismatched, uint64_t seed, uint64_t step_idx, void* stream);
+
+/* MR_Env.step(action) for n envs -- MR_env.py:70-98 -> Simulator.step MR_simulator.py:36-52
+ * (+ scipy RK45), convert_state :100-116, end :136-152, reward :89 / :118-134. */
+int mrsim_step(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
+               const MrsimStepIO* io, uint64_t seed, uint64_t step_idx, void* stream);
+
+/* Same launch bracketed by HIP events on `stream`; *kernel_ms_host = duration of the step
+ * kernel alone (synchronises the stream; measurement aid for bench.py, not a product path). */
+int mrsim_step_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
+                     const MrsimStepIO* io, uint64_t seed, uint64_t step_idx, void* stream,
+                     float* kernel_ms_host);
+
+/* Uniform random policy (the DDPG warm-up / exploration workload, RL/MR_ddpg.py:277):
+ * actions[n][2] ~ U[act_low, act_high). */
+int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float* actions,
+                        uint64_t seed, uint64_t step_idx, void* stream);
+
+/* Fused open-loop rollout, the batched utils.run_sim (utils.py:43-61): T steps of all n envs in
+ * one launch, state kept in registers.  actions: [T][n][2] per-env, or [T][2] shared by all envs
+ * when shared_actions != 0, or NULL for the in-kernel random policy.  Outputs (each optional):
+ * traj_xy [T][n][2] fp32 positions after each step, obs_T [T][n][5] / [T][5][n], rew_T [T][n],
+ * done_T [T][n].  Honors auto_reset.  step_idx0 .. step_idx0+T-1 are consumed. */
+int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
+                  int32_t T, const float* actions, int32_t shared_actions, const float* goal_table,
+                  float* traj_xy, float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T,
+                  int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream);
+
+/* Test aid: out[n][4] = the 4 standard normals of RNG call `c0` for envs env_id0..env_id0+n-1
+ * (bit-compared with the oracle's definition in tests/). */
+int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, uint32_t c0,
+                        float* out, void* stream);
+
+/* Number of HIP devices visible (0 without a GPU); fills name_host (may be NULL). */
+int mrsim_device_count(void);
+int mrsim_device_name(int device, char* name_host, int32_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRSIM_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of libmrsim.so (include/mrsim.h).  There is no fallback: if the
+HIP library is missing or a call fails, this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmrsim.so")
+
+OK, EINVAL, ENODEVICE, ELAUNCH, EALIGN, ERANGE = 0, -1, -2, -3, -4, -5
+INT_RK45, INT_EULER, INT_RK4 = 0, 1, 2
+REW_CONSTANT10, REW_GOAL = 0, 1
+OBS_AOS, OBS_SOA = 0, 1
+ABI_VERSION = 1
+
+# every symbol include/mrsim.h declares (tests check the .so exports exactly these)
+SYMBOLS = (
+    "mrsim_abi_version", "mrsim_strerror", "mrsim_default_params", "mrsim_reset", "mrsim_step",
+    "mrsim_step_timed", "mrsim_random_policy", "mrsim_rollout", "mrsim_debug_normals",
+    "mrsim_device_count", "mrsim_device_name",
+)
+
+
+class MrsimParams(C.Structure):
+    _fields_ = [
+        ("time_span", C.c_double), ("rtol", C.c_double), ("atol", C.c_double), ("a0", C.c_double),
+        ("sigma", C.c_double), ("min_dist2goal", C.c_double),
+        ("obs_low", C.c_double * 5), ("obs_high", C.c_double * 5),
+        ("init_low", C.c_double * 2), ("init_high", C.c_double * 2),
+        ("act_low", C.c_double * 2), ("act_high", C.c_double * 2),
+        ("mismatched", C.c_int32), ("integrator", C.c_int32), ("substeps", C.c_int32),
+        ("reward_mode", C.c_int32), ("max_timesteps", C.c_int32), ("auto_reset", C.c_int32),
+        ("goal_K", C.c_int32), ("goal_T", C.c_int32), ("obs_layout", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class MrsimState(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("aux", C.c_void_p), ("ep_ret", C.c_void_p)]
+
+
+class MrsimStepIO(C.Structure):
+    _fields_ = [
+        ("actions", C.c_void_p), ("actions_out", C.c_void_p), ("goal_table", C.c_void_p),
+        ("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("state_prime", C.c_void_p),
+        ("final_obs", C.c_void_p), ("final_ret", C.c_void_p), ("final_len", C.c_void_p),
+        ("status", C.c_void_p),
+    ]
+
+
+class MrsimError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(f"{what}: {strerror(code)} (MRSIM code {code})")
+
+
+_lib = None
+
+
+def lib():
+    """Load libmrsim.so (built by `make -C mr_rl_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C mr_rl_amd/csrc`. mr_rl_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, u32, u64, i32 = C.c_void_p, C.c_int64, C.c_uint32, C.c_uint64, C.c_int32
+    PP, PS, PIO = C.POINTER(MrsimParams), C.POINTER(MrsimState), C.POINTER(MrsimStepIO)
+    L.mrsim_abi_version.restype = C.c_int
+    L.mrsim_strerror.argtypes = [C.c_int]
+    L.mrsim_strerror.restype = C.c_char_p
+    L.mrsim_default_params.argtypes = [PP]
+    L.mrsim_reset.argtypes = [PP, i64, u32, PS, vp, vp, vp, vp, i32, u64, u64, vp]
+    L.mrsim_step.argtypes = [PP, i64, u32, PS, PIO, u64, u64, vp]
+    L.mrsim_step_timed.argtypes = [PP, i64, u32, PS, PIO, u64, u64, vp, C.POINTER(C.c_float)]
+    L.mrsim_random_policy.argtypes = [PP, i64, u32, vp, u64, u64, vp]
+    L.mrsim_rollout.argtypes = [PP, i64, u32, PS, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, u64, u64, vp]
+    L.mrsim_debug_normals.argtypes = [i64, u32, u64, u64, u32, vp, vp]
+    L.mrsim_device_count.restype = C.c_int
+    L.mrsim_device_name.argtypes = [C.c_int, C.c_char_p, i32]
+    for name in ("mrsim_default_params", "mrsim_reset", "mrsim_step", "mrsim_step_timed", "mrsim_random_policy",
+                 "mrsim_rollout", "mrsim_debug_normals", "mrsim_device_name"):
+        getattr(L, name).restype = C.c_int
+    if L.mrsim_abi_version() != ABI_VERSION:
+        raise ImportError(f"libmrsim.so ABI {L.mrsim_abi_version()} != binding ABI {ABI_VERSION}")
+    assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 10
+    _lib = L
+    return L
+
+
+def strerror(code):
+    return lib().mrsim_strerror(int(code)).decode()
+
+
+def check(code, what):
+    if code != OK:
+        raise MrsimError(code, what)
+
+
+def default_params():
+    p = MrsimParams()
+    check(lib().mrsim_default_params(C.byref(p)), "mrsim_default_params")
+    return p

@@ -1,0 +1,499 @@
+// mrsim_kernels.hip -- gfx950 kernels + the C ABI of include/mrsim.h.
+//
+// Kernels (all HBM-streaming maps over independent envs, one lane per env, no MFMA):
+//   mr_step_kernel     MR_Env.step for n envs            (MR_env.py:70-98)
+//   mr_reset_kernel    MR_Env.reset for masked envs      (MR_env.py:164-201)
+//   mr_policy_kernel   uniform random policy             (RL/MR_ddpg.py:277 exploration)
+//   mr_rollout_kernel  T fused steps, state in registers (utils.run_sim, utils.py:43-61)
+// Data layout: 16-byte records per env (pos = {x,y} fp64; aux = {f0x,f0y,hq,counter}) so each
+// wave moves 1 KiB per array per instruction; AoS observations [n][5] are transposed through
+// LDS and leave as dwordx4 stores.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "mrsim.h"
+#include "mrsim_device.h"
+
+namespace mrsim {
+
+struct StateArgs {
+    double* pos;
+    float* aux;
+    float* ep_ret;
+};
+
+struct IOArgs {
+    const float* actions;
+    float* actions_out;
+    const float* goal_table;
+    float* obs;
+    float* rew;
+    uint8_t* done;
+    float* state_prime;
+    float* final_obs;
+    float* final_ret;
+    int32_t* final_len;
+    int32_t* status;
+};
+
+// ---------------------------------------------------------------------------
+// step
+// ---------------------------------------------------------------------------
+template <bool RK45, bool NOISE, bool MIS, bool AOS>
+__global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const StateArgs st, const IOArgs io) {
+    __shared__ __attribute__((aligned(16))) float s_obs[AOS ? kBlock * 5 : 4];
+    const long long base = (long long)blockIdx.x * kBlock;
+    const long long i = base + threadIdx.x;
+    const bool active = i < P.n;
+    StepOut o;
+    if (active) {
+        EnvRegs e;
+        load_env(st.pos, st.aux, st.ep_ret, i, P, e);
+        const Rng R{P.seed_lo, P.seed_hi, P.step_lo, P.step_hi, P.env_id0 + (uint32_t)i};
+        float af, aa;
+        if (io.actions != nullptr) {
+            const float2 a = reinterpret_cast<const float2*>(io.actions)[i];
+            af = a.x; aa = a.y;
+        } else {
+            random_action(P, R, af, aa);
+        }
+        int fail = 0;
+        env_step<RK45, NOISE, MIS>(P, R, io.goal_table, e, af, aa, o, fail);
+        store_env(st.pos, st.aux, st.ep_ret, i, P, e);
+        io.rew[i] = o.rew;
+        io.done[i] = o.done;
+        if (io.actions_out != nullptr) reinterpret_cast<float2*>(io.actions_out)[i] = make_float2(af, aa);
+        if (io.state_prime != nullptr) reinterpret_cast<float2*>(io.state_prime)[i] = make_float2(o.spx, o.spy);
+        if (o.has_final) {
+            if (io.final_obs != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    if constexpr (AOS) io.final_obs[i * 5 + j] = o.fobs[j];
+                    else io.final_obs[(long long)j * P.n + i] = o.fobs[j];
+                }
+            }
+            if (io.final_ret != nullptr) io.final_ret[i] = o.fret;
+            if (io.final_len != nullptr) io.final_len[i] = o.flen;
+        }
+        if (fail && io.status != nullptr) atomicOr(io.status, fail);
+        if constexpr (!AOS) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) io.obs[(long long)j * P.n + i] = o.obs[j];
+        }
+    }
+    if constexpr (AOS) {
+        // observation packer: [n][5] rows leave the CU as 16-byte stores.  Row stride 5 dwords is
+        // coprime with the 32 LDS banks, so the transposing ds_write_b32 are conflict-free.
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) s_obs[threadIdx.x * 5 + j] = o.obs[j];
+        }
+        __syncthreads();
+        const long long rows = (P.n - base) < (long long)kBlock ? (P.n - base) : (long long)kBlock;
+        const int nvalid = (int)rows * 5;
+        float* __restrict__ dst = io.obs + base * 5;
+        for (int q = threadIdx.x * 4; q < nvalid; q += kBlock * 4) {
+            if (q + 4 <= nvalid) {
+                *reinterpret_cast<float4*>(dst + q) = *reinterpret_cast<const float4*>(s_obs + q);
+            } else {
+                for (int r = q; r < nvalid; ++r) dst[r] = s_obs[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// reset
+// ---------------------------------------------------------------------------
+template <bool RK45, bool NOISE, bool MIS_CTOR>
+__global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const StateArgs st,
+                                                          const uint8_t* __restrict__ mask,
+                                                          const double* __restrict__ init_xy,
+                                                          const float* __restrict__ goal_table,
+                                                          float* __restrict__ obs, int obs_layout) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    if (mask != nullptr && mask[i] == 0) return;
+    const Rng R{P.seed_lo, P.seed_hi, P.step_lo, P.step_hi, P.env_id0 + (uint32_t)i};
+    double x0, y0;
+    if (init_xy != nullptr) {
+        const double2 p = reinterpret_cast<const double2*>(init_xy)[i];
+        x0 = p.x; y0 = p.y;
+    } else {
+        sample_init(P, R, x0, y0);
+    }
+    EnvRegs e;
+    double spx, spy;
+    reset_env<RK45, NOISE, MIS_CTOR>(P, R, x0, y0, e, spx, spy);
+    store_env(st.pos, st.aux, st.ep_ret, i, P, e);
+    if (obs != nullptr) {
+        double gx, gy;
+        goal_at(P, goal_table, R.env, 0, gx, gy);
+        const double dx = gx - e.x, dy = gy - e.y;
+        const float v[5] = {(float)e.x, (float)e.y, (float)gx, (float)gy, __fsqrt_rn((float)(dx * dx + dy * dy))};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (obs_layout == MRSIM_OBS_AOS) obs[i * 5 + j] = v[j];
+            else obs[(long long)j * P.n + i] = v[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// random policy
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void mr_policy_kernel(const KParams P, float* __restrict__ actions) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    const Rng R{P.seed_lo, P.seed_hi, P.step_lo, P.step_hi, P.env_id0 + (uint32_t)i};
+    float f_t, al;
+    random_action(P, R, f_t, al);
+    reinterpret_cast<float2*>(actions)[i] = make_float2(f_t, al);
+}
+
+// ---------------------------------------------------------------------------
+// fused rollout: T steps, state in registers
+// ---------------------------------------------------------------------------
+struct RolloutArgs {
+    int32_t T;
+    int32_t shared_actions;
+    int32_t obs_layout;
+    int32_t pad;
+    const float* actions;
+    const float* goal_table;
+    float* traj_xy;
+    float* obs_T;
+    float* rew_T;
+    uint8_t* done_T;
+    float* actions_out_T;
+    int32_t* status;
+};
+
+template <bool RK45, bool NOISE, bool MIS>
+__global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, const StateArgs st, const RolloutArgs ra) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    EnvRegs e;
+    load_env(st.pos, st.aux, st.ep_ret, i, P, e);
+    Rng R{P.seed_lo, P.seed_hi, P.step_lo, P.step_hi, P.env_id0 + (uint32_t)i};
+    int fail = 0;
+    for (int t = 0; t < ra.T; ++t) {
+        const unsigned long long step = (((unsigned long long)P.step_hi << 32) | P.step_lo) + (unsigned long long)t;
+        R.step_lo = (uint32_t)step;
+        R.step_hi = (uint32_t)(step >> 32);
+        float af, aa;
+        if (ra.actions == nullptr) {
+            random_action(P, R, af, aa);
+        } else if (ra.shared_actions) {
+            const float2 a = reinterpret_cast<const float2*>(ra.actions)[t];
+            af = a.x; aa = a.y;
+        } else {
+            const float2 a = reinterpret_cast<const float2*>(ra.actions)[(long long)t * P.n + i];
+            af = a.x; aa = a.y;
+        }
+        StepOut o;
+        env_step<RK45, NOISE, MIS>(P, R, ra.goal_table, e, af, aa, o, fail);
+        quantise_env(P, e);
+        const long long ti = (long long)t * P.n + i;
+        if (ra.traj_xy != nullptr) {
+            // position AFTER the step and BEFORE any auto-reset == what run_sim records (utils.py:53)
+            const float px = o.has_final ? o.fobs[0] : o.obs[0];
+            const float py = o.has_final ? o.fobs[1] : o.obs[1];
+            reinterpret_cast<float2*>(ra.traj_xy)[ti] = make_float2(px, py);
+        }
+        if (ra.obs_T != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (ra.obs_layout == MRSIM_OBS_AOS) ra.obs_T[ti * 5 + j] = o.obs[j];
+                else ra.obs_T[((long long)t * 5 + j) * P.n + i] = o.obs[j];
+            }
+        }
+        if (ra.rew_T != nullptr) ra.rew_T[ti] = o.rew;
+        if (ra.done_T != nullptr) ra.done_T[ti] = o.done;
+        if (ra.actions_out_T != nullptr) reinterpret_cast<float2*>(ra.actions_out_T)[ti] = make_float2(af, aa);
+    }
+    store_env(st.pos, st.aux, st.ep_ret, i, P, e);
+    if (fail && ra.status != nullptr) atomicOr(ra.status, fail);
+}
+
+// ---------------------------------------------------------------------------
+// debug / test aid: raw normals of the RNG definition (bit-compared with the oracle)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void mr_debug_normals_kernel(const KParams P, uint32_t c0, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    const Rng R{P.seed_lo, P.seed_hi, P.step_lo, P.step_hi, P.env_id0 + (uint32_t)i};
+    float z[4];
+    block_normals<1>(R, c0, z);
+    reinterpret_cast<float4*>(out)[i] = make_float4(z[0], z[1], z[2], z[3]);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx,
+                        KParams& K) {
+    if (p == nullptr || n < 0) return MRSIM_EINVAL;
+    if (n > 0xFFFFFFFFll || (uint64_t)env_id0 + (uint64_t)n > 0x100000000ull) return MRSIM_ERANGE;
+    if (!(p->time_span > 0.0) || !(p->rtol > 0.0) || !(p->atol >= 0.0)) return MRSIM_EINVAL;
+    if (p->integrator < MRSIM_INT_RK45 || p->integrator > MRSIM_INT_RK4) return MRSIM_EINVAL;
+    if (p->reward_mode != MRSIM_REW_CONSTANT10 && p->reward_mode != MRSIM_REW_GOAL) return MRSIM_EINVAL;
+    if (p->obs_layout != MRSIM_OBS_AOS && p->obs_layout != MRSIM_OBS_SOA) return MRSIM_EINVAL;
+    if (p->integrator != MRSIM_INT_RK45 && (p->substeps < 1 || p->substeps > (1 << 20))) return MRSIM_EINVAL;
+    if (p->sigma < 0.0 || std::isnan(p->sigma)) return MRSIM_EINVAL;
+    std::memset(&K, 0, sizeof(K));
+    K.dt = p->time_span; K.rtol = p->rtol; K.atol = p->atol; K.a0 = p->a0;
+    K.sigma = p->sigma; K.sigma4 = p->sigma / 4;
+    K.min_dist2 = p->min_dist2goal * p->min_dist2goal;
+    for (int j = 0; j < 5; ++j) { K.obs_lo[j] = p->obs_low[j]; K.obs_hi[j] = p->obs_high[j]; }
+    K.dmax2 = p->obs_high[4] * p->obs_high[4];
+    for (int j = 0; j < 2; ++j) {
+        K.init_lo[j] = p->init_low[j]; K.init_span[j] = p->init_high[j] - p->init_low[j];
+        K.act_lo[j] = p->act_low[j]; K.act_span[j] = p->act_high[j] - p->act_low[j];
+    }
+    K.h1_thresh = 0.01 / std::pow(p->time_span, 5.0);
+    K.h1_thresh2_f = (float)(K.h1_thresh * K.h1_thresh);
+    K.dt2_f = (float)(p->time_span * p->time_span);
+    K.substeps = p->substeps; K.reward_mode = p->reward_mode; K.max_timesteps = p->max_timesteps;
+    K.auto_reset = p->auto_reset; K.goal_K = p->goal_K; K.goal_T = p->goal_T; K.integrator = p->integrator;
+    K.seed_lo = (uint32_t)seed; K.seed_hi = (uint32_t)(seed >> 32);
+    K.step_lo = (uint32_t)step_idx; K.step_hi = (uint32_t)(step_idx >> 32);
+    K.env_id0 = env_id0;
+    K.n = n;
+    return MRSIM_OK;
+}
+
+static int check_device() {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+        (void)hipGetLastError();
+        return MRSIM_ENODEVICE;
+    }
+    return MRSIM_OK;
+}
+
+static int check_state(const MrsimState* st) {
+    if (st == nullptr || st->pos == nullptr || st->aux == nullptr || st->ep_ret == nullptr) return MRSIM_EINVAL;
+    if (!aligned16(st->pos) || !aligned16(st->aux)) return MRSIM_EALIGN;
+    return MRSIM_OK;
+}
+
+struct LaunchCfg {
+    hipStream_t stream;
+    hipEvent_t start, stop;  // both null: plain launch
+};
+
+template <typename Kern, typename... Args>
+static int launch(const LaunchCfg& lc, Kern kern, long long n, Args... args) {
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    if (grid == 0) return MRSIM_OK;
+    if (lc.start != nullptr) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, lc.stream, lc.start, lc.stop, 0, args...);
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, lc.stream, args...);
+    return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+}
+
+template <bool RK45, bool NOISE, bool MIS>
+static int launch_step_l(const LaunchCfg& lc, bool aos, const KParams& K, const StateArgs& S, const IOArgs& IO) {
+    if (aos) return launch(lc, mr_step_kernel<RK45, NOISE, MIS, true>, K.n, K, S, IO);
+    return launch(lc, mr_step_kernel<RK45, NOISE, MIS, false>, K.n, K, S, IO);
+}
+
+template <bool RK45, bool NOISE>
+static int launch_step_m(const LaunchCfg& lc, bool mis, bool aos, const KParams& K, const StateArgs& S, const IOArgs& IO) {
+    return mis ? launch_step_l<RK45, NOISE, true>(lc, aos, K, S, IO) : launch_step_l<RK45, NOISE, false>(lc, aos, K, S, IO);
+}
+
+static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams& K, const StateArgs& S, const IOArgs& IO) {
+    const bool rk45 = p->integrator == MRSIM_INT_RK45, noise = p->sigma != 0.0, mis = p->mismatched != 0;
+    const bool aos = p->obs_layout == MRSIM_OBS_AOS;
+    if (rk45) return noise ? launch_step_m<true, true>(lc, mis, aos, K, S, IO) : launch_step_m<true, false>(lc, mis, aos, K, S, IO);
+    return noise ? launch_step_m<false, true>(lc, mis, aos, K, S, IO) : launch_step_m<false, false>(lc, mis, aos, K, S, IO);
+}
+
+static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, const MrsimStepIO* io,
+                     uint64_t seed, uint64_t step_idx, void* stream, float* kernel_ms) {
+    KParams K;
+    int rc = make_kparams(p, n, env_id0, seed, step_idx, K);
+    if (rc) return rc;
+    if ((rc = check_state(st))) return rc;
+    if (io == nullptr || io->obs == nullptr || io->rew == nullptr || io->done == nullptr) return MRSIM_EINVAL;
+    if (!aligned16(io->obs) || (io->actions && !aligned16(io->actions))) return MRSIM_EALIGN;
+    if (io->goal_table != nullptr && (p->goal_K < 1 || p->goal_T < 1)) return MRSIM_EINVAL;
+    if ((rc = check_device())) return rc;
+    const StateArgs S{st->pos, st->aux, st->ep_ret};
+    const IOArgs IO{io->actions, io->actions_out, io->goal_table, io->obs, io->rew, io->done, io->state_prime,
+                    io->final_obs, io->final_ret, io->final_len, io->status};
+    LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    if (kernel_ms == nullptr) return launch_step(lc, p, K, S, IO);
+    // timed variant: events attached to this one dispatch (hipExtLaunchKernelGGL)
+    if (hipEventCreate(&lc.start) != hipSuccess || hipEventCreate(&lc.stop) != hipSuccess) return MRSIM_ELAUNCH;
+    rc = launch_step(lc, p, K, S, IO);
+    if (rc == MRSIM_OK) {
+        if (hipEventSynchronize(lc.stop) != hipSuccess || hipEventElapsedTime(kernel_ms, lc.start, lc.stop) != hipSuccess)
+            rc = MRSIM_ELAUNCH;
+    }
+    (void)hipEventDestroy(lc.start);
+    (void)hipEventDestroy(lc.stop);
+    return rc;
+}
+
+template <bool RK45, bool NOISE>
+static int launch_reset_m(const LaunchCfg& lc, bool mis, const KParams& K, const StateArgs& S, const uint8_t* mask,
+                          const double* init_xy, const float* goal_table, float* obs, int layout) {
+    if (mis) return launch(lc, mr_reset_kernel<RK45, NOISE, true>, K.n, K, S, mask, init_xy, goal_table, obs, layout);
+    return launch(lc, mr_reset_kernel<RK45, NOISE, false>, K.n, K, S, mask, init_xy, goal_table, obs, layout);
+}
+
+template <bool RK45, bool NOISE>
+static int launch_rollout_m(const LaunchCfg& lc, bool mis, const KParams& K, const StateArgs& S, const RolloutArgs& ra) {
+    if (mis) return launch(lc, mr_rollout_kernel<RK45, NOISE, true>, K.n, K, S, ra);
+    return launch(lc, mr_rollout_kernel<RK45, NOISE, false>, K.n, K, S, ra);
+}
+
+}  // namespace mrsim
+
+using namespace mrsim;
+
+extern "C" {
+
+int mrsim_abi_version(void) { return MRSIM_ABI_VERSION; }
+
+const char* mrsim_strerror(int code) {
+    switch (code) {
+        case MRSIM_OK: return "ok";
+        case MRSIM_EINVAL: return "invalid argument";
+        case MRSIM_ENODEVICE: return "no HIP device (libmrsim has no CPU fallback)";
+        case MRSIM_ELAUNCH: return "HIP launch/runtime error";
+        case MRSIM_EALIGN: return "buffer not 16-byte aligned";
+        case MRSIM_ERANGE: return "n / env ids exceed 2^32";
+        default: return "unknown error";
+    }
+}
+
+int mrsim_default_params(MrsimParams* p) {
+    if (p == nullptr) return MRSIM_EINVAL;
+    std::memset(p, 0, sizeof(*p));
+    p->time_span = 0.030;            // MR_simulator.py:12
+    p->rtol = p->time_span / 100;    // MR_simulator.py:13,91
+    p->atol = 1e-4;                  // MR_simulator.py:91
+    p->a0 = 1.0;                     // MR_env.py:168
+    p->sigma = 1.0;                  // MR_env.py:167
+    p->min_dist2goal = 30.0;         // MR_env.py:63
+    const double lo[5] = {-5000, -5000, -5000, -5000, 0}, hi[5] = {5000, 5000, 5000, 5000, 80000};  // MR_env.py:38-39
+    for (int j = 0; j < 5; ++j) { p->obs_low[j] = lo[j]; p->obs_high[j] = hi[j]; }
+    p->init_low[0] = p->init_low[1] = 100.0;    // MR_env.py:41
+    p->init_high[0] = p->init_high[1] = 120.0;  // MR_env.py:42
+    p->act_low[0] = -20.0; p->act_high[0] = 20.0;  // RL/MR_ddpg.py:136-137,345 (tanh * action_bound)
+    p->act_low[1] = -2 * M_PI; p->act_high[1] = 2 * M_PI;
+    p->mismatched = 0;
+    p->integrator = MRSIM_INT_RK45;
+    p->substeps = 1;
+    p->reward_mode = MRSIM_REW_CONSTANT10;  // MR_env.py:89
+    p->max_timesteps = 50;                  // MR_env.py:62
+    p->auto_reset = 0;
+    p->goal_K = 1; p->goal_T = 1;
+    p->obs_layout = MRSIM_OBS_AOS;
+    return MRSIM_OK;
+}
+
+int mrsim_reset(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, const uint8_t* mask,
+                const double* init_xy, const float* goal_table, float* obs, int32_t ctor_mismatched, uint64_t seed,
+                uint64_t step_idx, void* stream) {
+    KParams K;
+    int rc = make_kparams(p, n, env_id0, seed, step_idx, K);
+    if (rc) return rc;
+    if ((rc = check_state(st))) return rc;
+    if (init_xy != nullptr && !aligned16(init_xy)) return MRSIM_EALIGN;
+    if (goal_table != nullptr && (p->goal_K < 1 || p->goal_T < 1)) return MRSIM_EINVAL;
+    if ((rc = check_device())) return rc;
+    const StateArgs S{st->pos, st->aux, st->ep_ret};
+    const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    const bool rk45 = p->integrator == MRSIM_INT_RK45, noise = p->sigma != 0.0, mis = ctor_mismatched != 0;
+    if (rk45)
+        return noise ? launch_reset_m<true, true>(lc, mis, K, S, mask, init_xy, goal_table, obs, p->obs_layout)
+                     : launch_reset_m<true, false>(lc, mis, K, S, mask, init_xy, goal_table, obs, p->obs_layout);
+    return launch_reset_m<false, false>(lc, false, K, S, mask, init_xy, goal_table, obs, p->obs_layout);
+}
+
+int mrsim_step(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, const MrsimStepIO* io,
+               uint64_t seed, uint64_t step_idx, void* stream) {
+    return step_impl(p, n, env_id0, st, io, seed, step_idx, stream, nullptr);
+}
+
+int mrsim_step_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, const MrsimStepIO* io,
+                     uint64_t seed, uint64_t step_idx, void* stream, float* kernel_ms_host) {
+    if (kernel_ms_host == nullptr) return MRSIM_EINVAL;
+    return step_impl(p, n, env_id0, st, io, seed, step_idx, stream, kernel_ms_host);
+}
+
+int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float* actions, uint64_t seed,
+                        uint64_t step_idx, void* stream) {
+    KParams K;
+    int rc = make_kparams(p, n, env_id0, seed, step_idx, K);
+    if (rc) return rc;
+    if (actions == nullptr) return MRSIM_EINVAL;
+    if (!aligned16(actions)) return MRSIM_EALIGN;
+    if ((rc = check_device())) return rc;
+    const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    return launch(lc, mr_policy_kernel, K.n, K, actions);
+}
+
+int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
+                  const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy, float* obs_T,
+                  float* rew_T, uint8_t* done_T, float* actions_out_T, int32_t* status, uint64_t seed,
+                  uint64_t step_idx0, void* stream) {
+    KParams K;
+    int rc = make_kparams(p, n, env_id0, seed, step_idx0, K);
+    if (rc) return rc;
+    if ((rc = check_state(st))) return rc;
+    if (T < 0) return MRSIM_EINVAL;
+    if (T == 0) return MRSIM_OK;
+    if ((actions && !aligned16(actions)) || (traj_xy && !aligned16(traj_xy)) || (actions_out_T && !aligned16(actions_out_T)))
+        return MRSIM_EALIGN;
+    if (goal_table != nullptr && (p->goal_K < 1 || p->goal_T < 1)) return MRSIM_EINVAL;
+    if ((rc = check_device())) return rc;
+    const StateArgs S{st->pos, st->aux, st->ep_ret};
+    const RolloutArgs ra{T, shared_actions, p->obs_layout, 0, actions, goal_table, traj_xy, obs_T, rew_T, done_T,
+                         actions_out_T, status};
+    const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    const bool rk45 = p->integrator == MRSIM_INT_RK45, noise = p->sigma != 0.0, mis = p->mismatched != 0;
+    if (rk45) return noise ? launch_rollout_m<true, true>(lc, mis, K, S, ra) : launch_rollout_m<true, false>(lc, mis, K, S, ra);
+    return noise ? launch_rollout_m<false, true>(lc, mis, K, S, ra) : launch_rollout_m<false, false>(lc, mis, K, S, ra);
+}
+
+int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, uint32_t c0, float* out,
+                        void* stream) {
+    MrsimParams p;
+    mrsim_default_params(&p);
+    KParams K;
+    int rc = make_kparams(&p, n, env_id0, seed, step_idx, K);
+    if (rc) return rc;
+    if (out == nullptr) return MRSIM_EINVAL;
+    if (!aligned16(out)) return MRSIM_EALIGN;
+    if ((rc = check_device())) return rc;
+    const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    return launch(lc, mr_debug_normals_kernel, K.n, K, c0, out);
+}
+
+int mrsim_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return cnt;
+}
+
+int mrsim_device_name(int device, char* name_host, int32_t len) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return MRSIM_ENODEVICE; }
+    if (name_host != nullptr && len > 0) {
+        std::snprintf(name_host, (size_t)len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    }
+    return MRSIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+"""MRVecEnv: N micro-robot environments advanced in lockstep by the HIP step kernel.
+
+Host-side mirror of the reference's gym API (class MR_Env, MR_env.py:21-229) for a
+batch: same method names, argument meaning and defaults, tensors instead of scalars.
+All compute happens in libmrsim.so on the GPU; torch is only the owner of device
+memory and streams.  There is no CPU path: constructing an env without a HIP device
+raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .config import MRConfig
+from .spaces import make_box
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class SimulatorView:
+    """`env.simulator.{noise_var,a0,is_mismatched,state_prime}` as the reference exposes them
+    (MR_env.py:179-183, utils.py:54)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    noise_var = property(lambda s: s._env.cfg.noise_var)
+    a0 = property(lambda s: s._env.cfg.a0)
+    is_mismatched = property(lambda s: s._env.cfg.is_mismatched)
+    state_prime = property(lambda s: s._env.state_prime)
+
+
+class MRVecEnv:
+    """N independent MR_Env instances on one GPU.
+
+    reset(mask=None, init=None, noise_var=None, a0=None, is_mismatched=None) -> obs[N,5]
+    step(actions[N,2] | None) -> (obs[N,5] f32, rew[N] f32, done[N] bool, info)
+
+    env_id0 / seed make the RNG stream a function of the GLOBAL env id, so a shard of a
+    larger job reproduces exactly the trajectories the unsharded job would produce.
+    """
+
+    metadata = {"render.modes": []}
+
+    def __init__(self, num_envs, cfg=None, device="cuda", seed=None, env_id0=0, goal_table=None,
+                 track_state_prime=False, track_actions=False):
+        torch = _torch()
+        self._L = _lib.lib()  # raises ImportError if the HIP extension is not built
+        if not torch.cuda.is_available() or self._L.mrsim_device_count() <= 0:
+            raise RuntimeError("MRVecEnv needs a HIP device (MI355X); mr_rl_amd has no CPU fallback")
+        self.cfg = cfg if cfg is not None else MRConfig()
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("MRVecEnv: device must be a cuda(HIP) device")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.seed_value = int(self.cfg.seed if seed is None else seed)
+        self.env_id0 = int(env_id0)
+        self.step_idx = 0  # global RNG step index; every reset()/step() call consumes one
+        n, dev = self.num_envs, self.device
+
+        # spaces (MR_env.py:34-45)
+        self.action_space = make_box(self.cfg.action_low, self.cfg.action_high)
+        self.observation_space = make_box(self.cfg.obs_low, self.cfg.obs_high)
+        self.init_space = make_box(self.cfg.init_low, self.cfg.init_high)
+        self.max_timesteps = self.cfg.max_timesteps
+        self.min_dist2goal = self.cfg.min_dist2goal
+
+        # goal / reference-trajectory table [K][T][2]; None = MR_Env.init_goal = (0,0) (MR_env.py:57)
+        self.goal_table = None
+        self._gK = self._gT = 1
+        if goal_table is not None:
+            g = torch.as_tensor(goal_table, dtype=torch.float32, device=dev).contiguous()
+            if g.dim() == 2:
+                g = g.unsqueeze(0)
+            assert g.dim() == 3 and g.shape[2] == 2, "goal_table must be [K][T][2]"
+            self.goal_table, self._gK, self._gT = g, int(g.shape[0]), int(g.shape[1])
+        self.init_goal = np.zeros(2)
+
+        # persistent state (include/mrsim.h: MrsimState)
+        self.pos = torch.zeros((n, 2), dtype=torch.float64, device=dev)   # == last_pos
+        self.aux = torch.zeros((n, 4), dtype=torch.float32, device=dev)   # f0x, f0y, h_abs/dt, counter(bits)
+        self.aux[:, 2] = 1.0
+        self.ep_ret = torch.zeros(n, dtype=torch.float32, device=dev)
+        # step outputs
+        self._soa = self.cfg.obs_layout == "soa"
+        oshape = (5, n) if self._soa else (n, 5)
+        self._obs = torch.zeros(oshape, dtype=torch.float32, device=dev)
+        self._final_obs = torch.zeros(oshape, dtype=torch.float32, device=dev)
+        self.rew = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._done_u8 = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.final_ret = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.final_len = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._state_prime = torch.zeros((n, 2), dtype=torch.float32, device=dev) if track_state_prime else None
+        self._actions_out = torch.zeros((n, 2), dtype=torch.float32, device=dev) if track_actions else None
+        self.last_action = None
+        self._prev_mismatched = False  # what Simulator.is_mismatched was before the latest reset (MR_env.py:181-183)
+        self._params = None
+        self._refresh_params()
+        self._st = _lib.MrsimState(self.pos.data_ptr(), self.aux.data_ptr(), self.ep_ret.data_ptr())
+        self.simulator = SimulatorView(self)
+
+    # ------------------------------------------------------------------ helpers
+    def _refresh_params(self):
+        self._params = self.cfg.to_params(self._gK, self._gT)
+
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def _view(self, t):
+        return t.t() if self._soa else t
+
+    @property
+    def obs(self):
+        return self._view(self._obs)
+
+    @property
+    def final_obs(self):
+        return self._view(self._final_obs)
+
+    @property
+    def done(self):
+        return self._done_u8.view(_torch().bool)
+
+    @property
+    def last_pos(self):
+        """[N,2] fp64 positions (MR_Env.last_pos, MR_env.py:91; read by utils.run_sim)."""
+        return self.pos
+
+    @property
+    def counter(self):
+        return self.aux[:, 3].view(_torch().int32)
+
+    @property
+    def state_prime(self):
+        if self._state_prime is None:
+            raise AttributeError("construct MRVecEnv(track_state_prime=True) to record Simulator.state_prime")
+        return self._state_prime
+
+    def seed(self, seed=None):
+        """keras-rl era callers use env.seed(n) (old/MR_dqn_keras_rl.py:19)."""
+        if seed is not None:
+            self.seed_value = int(seed)
+        return [self.seed_value]
+
+    # ------------------------------------------------------------------ gym API
+    def reset(self, mask=None, init=None, noise_var=None, a0=None, is_mismatched=None):
+        """MR_Env.reset for the masked envs (all when mask is None).  kwargs left at None keep the
+        current cfg (the reference's defaults noise_var=1, a0=1, is_mismatched=False are MRConfig's)."""
+        torch = _torch()
+        if noise_var is not None:
+            self.cfg.noise_var = float(noise_var)
+        if a0 is not None:
+            self.cfg.a0 = float(a0)
+        ctor_mis = self._prev_mismatched
+        if is_mismatched is not None:
+            self.cfg.is_mismatched = bool(is_mismatched)
+        self._prev_mismatched = self.cfg.is_mismatched
+        self._refresh_params()
+        mask_t = None
+        if mask is not None:
+            mask_t = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            assert mask_t.shape == (self.num_envs,)
+        init_t = None
+        if init is not None:
+            init_t = torch.as_tensor(init, dtype=torch.float64, device=self.device)
+            if init_t.dim() == 1:
+                init_t = init_t.expand(self.num_envs, 2)
+            init_t = init_t.contiguous()
+            assert init_t.shape == (self.num_envs, 2)
+        rc = self._L.mrsim_reset(C.byref(self._params), self.num_envs, self.env_id0, C.byref(self._st),
+                                 self._p(mask_t), self._p(init_t), self._p(self.goal_table), self._p(self._obs),
+                                 int(ctor_mis), self.seed_value, self.step_idx, self._stream())
+        _lib.check(rc, "mrsim_reset")
+        self.step_idx += 1
+        return self.obs
+
+    def step(self, actions=None):
+        """MR_Env.step for all envs.  actions: [N,2] float32 device tensor {f_t, alpha_t}, or None to
+        draw the uniform random policy in-kernel (cfg.policy_low/high)."""
+        torch = _torch()
+        act_t = None
+        if actions is not None:
+            act_t = actions if (torch.is_tensor(actions) and actions.dtype == torch.float32 and
+                                actions.device == self.device and actions.is_contiguous()) else \
+                torch.as_tensor(actions, dtype=torch.float32, device=self.device).contiguous()
+            if act_t.shape != (self.num_envs, 2):
+                raise IndexError(f"actions must have shape ({self.num_envs}, 2), got {tuple(act_t.shape)}")
+            self.last_action = act_t
+        elif self._actions_out is not None:
+            self.last_action = self._actions_out
+        io = _lib.MrsimStepIO(
+            self._p(act_t), self._p(self._actions_out), self._p(self.goal_table), self._p(self._obs),
+            self._p(self.rew), self._p(self._done_u8), self._p(self._state_prime), self._p(self._final_obs),
+            self._p(self.final_ret), self._p(self.final_len), self._p(self.status))
+        rc = self._L.mrsim_step(C.byref(self._params), self.num_envs, self.env_id0, C.byref(self._st), C.byref(io),
+                                self.seed_value, self.step_idx, self._stream())
+        _lib.check(rc, "mrsim_step")
+        self.step_idx += 1
+        info = {}
+        if self.cfg.auto_reset:
+            info = {"final_obs": self.final_obs, "final_ret": self.final_ret, "final_len": self.final_len}
+        return self.obs, self.rew, self.done, info
+
+    def step_timed(self, actions=None):
+        """One step whose kernel duration (ms) is measured with HIP events attached to the dispatch.
+        Measurement aid for bench.py; synchronises the stream."""
+        torch = _torch()
+        act_t = None if actions is None else torch.as_tensor(actions, dtype=torch.float32, device=self.device).contiguous()
+        io = _lib.MrsimStepIO(
+            self._p(act_t), self._p(self._actions_out), self._p(self.goal_table), self._p(self._obs),
+            self._p(self.rew), self._p(self._done_u8), self._p(self._state_prime), self._p(self._final_obs),
+            self._p(self.final_ret), self._p(self.final_len), self._p(self.status))
+        ms = C.c_float(0.0)
+        rc = self._L.mrsim_step_timed(C.byref(self._params), self.num_envs, self.env_id0, C.byref(self._st),
+                                      C.byref(io), self.seed_value, self.step_idx, self._stream(), C.byref(ms))
+        _lib.check(rc, "mrsim_step_timed")
+        self.step_idx += 1
+        return ms.value
+
+    def random_policy(self, out=None):
+        """actions[N,2] ~ U[policy_low, policy_high) on device (consumes no step index: it is keyed by the
+        step it feeds)."""
+        torch = _torch()
+        if out is None:
+            out = torch.empty((self.num_envs, 2), dtype=torch.float32, device=self.device)
+        rc = self._L.mrsim_random_policy(C.byref(self._params), self.num_envs, self.env_id0, self._p(out),
+                                         self.seed_value, self.step_idx, self._stream())
+        _lib.check(rc, "mrsim_random_policy")
+        return out
+
+    def rollout(self, T, actions=None, shared_actions=False, want=("traj",)):
+        """T fused steps in one launch (batched utils.run_sim).  actions: [T,N,2], or [T,2] with
+        shared_actions=True, or None for the on-device random policy.  Returns a dict of [T,...] tensors."""
+        torch = _torch()
+        n, dev = self.num_envs, self.device
+        act_t = None
+        if actions is not None:
+            act_t = torch.as_tensor(actions, dtype=torch.float32, device=dev).contiguous()
+            assert act_t.shape == ((T, 2) if shared_actions else (T, n, 2))
+        out = {}
+        traj = torch.empty((T, n, 2), dtype=torch.float32, device=dev) if "traj" in want else None
+        obs_T = torch.empty((T, 5, n) if self._soa else (T, n, 5), dtype=torch.float32, device=dev) if "obs" in want else None
+        rew_T = torch.empty((T, n), dtype=torch.float32, device=dev) if "rew" in want else None
+        done_T = torch.empty((T, n), dtype=torch.uint8, device=dev) if "done" in want else None
+        acts_T = torch.empty((T, n, 2), dtype=torch.float32, device=dev) if "actions" in want else None
+        rc = self._L.mrsim_rollout(C.byref(self._params), n, self.env_id0, C.byref(self._st), int(T), self._p(act_t),
+                                   int(bool(shared_actions)), self._p(self.goal_table), self._p(traj), self._p(obs_T),
+                                   self._p(rew_T), self._p(done_T), self._p(acts_T), self._p(self.status),
+                                   self.seed_value, self.step_idx, self._stream())
+        _lib.check(rc, "mrsim_rollout")
+        self.step_idx += int(T)
+        if traj is not None:
+            out["traj"] = traj
+        if obs_T is not None:
+            out["obs"] = obs_T.transpose(1, 2) if self._soa else obs_T
+        if rew_T is not None:
+            out["rew"] = rew_T
+        if done_T is not None:
+            out["done"] = done_T.view(torch.bool)
+        if acts_T is not None:
+            out["actions"] = acts_T
+        return out
+
+    def check_status(self):
+        """Synchronising check of the device status word (bit0: an env's RK45 attempt guard tripped --
+        the reference would have raised on a failed solver)."""
+        s = int(self.status.item())
+        if s:
+            raise RuntimeError(f"mrsim device status 0x{s:x}: RK45 step-size control failed in at least one env")
+        return s
+
+    # ------------------------------------------------------------------ reference API odds and ends
+    def render(self, mode="human"):
+        return None  # GUI (turtle viewer, MR_viewer.py) is out of scope
+
+    def close(self):
+        return None
+
+    def set_init_space(self, low, high):
+        """MR_env.py:154-155."""
+        self.cfg.init_low, self.cfg.init_high = tuple(float(x) for x in low), tuple(float(x) for x in high)
+        self.init_space = make_box(self.cfg.init_low, self.cfg.init_high)
+        self._refresh_params()
+
+    def set_goal(self, init=None):
+        """MR_env.py:157-162 -- a no-op returning init_goal."""
+        return self.init_goal
+
+    # ------------------------------------------------------------------ checkpoint
+    def state_dict(self):
+        return {"pos": self.pos.clone(), "aux": self.aux.clone(), "ep_ret": self.ep_ret.clone(),
+                "step_idx": self.step_idx, "seed": self.seed_value, "env_id0": self.env_id0,
+                "prev_mismatched": self._prev_mismatched}
+
+    def load_state_dict(self, sd):
+        self.pos.copy_(sd["pos"]); self.aux.copy_(sd["aux"]); self.ep_ret.copy_(sd["ep_ret"])
+        self.step_idx, self.seed_value, self.env_id0 = int(sd["step_idx"]), int(sd["seed"]), int(sd["env_id0"])
+        self._prev_mismatched = bool(sd["prev_mismatched"])

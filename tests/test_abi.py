@@ -1,0 +1,90 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mrsim.h declares; host-side logic."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    h = open(os.path.join(ROOT, "include", "mrsim.h")).read()
+    return sorted(set(re.findall(r"\b(mrsim_[a-z_0-9]+)\s*\(", h)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    from mr_rl_amd import _lib
+    L = _lib.lib()
+    declared = _declared_symbols()
+    assert declared, "no declarations parsed"
+    for s in declared:
+        assert hasattr(L, s), f"libmrsim.so does not export {s}"
+    assert sorted(_lib.SYMBOLS) == declared
+    assert L.mrsim_abi_version() == _lib.ABI_VERSION
+
+
+def test_default_params_match_reference_constants():
+    from mr_rl_amd import _lib
+    p = _lib.default_params()
+    assert p.time_span == 0.030 and p.rtol == 0.030 / 100 and p.atol == 1e-4   # MR_simulator.py:12-13,91
+    assert p.a0 == 1.0 and p.sigma == 1.0 and p.mismatched == 0                 # MR_env.py:167-169
+    assert p.max_timesteps == 50 and p.min_dist2goal == 30.0                    # MR_env.py:62-63
+    assert list(p.obs_low) == [-5000, -5000, -5000, -5000, 0] and list(p.obs_high) == [5000] * 4 + [80000]
+    assert list(p.init_low) == [100, 100] and list(p.init_high) == [120, 120]
+    assert p.integrator == _lib.INT_RK45 and p.reward_mode == _lib.REW_CONSTANT10 and p.auto_reset == 0
+
+
+def test_struct_layouts_match_oracle_defaults():
+    """MRConfig -> MrsimParams and the oracle's OrcParams agree on every shared field."""
+    from mr_rl_amd import MRConfig
+    from oracle import oracle as O
+    from tests.util import orc_params_from_cfg
+    cfg = MRConfig(noise_var=0.5, a0=1.5, is_mismatched=True, integrator="rk4", substeps=4, reward_mode="goal",
+                   auto_reset=True)
+    p, q = cfg.to_params(3, 7), orc_params_from_cfg(cfg, 3, 7)
+    for f in ("time_span", "rtol", "atol", "a0", "sigma", "min_dist2goal", "mismatched", "integrator", "substeps",
+              "reward_mode", "max_timesteps", "auto_reset", "goal_K", "goal_T"):
+        assert getattr(p, f) == getattr(q, f), f
+    for f in ("obs_low", "obs_high", "init_low", "init_high"):
+        assert list(getattr(p, f)) == list(getattr(q, f)), f
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    """Without a GPU every compute entry point must refuse (no CPU path)."""
+    import torch
+    from mr_rl_amd import _lib, MRVecEnv
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib.lib()
+    assert L.mrsim_device_count() == 0
+    p = _lib.default_params()
+    buf = np.zeros(64, dtype=np.float64)
+    st = _lib.MrsimState(buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)
+    io = _lib.MrsimStepIO(None, None, None, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data, None, None, None,
+                          None, None)
+    assert L.mrsim_step(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.ENODEVICE
+    assert L.mrsim_reset(C.byref(p), 4, 0, C.byref(st), None, None, None, None, 0, 0, 0, None) == _lib.ENODEVICE
+    assert L.mrsim_random_policy(C.byref(p), 4, 0, buf.ctypes.data, 0, 0, None) == _lib.ENODEVICE
+    with pytest.raises(RuntimeError):
+        MRVecEnv(4)
+
+
+def test_argument_validation():
+    from mr_rl_amd import _lib
+    L = _lib.lib()
+    p = _lib.default_params()
+    buf = np.zeros(64, dtype=np.float64)
+    st = _lib.MrsimState(buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)
+    io = _lib.MrsimStepIO(None, None, None, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data, None, None, None,
+                          None, None)
+    assert L.mrsim_step(None, 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EINVAL
+    assert L.mrsim_step(C.byref(p), -1, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EINVAL
+    assert L.mrsim_step(C.byref(p), 2**33, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.ERANGE
+    assert L.mrsim_step(C.byref(p), 4, 0, None, C.byref(io), 0, 0, None) == _lib.EINVAL
+    st_bad = _lib.MrsimState(buf.ctypes.data + 8, buf.ctypes.data, buf.ctypes.data)
+    assert L.mrsim_step(C.byref(p), 4, 0, C.byref(st_bad), C.byref(io), 0, 0, None) == _lib.EALIGN
+    p.integrator = 7
+    assert L.mrsim_step(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EINVAL
+    assert "align" in _lib.strerror(_lib.EALIGN)

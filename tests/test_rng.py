@@ -1,0 +1,71 @@
+"""CPU: the RNG definition (Philox4x32-10 + specified Box-Muller) of the oracle."""
+import numpy as np
+import scipy.stats as st
+
+from oracle import oracle as O
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10 (cross-checked here against ATen's
+    PhiloxRNGEngine.h compiled on the host: identical words)."""
+    assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_box_muller_matches_fp64_formula():
+    rng = np.random.default_rng(0)
+    ua = rng.integers(0, 2**32, 4000, dtype=np.uint64)
+    ub = rng.integers(0, 2**32, 4000, dtype=np.uint64)
+    for a, b in zip(ua, ub):
+        z0, z1 = O.box_muller(int(a), int(b))
+        r = np.sqrt(-2 * np.log((a + 0.5) / 2**32)); th = 2 * np.pi * (b + 0.5) / 2**32
+        assert abs(z0 - r * np.cos(th)) < 2e-5 and abs(z1 - r * np.sin(th)) < 2e-5
+    # edges: all octant boundaries, extreme u
+    for b in [0, 2**29 - 1, 2**29, 2**30, 2**31, 2**32 - 1, 3 << 29, (5 << 29) + 7]:
+        for a in [0, 1, 2**31, 2**32 - 1]:
+            z0, z1 = O.box_muller(a, b)
+            assert np.isfinite(z0) and np.isfinite(z1) and abs(z0) < 7 and abs(z1) < 7
+
+
+def test_normal_distribution():
+    z = O.fill_normals(12345, 7, 3, 0, 250_000).astype(np.float64)  # 1e6 draws
+    n = len(z)
+    assert abs(z.mean()) < 5 / np.sqrt(n)
+    assert abs(z.std() - 1) < 5 / np.sqrt(2 * n)
+    assert abs(st.skew(z)) < 0.02 and abs(st.kurtosis(z)) < 0.03
+    assert st.kstest(z[:200_000], "norm").pvalue > 1e-3
+    for a, b in [(0, 1), (0, 2), (1, 3), (2, 3)]:
+        assert abs(np.corrcoef(z[a::4], z[b::4])[0, 1]) < 0.01
+
+
+def test_streams_are_distinct():
+    a = O.normals4(1, 0, 0, O.c0(O.STREAM_DYN, 0, 0))
+    assert not np.array_equal(a, O.normals4(1, 1, 0, O.c0(O.STREAM_DYN, 0, 0)))   # env
+    assert not np.array_equal(a, O.normals4(1, 0, 1, O.c0(O.STREAM_DYN, 0, 0)))   # step
+    assert not np.array_equal(a, O.normals4(2, 0, 0, O.c0(O.STREAM_DYN, 0, 0)))   # seed
+    assert not np.array_equal(a, O.normals4(1, 0, 0, O.c0(O.STREAM_CTOR, 0, 0)))  # stream
+    assert not np.array_equal(a, O.normals4(1, 0, 0, O.c0(O.STREAM_DYN, 1, 0)))   # block
+    assert np.array_equal(a, O.normals4(1, 0, 0, O.c0(O.STREAM_DYN, 0, 0)))
+
+
+def test_noise_increment_law():
+    """away from the origin one env step adds noise with std 0.868937*dt*sigma per axis
+    and mean dt*(b1*v_prev + (1-b1)*v_new)."""
+    n = 20000
+    p = O.default_params(a0=1.0, sigma=1.0)
+    v = O.VecOracle(n, p, seed=99)
+    init = np.tile([[110.0, 115.0]], (n, 1))
+    v.reset(step_idx=0, init_xy=init)
+    act = np.tile(np.array([[4.0, 0.5]], dtype=np.float32), (n, 1))
+    v.step(act, step_idx=1)
+    y1 = v.envs["y"].copy()
+    v.step(act, step_idx=2)
+    d = v.envs["y"] - y1
+    vx, vy = 4 * np.cos(np.float64(np.float32(0.5))), 4 * np.sin(np.float64(np.float32(0.5)))
+    sd = 0.868937 * 0.03
+    assert abs(d[:, 0].mean() - 0.03 * vx) < 5 * sd / np.sqrt(n)
+    assert abs(d[:, 1].mean() - 0.03 * vy) < 5 * sd / np.sqrt(n)
+    assert abs(d[:, 0].std() / sd - 1) < 0.03 and abs(d[:, 1].std() / sd - 1) < 0.03
+    assert (v.envs["n_attempts"] == 1).all()
