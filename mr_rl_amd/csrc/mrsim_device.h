@@ -99,7 +99,7 @@ __device__ __forceinline__ float spec_logf(float u) {
 // Box-Muller, specified operation by operation (see oracle/mrsim_oracle.c: orc_box_muller).
 __device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float& z0, float& z1) {
     const float u = __builtin_fmaf((float)ua, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-    const float r = __fsqrt_rn(-2.0f * spec_logf(u));
+    const float r = __builtin_sqrtf(-2.0f * spec_logf(u));
     const uint32_t oct = ub >> 29;
     uint32_t rem = ub & 0x1FFFFFFFu;
     if (oct & 1u) rem = 0x1FFFFFFFu - rem;
@@ -296,7 +296,7 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
     //   h1 >= dt       <=  d1 <= TH and d2 <= TH, h0 = min(0.01 d0/d1, dt),  TH = 0.01/dt^5
     // Any NaN/inf makes a comparison false and falls through to the exact path.
     {
-        const float r0 = __frcp_rn((float)sc0), r1 = __frcp_rn((float)sc1);
+        const float r0 = __builtin_amdgcn_rcpf((float)sc0), r1 = __builtin_amdgcn_rcpf((float)sc1);
         const float y0s = (float)x * r0, y1s = (float)y * r1;
         const float g0 = (float)f0x * r0, g1 = (float)f0y * r1;
         const float e0 = (float)(f1x - f0x) * r0, e1 = (float)(f1y - f0y) * r1;
@@ -578,7 +578,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     if (P.reward_mode == 1) rew = reached ? 100.0f : ((!inb || timeout) ? -100.0f : -0.1f);  // :118-134
     e.ep_ret += rew;
     o.obs[0] = (float)e.x; o.obs[1] = (float)e.y; o.obs[2] = (float)gx; o.obs[3] = (float)gy;
-    o.obs[4] = __fsqrt_rn((float)d2);
+    o.obs[4] = __builtin_sqrtf((float)d2);
     o.rew = rew;
     o.done = done ? 1 : 0;
     o.spx = (float)spx; o.spy = (float)spy;
@@ -597,7 +597,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         goal_at(P, goal_table, R.env, 0, gx, gy);
         const double ex = gx - e.x, ey = gy - e.y;
         o.obs[0] = (float)e.x; o.obs[1] = (float)e.y; o.obs[2] = (float)gx; o.obs[3] = (float)gy;
-        o.obs[4] = __fsqrt_rn((float)(ex * ex + ey * ey));
+        o.obs[4] = __builtin_sqrtf((float)(ex * ex + ey * ey));
     }
 }
 

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const
         double gx, gy;
         goal_at(P, goal_table, R.env, 0, gx, gy);
         const double dx = gx - e.x, dy = gy - e.y;
-        const float v[5] = {(float)e.x, (float)e.y, (float)gx, (float)gy, __fsqrt_rn((float)(dx * dx + dy * dy))};
+        const float v[5] = {(float)e.x, (float)e.y, (float)gx, (float)gy, __builtin_sqrtf((float)(dx * dx + dy * dy))};
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             if (obs_layout == MRSIM_OBS_AOS) obs[i * 5 + j] = v[j];
