@@ -66,6 +66,10 @@ typedef struct MrsimParams {
     int32_t goal_T;        /*   = MR_Env.init_goal, MR_env.py:57                                */
     int32_t obs_layout;    /* MRSIM_OBS_*                                                       */
     int32_t reserved;
+    const uint64_t* step_base; /* optional DEVICE word added to every step_idx argument.  Kernel      */
+                           /*   arguments are frozen inside a captured hipGraph; keeping the base in */
+                           /*   HBM (advanced by mrsim_advance_step_base) lets each replay draw new  */
+                           /*   noise.  NULL = 0.                                                    */
 } MrsimParams;
 
 /* Per-env persistent state in HBM, caller-owned.  16-byte records so that every
@@ -140,6 +144,9 @@ int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mrsim
                   int32_t T, const float* actions, int32_t shared_actions, const float* goal_table,
                   float* traj_xy, float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T,
                   int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream);
+
+/* *step_base += delta on `stream` (a one-lane kernel; graph-capturable). */
+int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream);
 
 /* Test aid: out[n][4] = the 4 standard normals of RNG call `c0` for envs env_id0..env_id0+n-1
  * (bit-compared with the oracle's definition in tests/). */

@@ -15,7 +15,7 @@ ABI_VERSION = 1
 # every symbol include/mrsim.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
     "mrsim_abi_version", "mrsim_strerror", "mrsim_default_params", "mrsim_reset", "mrsim_step",
-    "mrsim_step_timed", "mrsim_random_policy", "mrsim_rollout", "mrsim_debug_normals",
+    "mrsim_step_timed", "mrsim_random_policy", "mrsim_rollout", "mrsim_advance_step_base", "mrsim_debug_normals",
     "mrsim_device_count", "mrsim_device_name",
 )
 
@@ -30,6 +30,7 @@ class MrsimParams(C.Structure):
         ("mismatched", C.c_int32), ("integrator", C.c_int32), ("substeps", C.c_int32),
         ("reward_mode", C.c_int32), ("max_timesteps", C.c_int32), ("auto_reset", C.c_int32),
         ("goal_K", C.c_int32), ("goal_T", C.c_int32), ("obs_layout", C.c_int32), ("reserved", C.c_int32),
+        ("step_base", C.c_void_p),
     ]
 
 
@@ -76,6 +77,8 @@ def lib():
     L.mrsim_step_timed.argtypes = [PP, i64, u32, PS, PIO, u64, u64, vp, C.POINTER(C.c_float)]
     L.mrsim_random_policy.argtypes = [PP, i64, u32, vp, u64, u64, vp]
     L.mrsim_rollout.argtypes = [PP, i64, u32, PS, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, u64, u64, vp]
+    L.mrsim_advance_step_base.argtypes = [vp, u64, vp]
+    L.mrsim_advance_step_base.restype = C.c_int
     L.mrsim_debug_normals.argtypes = [i64, u32, u64, u64, u32, vp, vp]
     L.mrsim_device_count.restype = C.c_int
     L.mrsim_device_name.argtypes = [C.c_int, C.c_char_p, i32]
@@ -84,7 +87,7 @@ def lib():
         getattr(L, name).restype = C.c_int
     if L.mrsim_abi_version() != ABI_VERSION:
         raise ImportError(f"libmrsim.so ABI {L.mrsim_abi_version()} != binding ABI {ABI_VERSION}")
-    assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 10
+    assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 10 + 8
     _lib = L
     return L
 

@@ -37,7 +37,17 @@ struct KParams {
     uint32_t seed_lo, seed_hi, step_lo, step_hi;
     uint32_t env_id0, pad2;
     long long n;
+    const unsigned long long* step_base;  // optional device word added to (step_hi:step_lo)
 };
+
+// effective 64-bit step index of this launch (+ t for the fused rollout)
+__device__ __forceinline__ void step_words(const KParams& P, unsigned long long t, uint32_t& lo, uint32_t& hi) {
+    unsigned long long s = (((unsigned long long)P.step_hi << 32) | P.step_lo) + t;
+    if (P.step_base != nullptr) s += *P.step_base;  // uniform scalar load
+    lo = (uint32_t)s;
+    hi = (uint32_t)(s >> 32);
+}
+__device__ __forceinline__ struct Rng make_rng(const KParams& P, long long i, unsigned long long t = 0);
 
 // ---------------------------------------------------------------------------
 // RNG: Philox4x32-10, counter = {c0, step lo, step hi, global env id}, key = seed
@@ -51,6 +61,14 @@ __device__ __forceinline__ constexpr uint32_t c0_of(uint32_t stream, uint32_t bl
 struct Rng {
     uint32_t k0, k1, step_lo, step_hi, env;
 };
+
+__device__ __forceinline__ Rng make_rng(const KParams& P, long long i, unsigned long long t) {
+    Rng R;
+    R.k0 = P.seed_lo; R.k1 = P.seed_hi;
+    step_words(P, t, R.step_lo, R.step_hi);
+    R.env = P.env_id0 + (uint32_t)i;
+    return R;
+}
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&o)[4]) {

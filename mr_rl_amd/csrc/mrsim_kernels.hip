@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
     if (active) {
         EnvRegs e;
         load_env(st.pos, st.aux, st.ep_ret, i, P, e);
-        const Rng R{P.seed_lo, P.seed_hi, P.step_lo, P.step_hi, P.env_id0 + (uint32_t)i};
+        const Rng R = make_rng(P, i);
         float af, aa;
         if (io.actions != nullptr) {
             const float2 a = reinterpret_cast<const float2*>(io.actions)[i];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
     if (mask != nullptr && mask[i] == 0) return;
-    const Rng R{P.seed_lo, P.seed_hi, P.step_lo, P.step_hi, P.env_id0 + (uint32_t)i};
+    const Rng R = make_rng(P, i);
     double x0, y0;
     if (init_xy != nullptr) {
         const double2 p = reinterpret_cast<const double2*>(init_xy)[i];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const
 __global__ __launch_bounds__(kBlock) void mr_policy_kernel(const KParams P, float* __restrict__ actions) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
-    const Rng R{P.seed_lo, P.seed_hi, P.step_lo, P.step_hi, P.env_id0 + (uint32_t)i};
+    const Rng R = make_rng(P, i);
     float f_t, al;
     random_action(P, R, f_t, al);
     reinterpret_cast<float2*>(actions)[i] = make_float2(f_t, al);
@@ -179,12 +179,9 @@ __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, con
     if (i >= P.n) return;
     EnvRegs e;
     load_env(st.pos, st.aux, st.ep_ret, i, P, e);
-    Rng R{P.seed_lo, P.seed_hi, P.step_lo, P.step_hi, P.env_id0 + (uint32_t)i};
     int fail = 0;
     for (int t = 0; t < ra.T; ++t) {
-        const unsigned long long step = (((unsigned long long)P.step_hi << 32) | P.step_lo) + (unsigned long long)t;
-        R.step_lo = (uint32_t)step;
-        R.step_hi = (uint32_t)(step >> 32);
+        const Rng R = make_rng(P, i, (unsigned long long)t);
         float af, aa;
         if (ra.actions == nullptr) {
             random_action(P, R, af, aa);
@@ -220,13 +217,17 @@ __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, con
     if (fail && ra.status != nullptr) atomicOr(ra.status, fail);
 }
 
+__global__ void mr_advance_kernel(unsigned long long* step_base, unsigned long long delta) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *step_base += delta;
+}
+
 // ---------------------------------------------------------------------------
 // debug / test aid: raw normals of the RNG definition (bit-compared with the oracle)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void mr_debug_normals_kernel(const KParams P, uint32_t c0, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
-    const Rng R{P.seed_lo, P.seed_hi, P.step_lo, P.step_hi, P.env_id0 + (uint32_t)i};
+    const Rng R = make_rng(P, i);
     float z[4];
     block_normals<1>(R, c0, z);
     reinterpret_cast<float4*>(out)[i] = make_float4(z[0], z[1], z[2], z[3]);
@@ -266,6 +267,7 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
     K.step_lo = (uint32_t)step_idx; K.step_hi = (uint32_t)(step_idx >> 32);
     K.env_id0 = env_id0;
     K.n = n;
+    K.step_base = reinterpret_cast<const unsigned long long*>(p->step_base);
     return MRSIM_OK;
 }
 
@@ -465,6 +467,15 @@ int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mrsim
     const bool rk45 = p->integrator == MRSIM_INT_RK45, noise = p->sigma != 0.0, mis = p->mismatched != 0;
     if (rk45) return noise ? launch_rollout_m<true, true>(lc, mis, K, S, ra) : launch_rollout_m<true, false>(lc, mis, K, S, ra);
     return noise ? launch_rollout_m<false, true>(lc, mis, K, S, ra) : launch_rollout_m<false, false>(lc, mis, K, S, ra);
+}
+
+int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream) {
+    if (step_base == nullptr) return MRSIM_EINVAL;
+    int rc = check_device();
+    if (rc) return rc;
+    hipLaunchKernelGGL(mr_advance_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<unsigned long long*>(step_base), (unsigned long long)delta);
+    return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 
 int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, uint32_t c0, float* out,

@@ -1,0 +1,77 @@
+"""Multi-GPU layer: one process per GPU, contiguous env shards, and the ONE collective of this
+path -- an all-gather of per-env episode returns at episode boundaries (RCCL over xGMI when the
+process group backend is "nccl"; the same code runs over gloo in the CPU tests).
+
+The step itself never communicates: environments are independent and the RNG is keyed by the
+GLOBAL env id, so rank r simply runs envs [env_id0, env_id0 + n_local).  xGMI is
+point-to-point and an episode's returns are only 4 B per env (1 MiB per rank at 262 144 envs),
+i.e. latency-bound: gather once per episode (every 51 steps), never per step.
+"""
+
+
+def shard_of(total_envs, rank, world_size):
+    """Contiguous block partition: returns (env_id0, n_local).  The first (total % world) ranks get
+    one extra env."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    base, rem = divmod(int(total_envs), int(world_size))
+    n_local = base + (1 if rank < rem else 0)
+    env_id0 = rank * base + min(rank, rem)
+    return env_id0, n_local
+
+
+def all_shards(total_envs, world_size):
+    return [shard_of(total_envs, r, world_size) for r in range(world_size)]
+
+
+def gather_returns(local_returns, out=None, group=None):
+    """all-gather of per-env episode returns: [n_local] on every rank -> [world * n_local] in GLOBAL
+    env order.  Requires equal shard sizes (all_gather_into_tensor); use gather_returns_ragged
+    otherwise.  Asynchronous with respect to the host on CUDA(HIP) tensors: the collective is
+    enqueued on the current stream."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if out is None:
+            return local_returns
+        out.copy_(local_returns)
+        return out
+    world = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty(world * local_returns.numel(), dtype=local_returns.dtype, device=local_returns.device)
+    dist.all_gather_into_tensor(out, local_returns.contiguous(), group=group)
+    return out
+
+
+def gather_returns_ragged(local_returns, total_envs, group=None):
+    """Same for unequal shards (total_envs not divisible by the world size): pads to the largest shard."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_returns
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shards = all_shards(total_envs, world)
+    nmax = max(n for _, n in shards)
+    pad = torch.zeros(nmax, dtype=local_returns.dtype, device=local_returns.device)
+    pad[: shards[rank][1]] = local_returns
+    buf = torch.empty(world * nmax, dtype=local_returns.dtype, device=local_returns.device)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    return torch.cat([buf[r * nmax: r * nmax + n] for r, (_, n) in enumerate(shards)])
+
+
+class ReturnGatherer:
+    """Episode-return reduction for a sharded MRVecEnv: keeps the gathered [total] tensor resident."""
+
+    def __init__(self, env, world_size=1, group=None):
+        import torch
+        self.env, self.world, self.group = env, int(world_size), group
+        self.all_returns = torch.zeros(self.world * env.num_envs, dtype=torch.float32, device=env.device)
+        self.n_gathers = 0
+
+    def gather(self):
+        gather_returns(self.env.final_ret, out=self.all_returns, group=self.group)
+        self.n_gathers += 1
+        return self.all_returns
+
+    def last_mean(self):
+        return float(self.all_returns.mean().item()) if self.n_gathers else None

@@ -108,6 +108,23 @@ class MRVecEnv:
     # ------------------------------------------------------------------ helpers
     def _refresh_params(self):
         self._params = self.cfg.to_params(self._gK, self._gT)
+        sb = getattr(self, "_step_base", None)
+        self._params.step_base = None if sb is None else sb.data_ptr()
+
+    def enable_device_step_base(self):
+        """Move the RNG step counter into HBM (MrsimParams.step_base): the step_idx argument of every
+        later call becomes an OFFSET from that device word.  Needed to replay a captured hipGraph with
+        fresh noise (kernel arguments are frozen at capture)."""
+        torch = _torch()
+        if getattr(self, "_step_base", None) is None:
+            self._step_base = torch.full((1,), self.step_idx, dtype=torch.int64, device=self.device)
+            self.step_idx = 0
+            self._refresh_params()
+        return self._step_base
+
+    def advance_step_base(self, delta):
+        rc = self._L.mrsim_advance_step_base(self._p(self._step_base), int(delta), self._stream())
+        _lib.check(rc, "mrsim_advance_step_base")
 
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
@@ -270,6 +287,36 @@ class MRVecEnv:
         if acts_T is not None:
             out["actions"] = acts_T
         return out
+
+    def capture_steps(self, G, policy="kernel"):
+        """Capture G env steps into one hipGraph (torch.cuda.CUDAGraph is only the capture plumbing).
+        policy: "kernel" = policy kernel writes actions to HBM, step kernel reads them (the shape of a
+        real actor -> env.step(actions) loop); "fused" = the step kernel draws the policy itself.
+        Each replay advances the device step base by G, so replays draw fresh noise."""
+        torch = _torch()
+        self.enable_device_step_base()
+        act = torch.empty((self.num_envs, 2), dtype=torch.float32, device=self.device)
+
+        def body():
+            self.step_idx = 0
+            for _ in range(G):
+                if policy == "kernel":
+                    self.step(self.random_policy(out=act))
+                else:
+                    self.step(None)
+            self.advance_step_base(G)
+            self.step_idx = 0
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            body()  # warm-up (executes for real)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        return graph
 
     def check_status(self):
         """Synchronising check of the device status word (bit0: an env's RK45 attempt guard tripped --
