@@ -41,6 +41,9 @@ enum {
 enum { MRSIM_INT_RK45 = 0, MRSIM_INT_EULER = 1, MRSIM_INT_RK4 = 2 };
 enum { MRSIM_REW_CONSTANT10 = 0, MRSIM_REW_GOAL = 1 };
 enum { MRSIM_OBS_AOS = 0 /* [N][5] */, MRSIM_OBS_SOA = 1 /* [5][N] */ };
+/* FAST: hardware v_log/v_sqrt/v_sin/v_cos (normals within ~1e-6 of SPEC).  SPEC: the operation-by-
+ * operation fp32 definition shared with the CPU oracle -- normals are bit-identical to the oracle's. */
+enum { MRSIM_NOISE_FAST = 0, MRSIM_NOISE_SPEC = 1 };
 
 /* Tunables of the reference path, with the place each one lives in the reference. */
 typedef struct MrsimParams {
@@ -65,7 +68,7 @@ typedef struct MrsimParams {
     int32_t goal_K;        /* goal/trajectory table [K][T][2] f32; NULL table = goal (0,0)      */
     int32_t goal_T;        /*   = MR_Env.init_goal, MR_env.py:57                                */
     int32_t obs_layout;    /* MRSIM_OBS_*                                                       */
-    int32_t reserved;
+    int32_t noise_math;    /* MRSIM_NOISE_*: how Box-Muller is evaluated (same uniforms either way)    */
     const uint64_t* step_base; /* optional DEVICE word added to every step_idx argument.  Kernel      */
                            /*   arguments are frozen inside a captured hipGraph; keeping the base in */
                            /*   HBM (advanced by mrsim_advance_step_base) lets each replay draw new  */
@@ -151,7 +154,7 @@ int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream);
 /* Test aid: out[n][4] = the 4 standard normals of RNG call `c0` for envs env_id0..env_id0+n-1
  * (bit-compared with the oracle's definition in tests/). */
 int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, uint32_t c0,
-                        float* out, void* stream);
+                        int32_t noise_math, float* out, void* stream);
 
 /* Number of HIP devices visible (0 without a GPU); fills name_host (may be NULL). */
 int mrsim_device_count(void);

@@ -10,6 +10,7 @@ OK, EINVAL, ENODEVICE, ELAUNCH, EALIGN, ERANGE = 0, -1, -2, -3, -4, -5
 INT_RK45, INT_EULER, INT_RK4 = 0, 1, 2
 REW_CONSTANT10, REW_GOAL = 0, 1
 OBS_AOS, OBS_SOA = 0, 1
+NOISE_FAST, NOISE_SPEC = 0, 1
 ABI_VERSION = 1
 
 # every symbol include/mrsim.h declares (tests check the .so exports exactly these)
@@ -29,7 +30,7 @@ class MrsimParams(C.Structure):
         ("act_low", C.c_double * 2), ("act_high", C.c_double * 2),
         ("mismatched", C.c_int32), ("integrator", C.c_int32), ("substeps", C.c_int32),
         ("reward_mode", C.c_int32), ("max_timesteps", C.c_int32), ("auto_reset", C.c_int32),
-        ("goal_K", C.c_int32), ("goal_T", C.c_int32), ("obs_layout", C.c_int32), ("reserved", C.c_int32),
+        ("goal_K", C.c_int32), ("goal_T", C.c_int32), ("obs_layout", C.c_int32), ("noise_math", C.c_int32),
         ("step_base", C.c_void_p),
     ]
 
@@ -79,7 +80,7 @@ def lib():
     L.mrsim_rollout.argtypes = [PP, i64, u32, PS, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, u64, u64, vp]
     L.mrsim_advance_step_base.argtypes = [vp, u64, vp]
     L.mrsim_advance_step_base.restype = C.c_int
-    L.mrsim_debug_normals.argtypes = [i64, u32, u64, u64, u32, vp, vp]
+    L.mrsim_debug_normals.argtypes = [i64, u32, u64, u64, u32, i32, vp, vp]
     L.mrsim_device_count.restype = C.c_int
     L.mrsim_device_name.argtypes = [C.c_int, C.c_char_p, i32]
     for name in ("mrsim_default_params", "mrsim_reset", "mrsim_step", "mrsim_step_timed", "mrsim_random_policy",

@@ -8,6 +8,7 @@ from . import _lib
 INTEGRATORS = {"reference": _lib.INT_RK45, "rk45": _lib.INT_RK45, "euler": _lib.INT_EULER, "rk4": _lib.INT_RK4}
 REWARD_MODES = {"constant10": _lib.REW_CONSTANT10, "goal": _lib.REW_GOAL}
 OBS_LAYOUTS = {"aos": _lib.OBS_AOS, "soa": _lib.OBS_SOA}
+NOISE_MATH = {"fast": _lib.NOISE_FAST, "spec": _lib.NOISE_SPEC}
 
 
 @dataclasses.dataclass
@@ -38,6 +39,7 @@ class MRConfig:
     reward_mode: str = "constant10"       # constant10 (MR_env.py:89) | goal (calculate_reward, :118-134)
     auto_reset: bool = False
     obs_layout: str = "aos"               # storage of obs: [N,5] rows or [5,N] planes (returned view is [N,5])
+    noise_math: str = "fast"              # Box-Muller on hardware transcendentals | "spec": bit-identical to the oracle
     seed: int = 0
 
     def to_params(self, goal_K=1, goal_T=1):
@@ -64,4 +66,5 @@ class MRConfig:
         p.auto_reset = int(bool(self.auto_reset))
         p.goal_K, p.goal_T = int(goal_K), int(goal_T)
         p.obs_layout = OBS_LAYOUTS[self.obs_layout]
+        p.noise_math = NOISE_MATH[self.noise_math]
         return p

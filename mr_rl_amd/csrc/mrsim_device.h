@@ -7,11 +7,16 @@
 //                                                    then build the NEXT RK45 object
 //   scipy RK45 semantics    rk.py rk_step/_step_impl, common.py select_initial_step
 //   MR_Env.step/end/...     MR_env.py:70-152
-// Because the RHS ignores (t, y), the RK stage arguments never matter: only the
-// stage VALUES K[i] (action velocity + fresh noise), the solution weights B and
-// the error weights E do.  The first stage K[0] is the derivative the RK45 object
-// computed when it was constructed -- at the end of the PREVIOUS env step, with the
-// previous action -- so it is carried in HBM between steps.
+//
+// Algebra used by the kernel.  The RHS ignores (t, y), so every stage value is
+//   K[i] = V(action) + N_i ,   N_i = fresh noise of that RHS evaluation,
+// except K[0], the derivative the RK45 object computed when it was constructed -- at the
+// end of the PREVIOUS env step, with the previous action; it is carried in HBM.
+// With the Dormand-Prince weights  sum(B) = 1, sum(E) = 0, B[1] = E[1] = 0:
+//   y_new = y + h * ( V + B0*(K0 - V) + sum_{i=2..5} B_i N_i )
+//   err   =     h * (     E0*(K0 - V) + sum_{i=2..6} E_i N_i )
+// The two noise sums are accumulated in fp32 (they are sums of fp32 normals); everything that
+// touches positions is fp64.  sigma = 0 reduces to the closed form of SURVEY 3.2.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,14 +25,19 @@ namespace mrsim {
 
 constexpr int kBlock = 256;  // 4 waves; 16-B records => every wave moves 1 KiB per array
 
+// noise generator variants (template parameter NZ)
+constexpr int kNoNoise = 0;    // sigma == 0: no RNG work at all
+constexpr int kNoiseSpec = 1;  // Box-Muller in specified fp32 arithmetic: bit-identical to the CPU oracle
+constexpr int kNoiseFast = 2;  // Box-Muller on the hardware transcendentals (v_log/v_sqrt/v_sin/v_cos)
+
 // ---------------------------------------------------------------------------
 // kernel-side parameter block (passed by value -> kernarg/SGPRs)
 // ---------------------------------------------------------------------------
 struct KParams {
-    double dt, rtol, atol, a0, sigma, sigma4;
+    double dt, inv_dt, rtol, atol, a0, sigma, sigma4;
     double min_dist2;  // min_dist2goal^2
-    double obs_lo[5], obs_hi[5];
-    double dmax2;      // obs_hi[4]^2
+    double obs_lo[4], obs_hi[4];
+    double dmin2, dmax2;  // obs_low[4]^2 (0 if <= 0), obs_high[4]^2
     double init_lo[2], init_span[2];
     double act_lo[2], act_span[2];
     double h1_thresh;  // 0.01 / dt^5 : select_initial_step's h1 >= dt  <=>  max(d1,d2) <= h1_thresh
@@ -39,15 +49,6 @@ struct KParams {
     long long n;
     const unsigned long long* step_base;  // optional device word added to (step_hi:step_lo)
 };
-
-// effective 64-bit step index of this launch (+ t for the fused rollout)
-__device__ __forceinline__ void step_words(const KParams& P, unsigned long long t, uint32_t& lo, uint32_t& hi) {
-    unsigned long long s = (((unsigned long long)P.step_hi << 32) | P.step_lo) + t;
-    if (P.step_base != nullptr) s += *P.step_base;  // uniform scalar load
-    lo = (uint32_t)s;
-    hi = (uint32_t)(s >> 32);
-}
-__device__ __forceinline__ struct Rng make_rng(const KParams& P, long long i, unsigned long long t = 0);
 
 // ---------------------------------------------------------------------------
 // RNG: Philox4x32-10, counter = {c0, step lo, step hi, global env id}, key = seed
@@ -62,7 +63,15 @@ struct Rng {
     uint32_t k0, k1, step_lo, step_hi, env;
 };
 
-__device__ __forceinline__ Rng make_rng(const KParams& P, long long i, unsigned long long t) {
+// effective 64-bit step index of this launch (+ t for the fused rollout)
+__device__ __forceinline__ void step_words(const KParams& P, unsigned long long t, uint32_t& lo, uint32_t& hi) {
+    unsigned long long s = (((unsigned long long)P.step_hi << 32) | P.step_lo) + t;
+    if (P.step_base != nullptr) s += *P.step_base;  // uniform scalar load
+    lo = (uint32_t)s;
+    hi = (uint32_t)(s >> 32);
+}
+
+__device__ __forceinline__ Rng make_rng(const KParams& P, long long i, unsigned long long t = 0) {
     Rng R;
     R.k0 = P.seed_lo; R.k1 = P.seed_hi;
     step_words(P, t, R.step_lo, R.step_hi);
@@ -114,44 +123,67 @@ __device__ __forceinline__ float spec_logf(float u) {
     return __builtin_fmaf((float)e, 0.693147180559945f, lm);
 }
 
-// Box-Muller, specified operation by operation (see oracle/mrsim_oracle.c: orc_box_muller).
+// IEEE-correct sqrt for w in [0, 64): v_sqrt_f32 (1 ulp) + the one-ulp fix-up hipcc's own sqrtf
+// uses, without its denormal/inf handling (never needed here).  Bit-identical to sqrtf().
+__device__ __forceinline__ float sqrt_rn_small(float w) {
+    const float s = __builtin_amdgcn_sqrtf(w);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u);
+    const float sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, w);
+    const float rp = __builtin_fmaf(-sp, s, w);
+    float r = (rm <= 0.0f) ? sm : s;
+    r = (rp > 0.0f) ? sp : r;
+    return r;
+}
+
+// Box-Muller.  kNoiseSpec: specified operation by operation (oracle/mrsim_oracle.c: orc_box_muller),
+// bit-identical to the oracle.  kNoiseFast: same uniforms, same formula, hardware transcendentals
+// (v_log_f32, v_sqrt_f32, v_sin_f32/v_cos_f32 take the angle in revolutions): within ~1e-6 of the spec.
+template <int NZ>
 __device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float& z0, float& z1) {
     const float u = __builtin_fmaf((float)ua, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-    const float r = __builtin_sqrtf(-2.0f * spec_logf(u));
-    const uint32_t oct = ub >> 29;
-    uint32_t rem = ub & 0x1FFFFFFFu;
-    if (oct & 1u) rem = 0x1FFFFFFFu - rem;
-    const float x = __builtin_fmaf((float)rem, 1.862645149230957e-09f, 9.313225746154785e-10f);
-    const float phi = x * 0.78539816339744831f;
-    const float zz = phi * phi;
-    float ps = -1.9515295891E-4f;
-    ps = __builtin_fmaf(ps, zz, 8.3321608736E-3f);
-    ps = __builtin_fmaf(ps, zz, -1.6666654611E-1f);
-    const float s = __builtin_fmaf(ps * zz, phi, phi);
-    float pc = 2.443315711809948E-005f;
-    pc = __builtin_fmaf(pc, zz, -1.388731625493765E-003f);
-    pc = __builtin_fmaf(pc, zz, 4.166664568298827E-002f);
-    const float c = __builtin_fmaf(pc * zz, zz, __builtin_fmaf(-0.5f, zz, 1.0f));
-    const uint32_t swap = ((oct + 1u) >> 1) & 1u;
-    const uint32_t cneg = ((oct + 2u) >> 2) & 1u;
-    const uint32_t sneg = oct >> 2;
-    float cc = swap ? s : c;
-    float ss = swap ? c : s;
-    if (cneg) cc = -cc;
-    if (sneg) ss = -ss;
-    z0 = r * cc;
-    z1 = r * ss;
+    if constexpr (NZ == kNoiseFast) {
+        const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // -2 ln2 log2 u
+        const float t = __builtin_fmaf((float)ub, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+        z0 = r * __builtin_amdgcn_cosf(t);
+        z1 = r * __builtin_amdgcn_sinf(t);
+    } else {
+        const float r = sqrt_rn_small(-2.0f * spec_logf(u));
+        const uint32_t oct = ub >> 29;
+        uint32_t rem = ub & 0x1FFFFFFFu;
+        if (oct & 1u) rem = 0x1FFFFFFFu - rem;
+        const float x = __builtin_fmaf((float)rem, 1.862645149230957e-09f, 9.313225746154785e-10f);
+        const float phi = x * 0.78539816339744831f;
+        const float zz = phi * phi;
+        float ps = -1.9515295891E-4f;
+        ps = __builtin_fmaf(ps, zz, 8.3321608736E-3f);
+        ps = __builtin_fmaf(ps, zz, -1.6666654611E-1f);
+        const float s = __builtin_fmaf(ps * zz, phi, phi);
+        float pc = 2.443315711809948E-005f;
+        pc = __builtin_fmaf(pc, zz, -1.388731625493765E-003f);
+        pc = __builtin_fmaf(pc, zz, 4.166664568298827E-002f);
+        const float c = __builtin_fmaf(pc * zz, zz, __builtin_fmaf(-0.5f, zz, 1.0f));
+        const uint32_t swap = ((oct + 1u) >> 1) & 1u;
+        const uint32_t cneg = ((oct + 2u) >> 2) & 1u;
+        const uint32_t sneg = oct >> 2;
+        float cc = swap ? s : c;
+        float ss = swap ? c : s;
+        if (cneg) cc = -cc;
+        if (sneg) ss = -ss;
+        z0 = r * cc;
+        z1 = r * ss;
+    }
 }
 
 // the first NCALLS*4 normals of one block (rk_step attempt / constructor / fixed sub-step)
-template <int NCALLS>
+template <int NZ, int NCALLS>
 __device__ __forceinline__ void block_normals(const Rng& R, uint32_t c0base, float (&z)[NCALLS * 4]) {
 #pragma unroll
     for (int j = 0; j < NCALLS; ++j) {
         uint32_t o[4];
         philox_call(R, c0base | (uint32_t)j, o);
-        box_muller(o[0], o[1], z[4 * j + 0], z[4 * j + 1]);
-        box_muller(o[2], o[3], z[4 * j + 2], z[4 * j + 3]);
+        box_muller<NZ>(o[0], o[1], z[4 * j + 0], z[4 * j + 1]);
+        box_muller<NZ>(o[2], o[3], z[4 * j + 2], z[4 * j + 3]);
     }
 }
 
@@ -218,96 +250,95 @@ __device__ __forceinline__ void sincos_f64(double a, double& s, double& c) {
     if (!(__builtin_fabs(a) < 1e15)) { s = __builtin_nan(""); c = s; }
 }
 
+// scipy common.norm of a 2-vector
+__device__ __forceinline__ double rms2(double a, double b) { return sqrt(a * a + b * b) / 1.4142135623730951; }
+
 // ---------------------------------------------------------------------------
-// Simulator.simulate (MR_simulator.py:58-88): per-action constants + per-eval noise
+// Simulator.simulate (MR_simulator.py:58-88) as  K = V + N:
+//   nominal:     V = (a0*f)*(cos a, sin a),            N = sigma*(z_x, z_y)                  :82-83
+//   mismatched:  a0b = a0 + (f/4)*0.8                                                        :55-56
+//                V = ((a0b*f)*cos(a+0.1) + 0.2, (a0b*f)*sin(a-0.15) - 0.1)                   :79-80
+//                N = (gx*z_a + sigma*z_x, gy*z_a + sigma*z_y),  (gx, gy) = (sigma/4)*f*(cos(a+0.1), sin(a-0.15))
 // ---------------------------------------------------------------------------
 template <bool MIS>
 struct RhsCtx {
-    // nominal:     k = ((a0*f)*cos a + n_x, (a0*f)*sin a + n_y)                       :82-83
-    // mismatched:  a0' = a0 + (f/4)*0.8 + n_a;  k = ((a0'*f)*cos(a+0.1) + n_x + 0.2,
-    //                                                (a0'*f)*sin(a-0.15) + n_y - 0.1)  :55-56,78-80
-    double vx, vy;        // nominal base velocity
-    double a0b, f, cA, sB;  // mismatched pieces
+    double vx, vy;
+    double gx, gy;  // mismatched only
 };
 
 template <bool MIS>
 __device__ __forceinline__ RhsCtx<MIS> make_ctx(const KParams& P, double f_t, double al) {
     RhsCtx<MIS> C;
     if constexpr (MIS) {
-        C.a0b = P.a0 + (f_t / 4) * 0.8;
-        C.f = f_t;
-        double t0, t1;
-        sincos_f64(al + 0.1, t0, C.cA);
-        sincos_f64(al - 0.15, C.sB, t1);
-        C.vx = C.vy = 0.0;
+        const double a0b = P.a0 + (f_t / 4) * 0.8;
+        double t0, t1, cA, sB;
+        sincos_f64(al + 0.1, t0, cA);
+        sincos_f64(al - 0.15, sB, t1);
+        const double af = a0b * f_t;
+        C.vx = af * cA + 0.2;
+        C.vy = af * sB - 0.1;
+        C.gx = (P.sigma4 * f_t) * cA;
+        C.gy = (P.sigma4 * f_t) * sB;
     } else {
         double s, c;
         sincos_f64(al, s, c);
         const double af = P.a0 * f_t;
         C.vx = af * c;
         C.vy = af * s;
-        C.a0b = C.f = C.cA = C.sB = 0.0;
+        C.gx = C.gy = 0.0;
     }
     return C;
 }
 
-// zero action (Simulator.reset_start_pos, MR_simulator.py:30): velocity terms vanish
+// zero action (Simulator.reset_start_pos, MR_simulator.py:30): the velocity terms vanish
 template <bool MIS>
-__device__ __forceinline__ RhsCtx<MIS> zero_ctx(const KParams& P) {
+__device__ __forceinline__ RhsCtx<MIS> zero_ctx(const KParams&) {
     RhsCtx<MIS> C;
-    C.vx = C.vy = 0.0;
-    C.a0b = P.a0; C.f = 0.0; C.cA = 1.0; C.sB = 0.0;
+    C.vx = MIS ? 0.2 : 0.0;
+    C.vy = MIS ? -0.1 : 0.0;
+    C.gx = C.gy = 0.0;
     return C;
 }
 
-template <bool NOISE, bool MIS>
-__device__ __forceinline__ void rhs_eval(const KParams& P, const RhsCtx<MIS>& C, float za, float zx, float zy,
-                                         double& kx, double& ky) {
+// N for one RHS evaluation from its normals (za only used when MIS)
+template <bool MIS>
+__device__ __forceinline__ void noise_vec(const KParams& P, const RhsCtx<MIS>& C, float za, float zx, float zy,
+                                          double& nx, double& ny) {
+    nx = P.sigma * (double)zx;
+    ny = P.sigma * (double)zy;
     if constexpr (MIS) {
-        double a0e = C.a0b;
-        if constexpr (NOISE) a0e = a0e + P.sigma4 * (double)za;
-        const double af = a0e * C.f;
-        kx = af * C.cA; ky = af * C.sB;
-        if constexpr (NOISE) { kx = kx + P.sigma * (double)zx; ky = ky + P.sigma * (double)zy; }
-        kx = kx + 0.2; ky = ky - 0.1;
-    } else {
-        kx = C.vx; ky = C.vy;
-        if constexpr (NOISE) { kx = kx + P.sigma * (double)zx; ky = ky + P.sigma * (double)zy; }
+        nx = __builtin_fma(C.gx, (double)za, nx);
+        ny = __builtin_fma(C.gy, (double)za, ny);
     }
 }
-
-// scipy common.norm of a 2-vector
-__device__ __forceinline__ double rms2(double a, double b) { return sqrt(a * a + b * b) / 1.4142135623730951; }
 
 // ---------------------------------------------------------------------------
 // RungeKutta.__init__ + select_initial_step: what Simulator.step does after integrating
-// (MR_simulator.py:46-50) and what reset_start_pos does (:31-34).  Two RHS evaluations
-// f0 (-> K[0] of the next step) and f1 (-> Simulator.state_prime).
+// (MR_simulator.py:46-50) and what reset_start_pos does (:31-34).  Two RHS evaluations:
+// f0 (-> K[0] of the next step) and f1 (-> Simulator.state_prime, and d2).
 // ---------------------------------------------------------------------------
-template <bool NOISE, bool MIS>
+template <int NZ, bool MIS>
 __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, uint32_t stream,
                                                double x, double y, double& f0x, double& f0y, double& h_abs,
                                                double& spx, double& spy) {
-    double f1x, f1y;
-    if constexpr (NOISE) {
+    double n0x = 0.0, n0y = 0.0, n1x = 0.0, n1y = 0.0;
+    if constexpr (NZ != kNoNoise) {
         constexpr int NC = MIS ? 2 : 1;
         float z[NC * 4];
-        block_normals<NC>(R, c0_of(stream, 0, 0), z);
+        block_normals<NZ, NC>(R, c0_of(stream, 0, 0), z);
         if constexpr (MIS) {
-            rhs_eval<NOISE, MIS>(P, C, z[0], z[1], z[2], f0x, f0y);
-            rhs_eval<NOISE, MIS>(P, C, z[3], z[4], z[5], f1x, f1y);
+            noise_vec<MIS>(P, C, z[0], z[1], z[2], n0x, n0y);
+            noise_vec<MIS>(P, C, z[3], z[4], z[5], n1x, n1y);
         } else {
-            rhs_eval<NOISE, MIS>(P, C, 0.f, z[0], z[1], f0x, f0y);
-            rhs_eval<NOISE, MIS>(P, C, 0.f, z[2], z[3], f1x, f1y);
+            noise_vec<MIS>(P, C, 0.f, z[0], z[1], n0x, n0y);
+            noise_vec<MIS>(P, C, 0.f, z[2], z[3], n1x, n1y);
         }
-    } else {
-        rhs_eval<NOISE, MIS>(P, C, 0.f, 0.f, 0.f, f0x, f0y);
-        f1x = f0x; f1y = f0y;
     }
-    spx = f1x; spy = f1y;
+    f0x = C.vx + n0x; f0y = C.vy + n0y;
+    spx = C.vx + n1x; spy = C.vy + n1y;
 
-    const double sc0 = P.atol + fabs(x) * P.rtol;
-    const double sc1 = P.atol + fabs(y) * P.rtol;
+    const double sc0 = __builtin_fma(__builtin_fabs(x), P.rtol, P.atol);
+    const double sc1 = __builtin_fma(__builtin_fabs(y), P.rtol, P.atol);
     // Fast path (fp32, 5 % margins): decide "h_abs == interval_length" without divisions, square
     // roots or pow.  With r = 1/scale: d0^2 = D0/2, d1^2 = D1/2, (d2*h0)^2 = DD/2.
     //   100*h0 >= dt   <=  d0,d1 >= 1e-5  and  d0/d1 >= dt
@@ -317,10 +348,10 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
         const float r0 = __builtin_amdgcn_rcpf((float)sc0), r1 = __builtin_amdgcn_rcpf((float)sc1);
         const float y0s = (float)x * r0, y1s = (float)y * r1;
         const float g0 = (float)f0x * r0, g1 = (float)f0y * r1;
-        const float e0 = (float)(f1x - f0x) * r0, e1 = (float)(f1y - f0y) * r1;
-        const float D0 = y0s * y0s + y1s * y1s;
-        const float D1 = g0 * g0 + g1 * g1;
-        const float DD = e0 * e0 + e1 * e1;
+        const float e0 = (float)(n1x - n0x) * r0, e1 = (float)(n1y - n0y) * r1;
+        const float D0 = __builtin_fmaf(y0s, y0s, y1s * y1s);
+        const float D1 = __builtin_fmaf(g0, g0, g1 * g1);
+        const float DD = __builtin_fmaf(e0, e0, e1 * e1);
         const float TH2 = P.h1_thresh2_f;
         const bool fast = (D0 > 1e-9f) && (D1 > 1e-9f) && (D0 >= 1.05f * P.dt2_f * D1) && (D1 <= 1.9f * TH2) &&
                           (DD <= 1.9f * TH2 * P.dt2_f) && (DD * D1 <= 1.9e-4f * TH2 * D0);
@@ -331,7 +362,7 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
     const double d1 = rms2(f0x / sc0, f0y / sc1);
     double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
     h0 = fmin(h0, P.dt);
-    const double d2 = rms2((f1x - f0x) / sc0, (f1y - f0y) / sc1) / h0;
+    const double d2 = rms2((spx - f0x) / sc0, (spy - f0y) / sc1) / h0;
     double h1;
     if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
     else h1 = fifth_root(0.01 / fmax(d1, d2));
@@ -342,125 +373,169 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
 // One RK45 env step: OdeSolver.step loop + RungeKutta._step_impl + rk_step, in time
 // relative to the start of the env step (tau in [0, dt]).
 // ---------------------------------------------------------------------------
-constexpr double kB0 = 35.0 / 384, kB2 = 500.0 / 1113, kB3 = 125.0 / 192, kB4 = -2187.0 / 6784, kB5 = 11.0 / 84;
-constexpr double kE0 = -71.0 / 57600, kE2 = 71.0 / 16695, kE3 = -71.0 / 1920, kE4 = 17253.0 / 339200,
-                 kE5 = -22.0 / 525, kE6 = 1.0 / 40;
+constexpr double kB0 = 35.0 / 384, kE0 = -71.0 / 57600;
+constexpr float kB2f = (float)(500.0 / 1113), kB3f = (float)(125.0 / 192), kB4f = (float)(-2187.0 / 6784),
+                kB5f = (float)(11.0 / 84);
+constexpr float kE2f = (float)(71.0 / 16695), kE3f = (float)(-71.0 / 1920), kE4f = (float)(17253.0 / 339200),
+                kE5f = (float)(-22.0 / 525), kE6f = (float)(1.0 / 40);
 constexpr int kMaxAttempts = 4096;  // every lane leaves the loop: bounded spin
 
-template <bool NOISE, bool MIS>
+// weighted noise sums of one rk_step attempt:  nb = sum_{2..5} B_i N_i,  ne = sum_{2..6} E_i N_i,
+// n6 = N_6 (f_new's noise; only matters when another sub-step follows)
+struct AttemptNoise {
+    double nbx, nby, nex, ney, n6x, n6y;
+};
+
+template <int NZ, bool MIS>
+__device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const RhsCtx<MIS>& C, const Rng& R,
+                                                      uint32_t attempt) {
+    AttemptNoise A;
+    if constexpr (NZ == kNoNoise) {
+        A.nbx = A.nby = A.nex = A.ney = A.n6x = A.n6y = 0.0;
+        return A;
+    } else {
+        // Draw order inside the block (= the reference's: stages K1..K5, then f_new = K6):
+        //   nominal     K_i <- normals (2(i-1), 2(i-1)+1) = (z_x, z_y)
+        //   mismatched  K_i <- normals (3(i-1) .. 3(i-1)+2) = (z_a, z_x, z_y)
+        // K1's draws never reach a result (B1 = E1 = 0).
+        constexpr int NC = MIS ? 5 : 3;
+        float z[NC * 4];
+        block_normals<NZ, NC>(R, c0_of(kStreamDyn, attempt, 0), z);
+        constexpr int D = MIS ? 3 : 2;
+        constexpr int O = MIS ? 1 : 0;  // offset of z_x inside an eval's draws
+        const float* k2 = z + D * 1, *k3 = z + D * 2, *k4 = z + D * 3, *k5 = z + D * 4, *k6 = z + D * 5;
+        float bx = kB2f * k2[O], by = kB2f * k2[O + 1];
+        bx = __builtin_fmaf(kB3f, k3[O], bx); by = __builtin_fmaf(kB3f, k3[O + 1], by);
+        bx = __builtin_fmaf(kB4f, k4[O], bx); by = __builtin_fmaf(kB4f, k4[O + 1], by);
+        bx = __builtin_fmaf(kB5f, k5[O], bx); by = __builtin_fmaf(kB5f, k5[O + 1], by);
+        float ex = kE2f * k2[O], ey = kE2f * k2[O + 1];
+        ex = __builtin_fmaf(kE3f, k3[O], ex); ey = __builtin_fmaf(kE3f, k3[O + 1], ey);
+        ex = __builtin_fmaf(kE4f, k4[O], ex); ey = __builtin_fmaf(kE4f, k4[O + 1], ey);
+        ex = __builtin_fmaf(kE5f, k5[O], ex); ey = __builtin_fmaf(kE5f, k5[O + 1], ey);
+        ex = __builtin_fmaf(kE6f, k6[O], ex); ey = __builtin_fmaf(kE6f, k6[O + 1], ey);
+        A.nbx = P.sigma * (double)bx; A.nby = P.sigma * (double)by;
+        A.nex = P.sigma * (double)ex; A.ney = P.sigma * (double)ey;
+        A.n6x = P.sigma * (double)k6[O]; A.n6y = P.sigma * (double)k6[O + 1];
+        if constexpr (MIS) {
+            float ba = kB2f * k2[0], ea = kE2f * k2[0];
+            ba = __builtin_fmaf(kB3f, k3[0], ba); ea = __builtin_fmaf(kE3f, k3[0], ea);
+            ba = __builtin_fmaf(kB4f, k4[0], ba); ea = __builtin_fmaf(kE4f, k4[0], ea);
+            ba = __builtin_fmaf(kB5f, k5[0], ba); ea = __builtin_fmaf(kE5f, k5[0], ea);
+            ea = __builtin_fmaf(kE6f, k6[0], ea);
+            A.nbx = __builtin_fma(C.gx, (double)ba, A.nbx); A.nby = __builtin_fma(C.gy, (double)ba, A.nby);
+            A.nex = __builtin_fma(C.gx, (double)ea, A.nex); A.ney = __builtin_fma(C.gy, (double)ea, A.ney);
+            A.n6x = __builtin_fma(C.gx, (double)k6[0], A.n6x); A.n6y = __builtin_fma(C.gy, (double)k6[0], A.n6y);
+        }
+        return A;
+    }
+}
+
+struct SubStep {
+    double tau, h_abs;
+    uint32_t attempt;
+    bool rejected;
+};
+
+// one rk_step attempt + the accept / reject decision of _step_impl.  Returns true when the
+// attempt was accepted (state advanced to tau = tn).
+template <int NZ, bool MIS>
+__device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, SubStep& S,
+                                             double& x, double& y, double& f0x, double& f0y, int& fail) {
+    double tn = S.tau + S.h_abs;
+    if (tn > P.dt) tn = P.dt;
+    const double h = tn - S.tau;
+    S.h_abs = h;
+    const AttemptNoise A = attempt_noise<NZ, MIS>(P, C, R, S.attempt);
+    S.attempt += 1;
+    const double dfx = f0x - C.vx, dfy = f0y - C.vy;
+    const double sx = __builtin_fma(kB0, dfx, C.vx) + A.nbx;
+    const double sy = __builtin_fma(kB0, dfy, C.vy) + A.nby;
+    const double xn = __builtin_fma(h, sx, x);
+    const double yn = __builtin_fma(h, sy, y);
+    const double ex = h * __builtin_fma(kE0, dfx, A.nex);
+    const double ey = h * __builtin_fma(kE0, dfy, A.ney);
+    const double sc0 = __builtin_fma(fmax(__builtin_fabs(x), __builtin_fabs(xn)), P.rtol, P.atol);
+    const double sc1 = __builtin_fma(fmax(__builtin_fabs(y), __builtin_fabs(yn)), P.rtol, P.atol);
+    const bool last = !(tn < P.dt);
+    // fast accept (no division / sqrt / pow): error_norm^2 = q / lim, 2 % margin; the step-size
+    // factor is only needed when another sub-step follows.
+    const double s00 = sc0 * sc0, s11 = sc1 * sc1;
+    const double q = __builtin_fma(ex * ex, s11, (ey * ey) * s00);
+    const double lim = 2.0 * s00 * s11;
+    bool accepted;
+    if (last && q < 0.98 * lim) {
+        accepted = true;
+    } else {
+        const double error_norm = rms2(ex / sc0, ey / sc1);
+        if (error_norm < 1.0) {
+            double factor = (error_norm == 0.0) ? 10.0 : fmin(10.0, 0.9 * inv_fifth_root(error_norm));
+            if (S.rejected) factor = fmin(1.0, factor);
+            S.h_abs *= factor;
+            accepted = true;
+        } else {
+            S.h_abs *= fmax(0.2, 0.9 * inv_fifth_root(error_norm));
+            S.rejected = true;
+            accepted = false;
+        }
+    }
+    if (!accepted && S.attempt >= (uint32_t)kMaxAttempts) {
+        // The reference would fail with TOO_SMALL_STEP / spin on NaN input: flag it and finish.
+        fail |= 1;
+        accepted = true;
+        tn = P.dt;
+    }
+    if (accepted) {
+        S.tau = tn; x = xn; y = yn;
+        f0x = C.vx + A.n6x; f0y = C.vy + A.n6y;  // f = f_new
+        S.rejected = false;
+    }
+    return accepted;
+}
+
+template <int NZ, bool MIS>
 __device__ __forceinline__ void rk45_integrate(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, double& x,
                                                double& y, double f0x, double f0y, double h_abs, int& fail) {
-    double tau = 0.0;
-    uint32_t attempt = 0;
-    // stage values without noise are the same for every attempt
-    double kx0, ky0;
-    rhs_eval<false, MIS>(P, C, 0.f, 0.f, 0.f, kx0, ky0);
-    while (tau < P.dt) {
-        bool accepted = false, rejected = false;
-        double xn = x, yn = y, fnx = f0x, fny = f0y, tn = tau;
-        while (!accepted) {
-            tn = tau + h_abs;
-            if (tn > P.dt) tn = P.dt;
-            const double h = tn - tau;
-            h_abs = h;
-            // rk_step: K[0] = f (carried), K[1..5] fresh RHS values, K[6] = f_new.
-            // B[1] = E[1] = 0, so K[1] never reaches a result (its draws are still consumed).
-            double k2x, k2y, k3x, k3y, k4x, k4y, k5x, k5y, k6x, k6y;
-            if constexpr (NOISE) {
-                constexpr int NC = MIS ? 5 : 3;
-                float z[NC * 4];
-                block_normals<NC>(R, c0_of(kStreamDyn, attempt, 0), z);
-                if constexpr (MIS) {
-                    rhs_eval<NOISE, MIS>(P, C, z[3], z[4], z[5], k2x, k2y);
-                    rhs_eval<NOISE, MIS>(P, C, z[6], z[7], z[8], k3x, k3y);
-                    rhs_eval<NOISE, MIS>(P, C, z[9], z[10], z[11], k4x, k4y);
-                    rhs_eval<NOISE, MIS>(P, C, z[12], z[13], z[14], k5x, k5y);
-                    rhs_eval<NOISE, MIS>(P, C, z[15], z[16], z[17], k6x, k6y);
-                } else {
-                    rhs_eval<NOISE, MIS>(P, C, 0.f, z[2], z[3], k2x, k2y);
-                    rhs_eval<NOISE, MIS>(P, C, 0.f, z[4], z[5], k3x, k3y);
-                    rhs_eval<NOISE, MIS>(P, C, 0.f, z[6], z[7], k4x, k4y);
-                    rhs_eval<NOISE, MIS>(P, C, 0.f, z[8], z[9], k5x, k5y);
-                    rhs_eval<NOISE, MIS>(P, C, 0.f, z[10], z[11], k6x, k6y);
-                }
-            } else {
-                k2x = k3x = k4x = k5x = k6x = kx0;
-                k2y = k3y = k4y = k5y = k6y = ky0;
-            }
-            ++attempt;
-            // y_new = y + h * dot(K[:-1].T, B)   (sequential, unfused -- as the oracle)
-            const double sx = f0x * kB0 + k2x * kB2 + k3x * kB3 + k4x * kB4 + k5x * kB5;
-            const double sy = f0y * kB0 + k2y * kB2 + k3y * kB3 + k4y * kB4 + k5y * kB5;
-            xn = x + h * sx;
-            yn = y + h * sy;
-            fnx = k6x; fny = k6y;
-            // error_norm = norm(dot(K.T, E) * h / scale),  scale = atol + max(|y|,|y_new|) * rtol
-            const double ex = (f0x * kE0 + k2x * kE2 + k3x * kE3 + k4x * kE4 + k5x * kE5 + k6x * kE6) * h;
-            const double ey = (f0y * kE0 + k2y * kE2 + k3y * kE3 + k4y * kE4 + k5y * kE5 + k6y * kE6) * h;
-            const double sc0 = P.atol + fmax(fabs(x), fabs(xn)) * P.rtol;
-            const double sc1 = P.atol + fmax(fabs(y), fabs(yn)) * P.rtol;
-            const bool last = !(tn < P.dt);
-            // fast accept (no division / sqrt / pow): error_norm^2 = q / lim with a 2 % margin; the
-            // step-size factor is only needed when another sub-step follows.
-            const double s00 = sc0 * sc0, s11 = sc1 * sc1;
-            const double q = ex * ex * s11 + ey * ey * s00;
-            const double lim = 2.0 * s00 * s11;
-            if (last && q < 0.98 * lim) {
-                accepted = true;
-            } else {
-                const double error_norm = rms2(ex / sc0, ey / sc1);
-                if (error_norm < 1.0) {
-                    double factor = (error_norm == 0.0) ? 10.0 : fmin(10.0, 0.9 * inv_fifth_root(error_norm));
-                    if (rejected) factor = fmin(1.0, factor);
-                    h_abs *= factor;
-                    accepted = true;
-                } else {
-                    h_abs *= fmax(0.2, 0.9 * inv_fifth_root(error_norm));
-                    rejected = true;
-                }
-            }
-            if (attempt >= (uint32_t)kMaxAttempts && !accepted) {
-                // The reference would fail with TOO_SMALL_STEP / loop forever on NaN input.
-                fail |= 1;
-                accepted = true;
-                tn = P.dt;
-            }
-        }
-        tau = tn; x = xn; y = yn; f0x = fnx; f0y = fny;
-        if (attempt >= (uint32_t)kMaxAttempts) { fail |= 1; break; }
+    SubStep S{0.0, h_abs, 0u, false};
+    // first attempt peeled: its RNG counters are wave-uniform (attempt = 0), and in the common
+    // regime (|y| >~ 1) it is the only one
+    rk45_attempt<NZ, MIS>(P, C, R, S, x, y, f0x, f0y, fail);
+    while (S.tau < P.dt) {
+        rk45_attempt<NZ, MIS>(P, C, R, S, x, y, f0x, f0y, fail);
+        if (S.attempt >= (uint32_t)kMaxAttempts) { fail |= 1; break; }
     }
 }
 
 // Build extension (BASELINE configs 2/3): fixed-step Euler / classical RK4, noise added to the
 // derivative at every RHS evaluation exactly as `simulate` does.  Mirrors the oracle's loop.
-template <bool NOISE, bool MIS>
+template <int NZ, bool MIS>
 __device__ __forceinline__ void fixed_integrate(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, double& x,
                                                 double& y, double& spx, double& spy) {
     const int S = P.substeps > 0 ? P.substeps : 1;
     const double h = P.dt / S;
     const bool rk4 = (P.integrator == 2);
+    spx = C.vx; spy = C.vy;
     for (int s = 0; s < S; ++s) {
-        double k1x, k1y, k2x, k2y, k3x, k3y, k4x, k4y;
-        if constexpr (NOISE) {
+        double n1x = 0, n1y = 0, n2x = 0, n2y = 0, n3x = 0, n3y = 0, n4x = 0, n4y = 0;
+        if constexpr (NZ != kNoNoise) {
             constexpr int NC = MIS ? 3 : 2;
             float z[NC * 4];
-            block_normals<NC>(R, c0_of(kStreamDyn, (uint32_t)s, 0), z);
+            block_normals<NZ, NC>(R, c0_of(kStreamDyn, (uint32_t)s, 0), z);
             if constexpr (MIS) {
-                rhs_eval<NOISE, MIS>(P, C, z[0], z[1], z[2], k1x, k1y);
-                rhs_eval<NOISE, MIS>(P, C, z[3], z[4], z[5], k2x, k2y);
-                rhs_eval<NOISE, MIS>(P, C, z[6], z[7], z[8], k3x, k3y);
-                rhs_eval<NOISE, MIS>(P, C, z[9], z[10], z[11], k4x, k4y);
+                noise_vec<MIS>(P, C, z[0], z[1], z[2], n1x, n1y);
+                noise_vec<MIS>(P, C, z[3], z[4], z[5], n2x, n2y);
+                noise_vec<MIS>(P, C, z[6], z[7], z[8], n3x, n3y);
+                noise_vec<MIS>(P, C, z[9], z[10], z[11], n4x, n4y);
             } else {
-                rhs_eval<NOISE, MIS>(P, C, 0.f, z[0], z[1], k1x, k1y);
-                rhs_eval<NOISE, MIS>(P, C, 0.f, z[2], z[3], k2x, k2y);
-                rhs_eval<NOISE, MIS>(P, C, 0.f, z[4], z[5], k3x, k3y);
-                rhs_eval<NOISE, MIS>(P, C, 0.f, z[6], z[7], k4x, k4y);
+                noise_vec<MIS>(P, C, 0.f, z[0], z[1], n1x, n1y);
+                noise_vec<MIS>(P, C, 0.f, z[2], z[3], n2x, n2y);
+                noise_vec<MIS>(P, C, 0.f, z[4], z[5], n3x, n3y);
+                noise_vec<MIS>(P, C, 0.f, z[6], z[7], n4x, n4y);
             }
-        } else {
-            rhs_eval<NOISE, MIS>(P, C, 0.f, 0.f, 0.f, k1x, k1y);
-            k2x = k3x = k4x = k1x; k2y = k3y = k4y = k1y;
         }
+        const double k1x = C.vx + n1x, k1y = C.vy + n1y;
         if (rk4) {
+            const double k2x = C.vx + n2x, k2y = C.vy + n2y, k3x = C.vx + n3x, k3y = C.vy + n3y;
+            const double k4x = C.vx + n4x, k4y = C.vy + n4y;
             x = x + (h / 6) * (k1x + 2 * k2x + 2 * k3x + k4x);
             y = y + (h / 6) * (k1y + 2 * k2y + 2 * k3y + k4y);
             spx = k4x; spy = k4y;
@@ -494,19 +569,21 @@ __device__ __forceinline__ void load_env(const double* __restrict__ pos, const f
     e.ep_ret = ep_ret[i];
 }
 
-// quantise the carried RK45 state exactly as it is stored in HBM (so a fused rollout and a
-// sequence of single steps produce identical bits)
+// the carried RK45 state exactly as it is stored in HBM (so a fused rollout and a sequence of
+// single steps produce identical bits)
+__device__ __forceinline__ float hq_of(const KParams& P, double h_abs) { return (float)(h_abs * P.inv_dt); }
+
 __device__ __forceinline__ void quantise_env(const KParams& P, EnvRegs& e) {
     e.f0x = (double)(float)e.f0x;
     e.f0y = (double)(float)e.f0y;
-    e.h_abs = (double)(float)(e.h_abs / P.dt) * P.dt;
+    e.h_abs = (double)hq_of(P, e.h_abs) * P.dt;
 }
 
 __device__ __forceinline__ void store_env(double* __restrict__ pos, float* __restrict__ aux, float* __restrict__ ep_ret,
                                           long long i, const KParams& P, const EnvRegs& e) {
     reinterpret_cast<double2*>(pos)[i] = make_double2(e.x, e.y);
     reinterpret_cast<float4*>(aux)[i] =
-        make_float4((float)e.f0x, (float)e.f0y, (float)(e.h_abs / P.dt), __int_as_float(e.counter));
+        make_float4((float)e.f0x, (float)e.f0y, hq_of(P, e.h_abs), __int_as_float(e.counter));
     ep_ret[i] = e.ep_ret;
 }
 
@@ -530,11 +607,10 @@ struct StepOut {
     float fobs[5];
     float fret;
     int32_t flen;
-    float act_f, act_a;
 };
 
 // MR_Env.reset body for one env (MR_env.py:164-201 -> MR_simulator.py:21-34)
-template <bool RK45, bool NOISE, bool MIS_CTOR>
+template <bool RK45, int NZ, bool MIS_CTOR>
 __device__ __forceinline__ void reset_env(const KParams& P, const Rng& R, double x0, double y0, EnvRegs& e,
                                           double& spx, double& spy) {
     e.x = x0; e.y = y0;
@@ -543,7 +619,7 @@ __device__ __forceinline__ void reset_env(const KParams& P, const Rng& R, double
     spx = spy = 0.0;
     if constexpr (RK45) {
         const RhsCtx<MIS_CTOR> Z = zero_ctx<MIS_CTOR>(P);
-        rk45_construct<NOISE, MIS_CTOR>(P, Z, R, kStreamResetCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy);
+        rk45_construct<NZ, MIS_CTOR>(P, Z, R, kStreamResetCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy);
     } else {
         e.f0x = e.f0y = 0.0;
         e.h_abs = P.dt;
@@ -565,38 +641,41 @@ __device__ __forceinline__ void random_action(const KParams& P, const Rng& R, fl
     al = (float)(P.act_lo[1] + P.act_span[1] * u1);
 }
 
+__device__ __forceinline__ void pack_obs(double x, double y, double gx, double gy, double d2, float (&obs)[5]) {
+    // convert_state (MR_env.py:100-116); dist emitted as the fp32 sqrt of the fp64 squared distance
+    obs[0] = (float)x; obs[1] = (float)y; obs[2] = (float)gx; obs[3] = (float)gy;
+    obs[4] = __builtin_sqrtf((float)d2);
+}
+
 // MR_Env.step for one env (MR_env.py:70-98)
-template <bool RK45, bool NOISE, bool MIS>
+template <bool RK45, int NZ, bool MIS>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
                                          EnvRegs& e, float act_f, float act_a, StepOut& o, int& fail) {
     e.counter += 1;  // :80
-    const double f_t = (double)act_f, al = (double)act_a;
-    const RhsCtx<MIS> C = make_ctx<MIS>(P, f_t, al);
+    const RhsCtx<MIS> C = make_ctx<MIS>(P, (double)act_f, (double)act_a);
     double spx = 0.0, spy = 0.0;
     if constexpr (RK45) {
-        rk45_integrate<NOISE, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail);              // MR_simulator.py:42-45
-        rk45_construct<NOISE, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy);  // :46-50
+        rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail);                  // MR_simulator.py:42-45
+        rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy);  // :46-50
     } else {
-        fixed_integrate<NOISE, MIS>(P, C, R, e.x, e.y, spx, spy);
+        fixed_integrate<NZ, MIS>(P, C, R, e.x, e.y, spx, spy);
         e.f0x = spx; e.f0y = spy; e.h_abs = P.dt;
     }
-    // convert_state (:100-116)
     double gx, gy;
     goal_at(P, goal_table, R.env, e.counter, gx, gy);
     const double dx = gx - e.x, dy = gy - e.y;
-    const double d2 = dx * dx + dy * dy;
-    // end (:136-152) / Box.contains as a numeric bounds test; d compared squared
+    const double d2 = __builtin_fma(dx, dx, dy * dy);
+    // end (:136-152); Box.contains as a numeric bounds test; distances compared squared
     const bool inb = (e.x >= P.obs_lo[0]) && (e.x <= P.obs_hi[0]) && (e.y >= P.obs_lo[1]) && (e.y <= P.obs_hi[1]) &&
                      (gx >= P.obs_lo[2]) && (gx <= P.obs_hi[2]) && (gy >= P.obs_lo[3]) && (gy <= P.obs_hi[3]) &&
-                     (d2 <= P.dmax2) && (P.obs_lo[4] <= 0.0 || d2 >= P.obs_lo[4] * P.obs_lo[4]);
+                     (d2 <= P.dmax2) && (d2 >= P.dmin2);
     const bool timeout = e.counter > P.max_timesteps;
     const bool reached = d2 < P.min_dist2;
     const bool done = (!inb) || timeout || reached;
     float rew = 10.0f;  // :89
     if (P.reward_mode == 1) rew = reached ? 100.0f : ((!inb || timeout) ? -100.0f : -0.1f);  // :118-134
     e.ep_ret += rew;
-    o.obs[0] = (float)e.x; o.obs[1] = (float)e.y; o.obs[2] = (float)gx; o.obs[3] = (float)gy;
-    o.obs[4] = __builtin_sqrtf((float)d2);
+    pack_obs(e.x, e.y, gx, gy, d2, o.obs);
     o.rew = rew;
     o.done = done ? 1 : 0;
     o.spx = (float)spx; o.spy = (float)spy;
@@ -610,12 +689,11 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         o.flen = e.counter;
         double x0, y0, rx, ry;
         sample_init(P, R, x0, y0);
-        reset_env<RK45, NOISE, false>(P, R, x0, y0, e, rx, ry);
+        reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry);
         if constexpr (RK45) { o.spx = (float)rx; o.spy = (float)ry; }  // state_prime = last RHS value
         goal_at(P, goal_table, R.env, 0, gx, gy);
         const double ex = gx - e.x, ey = gy - e.y;
-        o.obs[0] = (float)e.x; o.obs[1] = (float)e.y; o.obs[2] = (float)gx; o.obs[3] = (float)gy;
-        o.obs[4] = __builtin_sqrtf((float)(ex * ex + ey * ey));
+        pack_obs(e.x, e.y, gx, gy, __builtin_fma(ex, ex, ey * ey), o.obs);
     }
 }
 

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "mrsim.h"
 #include "mrsim_device.h"
@@ -43,7 +44,7 @@ struct IOArgs {
 // ---------------------------------------------------------------------------
 // step
 // ---------------------------------------------------------------------------
-template <bool RK45, bool NOISE, bool MIS, bool AOS>
+template <bool RK45, int NZ, bool MIS, bool AOS>
 __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const StateArgs st, const IOArgs io) {
     __shared__ __attribute__((aligned(16))) float s_obs[AOS ? kBlock * 5 : 4];
     const long long base = (long long)blockIdx.x * kBlock;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
             random_action(P, R, af, aa);
         }
         int fail = 0;
-        env_step<RK45, NOISE, MIS>(P, R, io.goal_table, e, af, aa, o, fail);
+        env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, af, aa, o, fail);
         store_env(st.pos, st.aux, st.ep_ret, i, P, e);
         io.rew[i] = o.rew;
         io.done[i] = o.done;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
 // ---------------------------------------------------------------------------
 // reset
 // ---------------------------------------------------------------------------
-template <bool RK45, bool NOISE, bool MIS_CTOR>
+template <bool RK45, int NZ, bool MIS_CTOR>
 __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const StateArgs st,
                                                           const uint8_t* __restrict__ mask,
                                                           const double* __restrict__ init_xy,
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const
     }
     EnvRegs e;
     double spx, spy;
-    reset_env<RK45, NOISE, MIS_CTOR>(P, R, x0, y0, e, spx, spy);
+    reset_env<RK45, NZ, MIS_CTOR>(P, R, x0, y0, e, spx, spy);
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
     if (obs != nullptr) {
         double gx, gy;
@@ -173,7 +174,7 @@ struct RolloutArgs {
     int32_t* status;
 };
 
-template <bool RK45, bool NOISE, bool MIS>
+template <bool RK45, int NZ, bool MIS>
 __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, const StateArgs st, const RolloutArgs ra) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, con
             af = a.x; aa = a.y;
         }
         StepOut o;
-        env_step<RK45, NOISE, MIS>(P, R, ra.goal_table, e, af, aa, o, fail);
+        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, af, aa, o, fail);
         quantise_env(P, e);
         const long long ti = (long long)t * P.n + i;
         if (ra.traj_xy != nullptr) {
@@ -224,12 +225,13 @@ __global__ void mr_advance_kernel(unsigned long long* step_base, unsigned long l
 // ---------------------------------------------------------------------------
 // debug / test aid: raw normals of the RNG definition (bit-compared with the oracle)
 // ---------------------------------------------------------------------------
+template <int NZ>
 __global__ __launch_bounds__(kBlock) void mr_debug_normals_kernel(const KParams P, uint32_t c0, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
     const Rng R = make_rng(P, i);
     float z[4];
-    block_normals<1>(R, c0, z);
+    block_normals<NZ, 1>(R, c0, z);
     reinterpret_cast<float4*>(out)[i] = make_float4(z[0], z[1], z[2], z[3]);
 }
 
@@ -249,11 +251,13 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
     if (p->integrator != MRSIM_INT_RK45 && (p->substeps < 1 || p->substeps > (1 << 20))) return MRSIM_EINVAL;
     if (p->sigma < 0.0 || std::isnan(p->sigma)) return MRSIM_EINVAL;
     std::memset(&K, 0, sizeof(K));
-    K.dt = p->time_span; K.rtol = p->rtol; K.atol = p->atol; K.a0 = p->a0;
+    if (p->noise_math != MRSIM_NOISE_FAST && p->noise_math != MRSIM_NOISE_SPEC) return MRSIM_EINVAL;
+    K.dt = p->time_span; K.inv_dt = 1.0 / p->time_span; K.rtol = p->rtol; K.atol = p->atol; K.a0 = p->a0;
     K.sigma = p->sigma; K.sigma4 = p->sigma / 4;
     K.min_dist2 = p->min_dist2goal * p->min_dist2goal;
-    for (int j = 0; j < 5; ++j) { K.obs_lo[j] = p->obs_low[j]; K.obs_hi[j] = p->obs_high[j]; }
+    for (int j = 0; j < 4; ++j) { K.obs_lo[j] = p->obs_low[j]; K.obs_hi[j] = p->obs_high[j]; }
     K.dmax2 = p->obs_high[4] * p->obs_high[4];
+    K.dmin2 = p->obs_low[4] > 0.0 ? p->obs_low[4] * p->obs_low[4] : 0.0;
     for (int j = 0; j < 2; ++j) {
         K.init_lo[j] = p->init_low[j]; K.init_span[j] = p->init_high[j] - p->init_low[j];
         K.act_lo[j] = p->act_low[j]; K.act_span[j] = p->act_high[j] - p->act_low[j];
@@ -300,22 +304,35 @@ static int launch(const LaunchCfg& lc, Kern kern, long long n, Args... args) {
     return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 
-template <bool RK45, bool NOISE, bool MIS>
-static int launch_step_l(const LaunchCfg& lc, bool aos, const KParams& K, const StateArgs& S, const IOArgs& IO) {
-    if (aos) return launch(lc, mr_step_kernel<RK45, NOISE, MIS, true>, K.n, K, S, IO);
-    return launch(lc, mr_step_kernel<RK45, NOISE, MIS, false>, K.n, K, S, IO);
+// runtime (integrator, noise variant, mismatch) -> template instantiation
+static int noise_variant(const MrsimParams* p) {
+    if (p->sigma == 0.0) return kNoNoise;
+    return p->noise_math == MRSIM_NOISE_SPEC ? kNoiseSpec : kNoiseFast;
 }
 
-template <bool RK45, bool NOISE>
-static int launch_step_m(const LaunchCfg& lc, bool mis, bool aos, const KParams& K, const StateArgs& S, const IOArgs& IO) {
-    return mis ? launch_step_l<RK45, NOISE, true>(lc, aos, K, S, IO) : launch_step_l<RK45, NOISE, false>(lc, aos, K, S, IO);
+template <typename F>
+static int dispatch(bool rk45, int nz, bool mis, F&& f) {
+    auto with_mis = [&](auto RK, auto NZ) {
+        return mis ? f(RK, NZ, std::true_type{}) : f(RK, NZ, std::false_type{});
+    };
+    auto with_nz = [&](auto RK) {
+        switch (nz) {
+            case kNoNoise: return with_mis(RK, std::integral_constant<int, kNoNoise>{});
+            case kNoiseSpec: return with_mis(RK, std::integral_constant<int, kNoiseSpec>{});
+            default: return with_mis(RK, std::integral_constant<int, kNoiseFast>{});
+        }
+    };
+    return rk45 ? with_nz(std::true_type{}) : with_nz(std::false_type{});
 }
 
 static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams& K, const StateArgs& S, const IOArgs& IO) {
-    const bool rk45 = p->integrator == MRSIM_INT_RK45, noise = p->sigma != 0.0, mis = p->mismatched != 0;
     const bool aos = p->obs_layout == MRSIM_OBS_AOS;
-    if (rk45) return noise ? launch_step_m<true, true>(lc, mis, aos, K, S, IO) : launch_step_m<true, false>(lc, mis, aos, K, S, IO);
-    return noise ? launch_step_m<false, true>(lc, mis, aos, K, S, IO) : launch_step_m<false, false>(lc, mis, aos, K, S, IO);
+    return dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
+        constexpr bool rk = decltype(RK)::value, mis = decltype(MIS)::value;
+        constexpr int nz = decltype(NZ)::value;
+        if (aos) return launch(lc, mr_step_kernel<rk, nz, mis, true>, K.n, K, S, IO);
+        return launch(lc, mr_step_kernel<rk, nz, mis, false>, K.n, K, S, IO);
+    });
 }
 
 static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, const MrsimStepIO* io,
@@ -343,19 +360,6 @@ static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
     (void)hipEventDestroy(lc.start);
     (void)hipEventDestroy(lc.stop);
     return rc;
-}
-
-template <bool RK45, bool NOISE>
-static int launch_reset_m(const LaunchCfg& lc, bool mis, const KParams& K, const StateArgs& S, const uint8_t* mask,
-                          const double* init_xy, const float* goal_table, float* obs, int layout) {
-    if (mis) return launch(lc, mr_reset_kernel<RK45, NOISE, true>, K.n, K, S, mask, init_xy, goal_table, obs, layout);
-    return launch(lc, mr_reset_kernel<RK45, NOISE, false>, K.n, K, S, mask, init_xy, goal_table, obs, layout);
-}
-
-template <bool RK45, bool NOISE>
-static int launch_rollout_m(const LaunchCfg& lc, bool mis, const KParams& K, const StateArgs& S, const RolloutArgs& ra) {
-    if (mis) return launch(lc, mr_rollout_kernel<RK45, NOISE, true>, K.n, K, S, ra);
-    return launch(lc, mr_rollout_kernel<RK45, NOISE, false>, K.n, K, S, ra);
 }
 
 }  // namespace mrsim
@@ -401,6 +405,8 @@ int mrsim_default_params(MrsimParams* p) {
     p->auto_reset = 0;
     p->goal_K = 1; p->goal_T = 1;
     p->obs_layout = MRSIM_OBS_AOS;
+    p->noise_math = MRSIM_NOISE_FAST;
+    p->step_base = nullptr;
     return MRSIM_OK;
 }
 
@@ -416,11 +422,12 @@ int mrsim_reset(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimSt
     if ((rc = check_device())) return rc;
     const StateArgs S{st->pos, st->aux, st->ep_ret};
     const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
-    const bool rk45 = p->integrator == MRSIM_INT_RK45, noise = p->sigma != 0.0, mis = ctor_mismatched != 0;
-    if (rk45)
-        return noise ? launch_reset_m<true, true>(lc, mis, K, S, mask, init_xy, goal_table, obs, p->obs_layout)
-                     : launch_reset_m<true, false>(lc, mis, K, S, mask, init_xy, goal_table, obs, p->obs_layout);
-    return launch_reset_m<false, false>(lc, false, K, S, mask, init_xy, goal_table, obs, p->obs_layout);
+    const bool rk45 = p->integrator == MRSIM_INT_RK45;
+    // fixed-step modes carry no RK45 object: nothing stochastic happens in their reset
+    return dispatch(rk45, rk45 ? noise_variant(p) : kNoNoise, rk45 && ctor_mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
+        return launch(lc, mr_reset_kernel<decltype(RK)::value, decltype(NZ)::value, decltype(MIS)::value>, K.n, K, S, mask,
+                      init_xy, goal_table, obs, (int)p->obs_layout);
+    });
 }
 
 int mrsim_step(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, const MrsimStepIO* io,
@@ -464,9 +471,9 @@ int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mrsim
     const RolloutArgs ra{T, shared_actions, p->obs_layout, 0, actions, goal_table, traj_xy, obs_T, rew_T, done_T,
                          actions_out_T, status};
     const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
-    const bool rk45 = p->integrator == MRSIM_INT_RK45, noise = p->sigma != 0.0, mis = p->mismatched != 0;
-    if (rk45) return noise ? launch_rollout_m<true, true>(lc, mis, K, S, ra) : launch_rollout_m<true, false>(lc, mis, K, S, ra);
-    return noise ? launch_rollout_m<false, true>(lc, mis, K, S, ra) : launch_rollout_m<false, false>(lc, mis, K, S, ra);
+    return dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
+        return launch(lc, mr_rollout_kernel<decltype(RK)::value, decltype(NZ)::value, decltype(MIS)::value>, K.n, K, S, ra);
+    });
 }
 
 int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream) {
@@ -478,8 +485,8 @@ int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream) {
     return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 
-int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, uint32_t c0, float* out,
-                        void* stream) {
+int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, uint32_t c0, int32_t noise_math,
+                        float* out, void* stream) {
     MrsimParams p;
     mrsim_default_params(&p);
     KParams K;
@@ -489,7 +496,8 @@ int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t ste
     if (!aligned16(out)) return MRSIM_EALIGN;
     if ((rc = check_device())) return rc;
     const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
-    return launch(lc, mr_debug_normals_kernel, K.n, K, c0, out);
+    if (noise_math == MRSIM_NOISE_SPEC) return launch(lc, mr_debug_normals_kernel<kNoiseSpec>, K.n, K, c0, out);
+    return launch(lc, mr_debug_normals_kernel<kNoiseFast>, K.n, K, c0, out);
 }
 
 int mrsim_device_count(void) {
