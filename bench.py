@@ -4,12 +4,20 @@
 Workload (BASELINE config 4): N = 262 144 envs per GPU, integrator = reference
 (SciPy-RK45 semantics), sigma = 1 (MR_Env.reset default), uniform random policy in the DDPG actor
 range drawn on device, reward + done on device, same-step auto-reset (every episode is 51 steps),
-seed 7.  One "step" = one env.step() of all N envs = [policy kernel -> actions in HBM] +
-[step kernel], captured as a hipGraph of --graph-len steps.  With --gpus N>1 every rank owns a
-contiguous shard of N*262144 envs (weak scaling), there is no data-path collective, and episode
-returns are all-gathered over RCCL at episode boundaries (every 51 steps) inside the timed region.
+seed 7.  One "step" = one MR_Env.step() of all N envs.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+--mode rollout (default): the fused kernel advances all envs --rollout-len (= 51, one episode) steps
+    per launch with the env state in registers and writes every step's transition (obs[5], action[2],
+    reward, done = 33 B per env-step) to [T, N, ...] buffers in HBM -- the DDPG warm-up/rollout
+    workload.  K steps = K / 51 launches.
+--mode step: one launch per env.step() (the drop-in gym loop): [policy kernel -> actions in HBM] +
+    [step kernel], captured as a hipGraph of --graph-len steps.
+
+With --gpus N>1 every rank owns a contiguous shard of N x 262144 envs (weak scaling), there is no
+data-path collective, and episode returns are all-gathered over RCCL at episode boundaries (every
+51 steps) inside the timed region.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel of the chosen mode) and
 `cpu_baseline` objects.
 """
 import argparse
@@ -22,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = 97   # fp64 positions -> reads 40 + writes 57
+ALGO_BYTES_PER_ENV_STEP = 97   # fp64 positions -> reads 40 + writes 57 per env-step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -32,21 +40,23 @@ def parse():
     ap.add_argument("--steps", type=int, default=510)     # 10 episodes
     ap.add_argument("--warmup", type=int, default=51)
     ap.add_argument("--envs-per-gpu", type=int, default=262144)
-    ap.add_argument("--policy", choices=["kernel", "fused"], default="kernel")
-    ap.add_argument("--launch", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--mode", choices=["rollout", "step"], default="rollout")
+    ap.add_argument("--rollout-len", type=int, default=51)
+    ap.add_argument("--policy", choices=["kernel", "fused"], default="kernel", help="step mode only")
+    ap.add_argument("--launch", choices=["graph", "eager"], default="graph", help="step mode only")
     ap.add_argument("--graph-len", type=int, default=51)
     ap.add_argument("--obs-layout", choices=["aos", "soa"], default="aos")
+    ap.add_argument("--noise-math", choices=["fast", "spec"], default="fast")
     ap.add_argument("--sigma", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--kernel-samples", type=int, default=102)
+    ap.add_argument("--kernel-samples", type=int, default=0, help="0 = auto")
     return ap.parse_args()
 
 
 def cpu_baseline(cfg, seed, target_seconds):
     """The oracle (C restatement, kind "port") timed on this box's host cores on a bounded sample of
     the same workload: n_cpu envs, same config, random policy, auto-reset."""
-    import numpy as np
     from oracle import oracle as O
     from tests.util import orc_params_from_cfg
     cores = len(os.sched_getaffinity(0))
@@ -58,8 +68,7 @@ def cpu_baseline(cfg, seed, target_seconds):
     a = orc.random_policy(1, lo, hi)
     orc.step(a, 1)  # warm
     t0 = time.perf_counter()
-    steps = 0
-    k = 2
+    steps, k = 0, 2
     while True:
         a = orc.random_policy(k, lo, hi)
         orc.step(a, k)
@@ -96,53 +105,68 @@ def main():
     total = n_local * world
     env_id0, _ = shard_of(total, rank, world)
     seed = 7
-    cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, seed=seed)
+    cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math,
+                   seed=seed)
     env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0)
     env.reset()
     gatherer = ReturnGatherer(env, world)
-    K, W, G = args.steps, args.warmup, args.graph_len
+    K, W = args.steps, args.warmup
     ep = cfg.max_timesteps + 1
-
-    act = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
-
-    def eager_step():
-        if args.policy == "kernel":
-            env.step(env.random_policy(out=act))
-        else:
-            env.step(None)
-
-    graph = None
-    if args.launch == "graph":
-        graph = env.capture_steps(G, policy=args.policy)
-
     done_steps = [0]
+    WANT = ("obs", "rew", "done", "actions")
 
-    def run(nsteps):
-        """exactly nsteps env steps; all-gather of episode returns at each episode boundary"""
-        left = nsteps
-        while left > 0:
-            to_boundary = ep - (done_steps[0] % ep)
-            chunk = min(left, to_boundary)
-            if graph is not None and chunk == G:
-                graph.replay()
+    if args.mode == "rollout":
+        T = args.rollout_len
+        bufs = {}
+
+        def run(nsteps):
+            """exactly nsteps env steps in launches of <= T, cut at episode boundaries"""
+            left = nsteps
+            while left > 0:
+                chunk = min(left, T, ep - (done_steps[0] % ep))
+                env.rollout(chunk, actions=None, want=WANT, out=bufs if chunk == T else None)
+                done_steps[0] += chunk
+                left -= chunk
+                if done_steps[0] % ep == 0:
+                    gatherer.gather()  # RCCL all-gather of this episode's returns
+        launch_desc = {"rollout_len": T, "transition_bytes_per_env_step": 33}
+    else:
+        G = args.graph_len
+        act = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
+
+        def eager_step():
+            if args.policy == "kernel":
+                env.step(env.random_policy(out=act))
             else:
-                if graph is not None:
-                    env.step_idx = 0
-                for _ in range(chunk):
-                    eager_step()
-                if graph is not None:
-                    env.advance_step_base(chunk); env.step_idx = 0
-            done_steps[0] += chunk
-            left -= chunk
-            if done_steps[0] % ep == 0:
-                gatherer.gather()  # RCCL all-gather of this episode's returns (no-op object at world=1)
+                env.step(None)
+
+        graph = env.capture_steps(G, policy=args.policy) if args.launch == "graph" else None
+
+        def run(nsteps):
+            left = nsteps
+            while left > 0:
+                chunk = min(left, ep - (done_steps[0] % ep))
+                if graph is not None and chunk == G:
+                    graph.replay()
+                else:
+                    if graph is not None:
+                        env.step_idx = 0
+                    for _ in range(chunk):
+                        eager_step()
+                    if graph is not None:
+                        env.advance_step_base(chunk)
+                        env.step_idx = 0
+                done_steps[0] += chunk
+                left -= chunk
+                if done_steps[0] % ep == 0:
+                    gatherer.gather()
+        launch_desc = {"policy": args.policy, "launch": args.launch, "graph_len": G if graph is not None else 0}
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # warm-up (the capture already ran G steps once for real)
     run(W)
     barrier()
     t0 = time.perf_counter()
@@ -157,23 +181,29 @@ def main():
     env.check_status()
     mean_ret = gatherer.last_mean()
 
-    # ---- per-kernel duration of the dominant kernel (the step kernel), HIP events attached to the
-    # dispatch (hipExtLaunchKernelGGL) on the stream it runs on; same state regime, right after the
-    # timed region.
+    # ---- duration of the dominant kernel, HIP events attached to the dispatch (hipExtLaunchKernelGGL)
+    # on the stream it runs on; same state regime, right after the timed region.
     roof = None
     if rank == 0:
-        ms = []
-        for i in range(args.kernel_samples):
-            a = env.random_policy(out=act) if args.policy == "kernel" else None
-            ms.append(env.step_timed(a))
-        ms = sorted(ms)
+        if args.mode == "rollout":
+            T = args.rollout_len
+            ns = args.kernel_samples or 10
+            ms = sorted(env.rollout(T, actions=None, want=WANT, out=bufs, timed=True)["kernel_ms"] for _ in range(ns))
+            units = n_local * T
+            kname = "mr_rollout_kernel<RK45,%s,nominal>" % ("nonoise" if args.sigma == 0 else args.noise_math)
+        else:
+            ns = args.kernel_samples or 102
+            ms = sorted(env.step_timed(env.random_policy(out=act) if args.policy == "kernel" else None)
+                        for _ in range(ns))
+            units = n_local
+            kname = "mr_step_kernel<RK45,%s,nominal,%s>" % ("nonoise" if args.sigma == 0 else args.noise_math,
+                                                            args.obs_layout)
         avg_ms = sum(ms) / len(ms)
-        ach = n_local * ALGO_BYTES_PER_ENV_STEP / (avg_ms * 1e-3) / 1e9
+        ach = units * ALGO_BYTES_PER_ENV_STEP / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "mr_step_kernel<RK45,noise,nominal,%s>" % args.obs_layout,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kname,
                 "avg_kernel_us": round(avg_ms * 1e3, 3), "median_kernel_us": round(ms[len(ms) // 2] * 1e3, 3),
-                "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "envs_per_launch": n_local}
+                "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "env_steps_per_launch": units}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, seed, args.cpu_seconds)
@@ -182,19 +212,18 @@ def main():
         dist.barrier()
     if rank == 0:
         value = total * K / el
-        out = {
-            "metric": "env-steps/sec at N parallel envs", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE config 4: DDPG rollout, uniform random policy in the actor range drawn "
-                                   "on device, sigma=1, integrator=reference(RK45), reward+done on device, auto-reset",
-                       "envs_per_gpu": n_local, "total_envs": total, "policy": args.policy, "launch": args.launch,
-                       "graph_len": G if graph is not None else 0, "obs_layout": args.obs_layout,
-                       "sigma": args.sigma, "seed": seed, "mean_episode_return": mean_ret,
-                       "returns_allgather": "rccl every 51 steps" if world > 1 else "local"},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
+        config = {"workload": "BASELINE config 4: DDPG rollout, uniform random policy in the actor range drawn on "
+                              "device, sigma=%g, integrator=reference(RK45), reward+done on device, auto-reset, all "
+                              "transitions written to HBM" % args.sigma,
+                  "mode": args.mode, "envs_per_gpu": n_local, "total_envs": total, "obs_layout": args.obs_layout,
+                  "noise_math": args.noise_math, "sigma": args.sigma, "seed": seed,
+                  "mean_episode_return": mean_ret,
+                  "returns_allgather": "rccl every 51 steps" if world > 1 else "local"}
+        config.update(launch_desc)
+        out = {"metric": "env-steps/sec at N parallel envs", "value": value, "unit": "env-steps/s",
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic", "config": config, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -148,6 +148,14 @@ int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mrsim
                   float* traj_xy, float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T,
                   int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream);
 
+/* mrsim_rollout with HIP events attached to the dispatch: *kernel_ms_host = kernel duration
+ * (synchronises the stream; measurement aid for bench.py). */
+int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
+                        int32_t T, const float* actions, int32_t shared_actions, const float* goal_table,
+                        float* traj_xy, float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T,
+                        int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream,
+                        float* kernel_ms_host);
+
 /* *step_base += delta on `stream` (a one-lane kernel; graph-capturable). */
 int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream);
 

@@ -448,12 +448,15 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
     const AttemptNoise A = attempt_noise<NZ, MIS>(P, C, R, S.attempt);
     S.attempt += 1;
     const double dfx = f0x - C.vx, dfy = f0y - C.vy;
-    const double sx = __builtin_fma(kB0, dfx, C.vx) + A.nbx;
-    const double sy = __builtin_fma(kB0, dfy, C.vy) + A.nby;
+    double sx = __builtin_fma(kB0, dfx, C.vx), sy = __builtin_fma(kB0, dfy, C.vy);
+    double ex = kE0 * dfx, ey = kE0 * dfy;
+    if constexpr (NZ != kNoNoise) {
+        sx += A.nbx; sy += A.nby;
+        ex += A.nex; ey += A.ney;
+    }
     const double xn = __builtin_fma(h, sx, x);
     const double yn = __builtin_fma(h, sy, y);
-    const double ex = h * __builtin_fma(kE0, dfx, A.nex);
-    const double ey = h * __builtin_fma(kE0, dfy, A.ney);
+    ex *= h; ey *= h;
     const double sc0 = __builtin_fma(fmax(__builtin_fabs(x), __builtin_fabs(xn)), P.rtol, P.atol);
     const double sc1 = __builtin_fma(fmax(__builtin_fabs(y), __builtin_fabs(yn)), P.rtol, P.atol);
     const bool last = !(tn < P.dt);
@@ -486,7 +489,8 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
     }
     if (accepted) {
         S.tau = tn; x = xn; y = yn;
-        f0x = C.vx + A.n6x; f0y = C.vy + A.n6y;  // f = f_new
+        f0x = C.vx; f0y = C.vy;  // f = f_new
+        if constexpr (NZ != kNoNoise) { f0x += A.n6x; f0y += A.n6y; }
         S.rejected = false;
     }
     return accepted;

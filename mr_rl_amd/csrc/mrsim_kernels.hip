@@ -453,10 +453,10 @@ int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float
     return launch(lc, mr_policy_kernel, K.n, K, actions);
 }
 
-int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
-                  const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy, float* obs_T,
-                  float* rew_T, uint8_t* done_T, float* actions_out_T, int32_t* status, uint64_t seed,
-                  uint64_t step_idx0, void* stream) {
+static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
+                        const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy,
+                        float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T, int32_t* status,
+                        uint64_t seed, uint64_t step_idx0, void* stream, float* kernel_ms) {
     KParams K;
     int rc = make_kparams(p, n, env_id0, seed, step_idx0, K);
     if (rc) return rc;
@@ -470,10 +470,37 @@ int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mrsim
     const StateArgs S{st->pos, st->aux, st->ep_ret};
     const RolloutArgs ra{T, shared_actions, p->obs_layout, 0, actions, goal_table, traj_xy, obs_T, rew_T, done_T,
                          actions_out_T, status};
-    const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
-    return dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
+    LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    if (kernel_ms != nullptr && (hipEventCreate(&lc.start) != hipSuccess || hipEventCreate(&lc.stop) != hipSuccess))
+        return MRSIM_ELAUNCH;
+    rc = dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
         return launch(lc, mr_rollout_kernel<decltype(RK)::value, decltype(NZ)::value, decltype(MIS)::value>, K.n, K, S, ra);
     });
+    if (kernel_ms != nullptr) {
+        if (rc == MRSIM_OK && (hipEventSynchronize(lc.stop) != hipSuccess ||
+                               hipEventElapsedTime(kernel_ms, lc.start, lc.stop) != hipSuccess))
+            rc = MRSIM_ELAUNCH;
+        (void)hipEventDestroy(lc.start);
+        (void)hipEventDestroy(lc.stop);
+    }
+    return rc;
+}
+
+int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
+                  const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy, float* obs_T,
+                  float* rew_T, uint8_t* done_T, float* actions_out_T, int32_t* status, uint64_t seed,
+                  uint64_t step_idx0, void* stream) {
+    return rollout_impl(p, n, env_id0, st, T, actions, shared_actions, goal_table, traj_xy, obs_T, rew_T, done_T,
+                        actions_out_T, status, seed, step_idx0, stream, nullptr);
+}
+
+int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
+                        const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy,
+                        float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T, int32_t* status,
+                        uint64_t seed, uint64_t step_idx0, void* stream, float* kernel_ms_host) {
+    if (kernel_ms_host == nullptr) return MRSIM_EINVAL;
+    return rollout_impl(p, n, env_id0, st, T, actions, shared_actions, goal_table, traj_xy, obs_T, rew_T, done_T,
+                        actions_out_T, status, seed, step_idx0, stream, kernel_ms_host);
 }
 
 int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream) {

@@ -255,7 +255,7 @@ class MRVecEnv:
         _lib.check(rc, "mrsim_random_policy")
         return out
 
-    def rollout(self, T, actions=None, shared_actions=False, want=("traj",)):
+    def rollout(self, T, actions=None, shared_actions=False, want=("traj",), out=None, timed=False):
         """T fused steps in one launch (batched utils.run_sim).  actions: [T,N,2], or [T,2] with
         shared_actions=True, or None for the on-device random policy.  Returns a dict of [T,...] tensors."""
         torch = _torch()
@@ -264,17 +264,33 @@ class MRVecEnv:
         if actions is not None:
             act_t = torch.as_tensor(actions, dtype=torch.float32, device=dev).contiguous()
             assert act_t.shape == ((T, 2) if shared_actions else (T, n, 2))
-        out = {}
-        traj = torch.empty((T, n, 2), dtype=torch.float32, device=dev) if "traj" in want else None
-        obs_T = torch.empty((T, 5, n) if self._soa else (T, n, 5), dtype=torch.float32, device=dev) if "obs" in want else None
-        rew_T = torch.empty((T, n), dtype=torch.float32, device=dev) if "rew" in want else None
-        done_T = torch.empty((T, n), dtype=torch.uint8, device=dev) if "done" in want else None
-        acts_T = torch.empty((T, n, 2), dtype=torch.float32, device=dev) if "actions" in want else None
-        rc = self._L.mrsim_rollout(C.byref(self._params), n, self.env_id0, C.byref(self._st), int(T), self._p(act_t),
-                                   int(bool(shared_actions)), self._p(self.goal_table), self._p(traj), self._p(obs_T),
-                                   self._p(rew_T), self._p(done_T), self._p(acts_T), self._p(self.status),
-                                   self.seed_value, self.step_idx, self._stream())
-        _lib.check(rc, "mrsim_rollout")
+        # `out` lets a caller reuse preallocated [T,...] buffers (keys "_traj", "_obs", "_rew", "_done", "_actions")
+        buf = out if out is not None else {}
+
+        def get(key, shape, dtype):
+            if key[1:] not in want:
+                return None
+            t = buf.get(key)
+            if t is None:
+                t = buf[key] = torch.empty(shape, dtype=dtype, device=dev)
+            return t
+
+        traj = get("_traj", (T, n, 2), torch.float32)
+        obs_T = get("_obs", (T, 5, n) if self._soa else (T, n, 5), torch.float32)
+        rew_T = get("_rew", (T, n), torch.float32)
+        done_T = get("_done", (T, n), torch.uint8)
+        acts_T = get("_actions", (T, n, 2), torch.float32)
+        out = buf
+        args = [C.byref(self._params), n, self.env_id0, C.byref(self._st), int(T), self._p(act_t),
+                int(bool(shared_actions)), self._p(self.goal_table), self._p(traj), self._p(obs_T),
+                self._p(rew_T), self._p(done_T), self._p(acts_T), self._p(self.status),
+                self.seed_value, self.step_idx, self._stream()]
+        if timed:
+            ms = C.c_float(0.0)
+            _lib.check(self._L.mrsim_rollout_timed(*args, C.byref(ms)), "mrsim_rollout_timed")
+            out["kernel_ms"] = ms.value
+        else:
+            _lib.check(self._L.mrsim_rollout(*args), "mrsim_rollout")
         self.step_idx += int(T)
         if traj is not None:
             out["traj"] = traj
