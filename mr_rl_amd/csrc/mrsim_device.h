@@ -85,9 +85,18 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        // Rounds 0-2 still have wave-uniform operands (step index, seed, call id live in SGPRs) and are
+        // left to the scalar unit; from round 3 on everything is per-lane and the three-input xor is one
+        // VALU op (v_bitop3_b32, truth table 0x96; gfx950 has no v_xor3).
+        uint32_t n0, n2;
+        if (r < 3) {
+            n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+            n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        } else {
+            n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+            n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+        }
         const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
         const uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u;
@@ -175,13 +184,16 @@ __device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float& z0, 
     }
 }
 
-// the first NCALLS*4 normals of one block (rk_step attempt / constructor / fixed sub-step)
-template <int NZ, int NCALLS>
-__device__ __forceinline__ void block_normals(const Rng& R, uint32_t c0base, float (&z)[NCALLS * 4]) {
+// the first NCALLS*4 normals of one block (rk_step attempt / constructor / fixed sub-step).
+// HAVE0: the Philox words of call 0 were already computed by the caller (w0).
+template <int NZ, int NCALLS, bool HAVE0 = false>
+__device__ __forceinline__ void block_normals(const Rng& R, uint32_t c0base, float (&z)[NCALLS * 4],
+                                              const uint32_t* w0 = nullptr) {
 #pragma unroll
     for (int j = 0; j < NCALLS; ++j) {
         uint32_t o[4];
-        philox_call(R, c0base | (uint32_t)j, o);
+        if (HAVE0 && j == 0) { o[0] = w0[0]; o[1] = w0[1]; o[2] = w0[2]; o[3] = w0[3]; }
+        else philox_call(R, c0base | (uint32_t)j, o);
         box_muller<NZ>(o[0], o[1], z[4 * j + 0], z[4 * j + 1]);
         box_muller<NZ>(o[2], o[3], z[4 * j + 2], z[4 * j + 3]);
     }
@@ -386,9 +398,9 @@ struct AttemptNoise {
     double nbx, nby, nex, ney, n6x, n6y;
 };
 
-template <int NZ, bool MIS>
+template <int NZ, bool MIS, bool FIRST>
 __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const RhsCtx<MIS>& C, const Rng& R,
-                                                      uint32_t attempt) {
+                                                      uint32_t attempt, const uint32_t* d0) {
     AttemptNoise A;
     if constexpr (NZ == kNoNoise) {
         A.nbx = A.nby = A.nex = A.ney = A.n6x = A.n6y = 0.0;
@@ -400,7 +412,9 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         // K1's draws never reach a result (B1 = E1 = 0).
         constexpr int NC = MIS ? 5 : 3;
         float z[NC * 4];
-        block_normals<NZ, NC>(R, c0_of(kStreamDyn, attempt, 0), z);
+        // FIRST: attempt 0, whose call 0 (= DYN block 0 call 0) the caller already computed
+        if constexpr (FIRST) block_normals<NZ, NC, true>(R, c0_of(kStreamDyn, 0, 0), z, d0);
+        else block_normals<NZ, NC>(R, c0_of(kStreamDyn, attempt, 0), z);
         constexpr int D = MIS ? 3 : 2;
         constexpr int O = MIS ? 1 : 0;  // offset of z_x inside an eval's draws
         const float* k2 = z + D * 1, *k3 = z + D * 2, *k4 = z + D * 3, *k5 = z + D * 4, *k6 = z + D * 5;
@@ -438,14 +452,15 @@ struct SubStep {
 
 // one rk_step attempt + the accept / reject decision of _step_impl.  Returns true when the
 // attempt was accepted (state advanced to tau = tn).
-template <int NZ, bool MIS>
+template <int NZ, bool MIS, bool FIRST>
 __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, SubStep& S,
-                                             double& x, double& y, double& f0x, double& f0y, int& fail) {
+                                             double& x, double& y, double& f0x, double& f0y, int& fail,
+                                             const uint32_t* d0) {
     double tn = S.tau + S.h_abs;
     if (tn > P.dt) tn = P.dt;
     const double h = tn - S.tau;
     S.h_abs = h;
-    const AttemptNoise A = attempt_noise<NZ, MIS>(P, C, R, S.attempt);
+    const AttemptNoise A = attempt_noise<NZ, MIS, FIRST>(P, C, R, S.attempt, d0);
     S.attempt += 1;
     const double dfx = f0x - C.vx, dfy = f0y - C.vy;
     double sx = __builtin_fma(kB0, dfx, C.vx), sy = __builtin_fma(kB0, dfy, C.vy);
@@ -498,13 +513,14 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
 
 template <int NZ, bool MIS>
 __device__ __forceinline__ void rk45_integrate(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, double& x,
-                                               double& y, double f0x, double f0y, double h_abs, int& fail) {
+                                               double& y, double f0x, double f0y, double h_abs, int& fail,
+                                               const uint32_t* d0) {
     SubStep S{0.0, h_abs, 0u, false};
     // first attempt peeled: its RNG counters are wave-uniform (attempt = 0), and in the common
     // regime (|y| >~ 1) it is the only one
-    rk45_attempt<NZ, MIS>(P, C, R, S, x, y, f0x, f0y, fail);
+    rk45_attempt<NZ, MIS, true>(P, C, R, S, x, y, f0x, f0y, fail, d0);
     while (S.tau < P.dt) {
-        rk45_attempt<NZ, MIS>(P, C, R, S, x, y, f0x, f0y, fail);
+        rk45_attempt<NZ, MIS, false>(P, C, R, S, x, y, f0x, f0y, fail, nullptr);
         if (S.attempt >= (uint32_t)kMaxAttempts) { fail |= 1; break; }
     }
 }
@@ -638,11 +654,29 @@ __device__ __forceinline__ void sample_init(const KParams& P, const Rng& R, doub
     y0 = (double)(float)(P.init_lo[1] + P.init_span[1] * u1);
 }
 
-__device__ __forceinline__ void random_action(const KParams& P, const Rng& R, float& f_t, float& al) {
-    double u0, u1;
-    uniform2(R, c0_of(kStreamPolicy, 0, 0), u0, u1);
+// Exploration policy: action ~ U[act_lo, act_lo + act_span) from the first two words of one Philox call.
+// In RK45 mode that call is DYN block 0 call 0: its words 0,1 would only feed stage K1 of the first
+// rk_step attempt, which never reaches a result (B1 = E1 = 0), so the policy reuses them and the
+// fused kernels pay one Philox call less per step.  Fixed-step modes consume those words for noise,
+// so there the policy has a call of its own (POLICY stream).
+__device__ __forceinline__ constexpr uint32_t policy_c0(bool rk45) {
+    return rk45 ? c0_of(kStreamDyn, 0, 0) : c0_of(kStreamPolicy, 0, 0);
+}
+__device__ __forceinline__ void action_from_words(const KParams& P, const uint32_t* w, float& f_t, float& al) {
+    const double u0 = ((double)w[0] + 0.5) * 2.3283064365386963e-10;
+    const double u1 = ((double)w[1] + 0.5) * 2.3283064365386963e-10;
     f_t = (float)(P.act_lo[0] + P.act_span[0] * u0);
     al = (float)(P.act_lo[1] + P.act_span[1] * u1);
+}
+// Philox words the step needs up front: the policy's (when the policy is drawn in-kernel) and/or
+// the first noise call of the RK45 integrator.  Returns whether d0 holds DYN block 0 call 0.
+template <bool RK45, int NZ>
+__device__ __forceinline__ void step_prologue(const KParams& P, const Rng& R, bool random_policy, uint32_t (&d0)[4],
+                                              float& af, float& aa) {
+    constexpr bool NEED0 = RK45 && NZ != kNoNoise;
+    d0[0] = d0[1] = d0[2] = d0[3] = 0u;
+    if (NEED0 || random_policy) philox_call(R, policy_c0(RK45), d0);
+    if (random_policy) action_from_words(P, d0, af, aa);
 }
 
 __device__ __forceinline__ void pack_obs(double x, double y, double gx, double gy, double d2, float (&obs)[5]) {
@@ -654,12 +688,13 @@ __device__ __forceinline__ void pack_obs(double x, double y, double gx, double g
 // MR_Env.step for one env (MR_env.py:70-98)
 template <bool RK45, int NZ, bool MIS>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
-                                         EnvRegs& e, float act_f, float act_a, StepOut& o, int& fail) {
+                                         EnvRegs& e, float act_f, float act_a, const uint32_t* d0, StepOut& o,
+                                         int& fail) {
     e.counter += 1;  // :80
     const RhsCtx<MIS> C = make_ctx<MIS>(P, (double)act_f, (double)act_a);
     double spx = 0.0, spy = 0.0;
     if constexpr (RK45) {
-        rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail);                  // MR_simulator.py:42-45
+        rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, d0);              // MR_simulator.py:42-45
         rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy);  // :46-50
     } else {
         fixed_integrate<NZ, MIS>(P, C, R, e.x, e.y, spx, spy);

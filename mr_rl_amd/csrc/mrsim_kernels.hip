@@ -55,15 +55,15 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
         EnvRegs e;
         load_env(st.pos, st.aux, st.ep_ret, i, P, e);
         const Rng R = make_rng(P, i);
-        float af, aa;
+        float af = 0.f, aa = 0.f;
+        uint32_t d0[4];
         if (io.actions != nullptr) {
             const float2 a = reinterpret_cast<const float2*>(io.actions)[i];
             af = a.x; aa = a.y;
-        } else {
-            random_action(P, R, af, aa);
         }
+        step_prologue<RK45, NZ>(P, R, io.actions == nullptr, d0, af, aa);
         int fail = 0;
-        env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, af, aa, o, fail);
+        env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, af, aa, d0, o, fail);
         store_env(st.pos, st.aux, st.ep_ret, i, P, e);
         io.rew[i] = o.rew;
         io.done[i] = o.done;
@@ -152,7 +152,9 @@ __global__ __launch_bounds__(kBlock) void mr_policy_kernel(const KParams P, floa
     if (i >= P.n) return;
     const Rng R = make_rng(P, i);
     float f_t, al;
-    random_action(P, R, f_t, al);
+    uint32_t w[4];
+    philox_call(R, P.integrator == MRSIM_INT_RK45 ? policy_c0(true) : policy_c0(false), w);
+    action_from_words(P, w, f_t, al);
     reinterpret_cast<float2*>(actions)[i] = make_float2(f_t, al);
 }
 
@@ -183,9 +185,9 @@ __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, con
     int fail = 0;
     for (int t = 0; t < ra.T; ++t) {
         const Rng R = make_rng(P, i, (unsigned long long)t);
-        float af, aa;
+        float af = 0.f, aa = 0.f;
+        uint32_t d0[4];
         if (ra.actions == nullptr) {
-            random_action(P, R, af, aa);
         } else if (ra.shared_actions) {
             const float2 a = reinterpret_cast<const float2*>(ra.actions)[t];
             af = a.x; aa = a.y;
@@ -193,8 +195,9 @@ __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, con
             const float2 a = reinterpret_cast<const float2*>(ra.actions)[(long long)t * P.n + i];
             af = a.x; aa = a.y;
         }
+        step_prologue<RK45, NZ>(P, R, ra.actions == nullptr, d0, af, aa);
         StepOut o;
-        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, af, aa, o, fail);
+        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, af, aa, d0, o, fail);
         quantise_env(P, e);
         const long long ti = (long long)t * P.n + i;
         if (ra.traj_xy != nullptr) {

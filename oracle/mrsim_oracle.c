@@ -420,10 +420,15 @@ void orc_sample_init(const OrcParams* p, uint64_t seed, uint32_t env_id, uint64_
     xy[1] = (double)(float)(p->init_low[1] + (p->init_high[1] - p->init_low[1]) * u[1]);
 }
 
-void orc_random_action(uint64_t seed, uint32_t env_id, uint64_t step_idx, const double lo[2], const double hi[2],
-                       float act[2]) {
+/* Exploration policy (build extension).  With the RK45 integrator the two uniform words are words 0,1
+ * of DYN block 0 call 0 -- the words whose normals would feed stage K1 of the first rk_step attempt,
+ * which never reaches a result (B[1] = E[1] = 0) -- so the fused GPU kernels need one Philox call
+ * less per step.  Fixed-step modes consume those words for noise and give the policy its own call. */
+void orc_random_action(int integrator, uint64_t seed, uint32_t env_id, uint64_t step_idx, const double lo[2],
+                       const double hi[2], float act[2]) {
     double u[2];
-    orc_uniform2(seed, env_id, step_idx, C0(STREAM_POLICY, 0, 0), u);
+    orc_uniform2(seed, env_id, step_idx,
+                 integrator == ORC_INT_RK45 ? C0(STREAM_DYN, 0, 0) : C0(STREAM_POLICY, 0, 0), u);
     act[0] = (float)(lo[0] + (hi[0] - lo[0]) * u[0]);
     act[1] = (float)(lo[1] + (hi[1] - lo[1]) * u[1]);
 }
@@ -503,11 +508,11 @@ int orc_vec_step(const OrcParams* p, int64_t n, uint32_t env_id0, OrcEnv* envs, 
     return bad ? -1 : 0;
 }
 
-int orc_vec_random_policy(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, const double lo[2],
-                          const double hi[2], float* actions, int threads) {
+int orc_vec_random_policy(int integrator, int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx,
+                          const double lo[2], const double hi[2], float* actions, int threads) {
     (void)threads;
 #pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
     for (int64_t i = 0; i < n; ++i)
-        orc_random_action(seed, env_id0 + (uint32_t)i, step_idx, lo, hi, actions + 2 * i);
+        orc_random_action(integrator, seed, env_id0 + (uint32_t)i, step_idx, lo, hi, actions + 2 * i);
     return 0;
 }

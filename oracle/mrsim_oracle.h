@@ -109,7 +109,7 @@ double orc_calculate_reward(const OrcParams* p, const double obs[5], int32_t cou
 int  orc_end(const OrcParams* p, const double obs[5], int32_t counter);
 void orc_goal_at(const OrcParams* p, const float* goal_table, uint32_t env_id, int32_t counter, double goal[2]);
 void orc_sample_init(const OrcParams* p, uint64_t seed, uint32_t env_id, uint64_t step_idx, double xy[2]);
-void orc_random_action(uint64_t seed, uint32_t env_id, uint64_t step_idx, const double lo[2],
+void orc_random_action(int integrator, uint64_t seed, uint32_t env_id, uint64_t step_idx, const double lo[2],
                        const double hi[2], float act[2]);
 
 /* Batched drivers over n envs (global ids env_id0..env_id0+n-1); PHILOX noise or none.
@@ -121,7 +121,7 @@ int orc_vec_step(const OrcParams* p, int64_t n, uint32_t env_id0, OrcEnv* envs, 
                  const float* actions /* [n][2] */, uint64_t seed, uint64_t step_idx,
                  double* obs /* [n][5] */, double* rew, uint8_t* done,
                  double* final_obs /* [n][5] or NULL */, double* final_ret, int32_t* final_len, int threads);
-int orc_vec_random_policy(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx,
+int orc_vec_random_policy(int integrator, int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx,
                           const double lo[2], const double hi[2], float* actions, int threads);
 int orc_num_threads(void);
 int orc_sizeof_env(void);

@@ -95,8 +95,8 @@ def lib():
                                    C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_vec_step.restype = C.c_int
-        L.orc_vec_random_policy.argtypes = [C.c_int64, C.c_uint32, C.c_uint64, C.c_uint64, dp, dp, C.c_void_p,
-                                            C.c_int]
+        L.orc_vec_random_policy.argtypes = [C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_uint64, dp, dp,
+                                            C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -221,5 +221,6 @@ class VecOracle:
     def random_policy(self, step_idx, lo, hi):
         a = np.zeros((self.n, 2), dtype=np.float32)
         lo_ = (C.c_double * 2)(*lo); hi_ = (C.c_double * 2)(*hi)
-        lib().orc_vec_random_policy(self.n, self.env_id0, self.seed, step_idx, lo_, hi_, _ptr(a), self.threads)
+        lib().orc_vec_random_policy(self.p.integrator, self.n, self.env_id0, self.seed, step_idx, lo_, hi_, _ptr(a),
+                                    self.threads)
         return a
