@@ -38,12 +38,13 @@ struct KParams {
     double min_dist2;  // min_dist2goal^2
     double obs_lo[4], obs_hi[4];
     double dmin2, dmax2;  // obs_low[4]^2 (0 if <= 0), obs_high[4]^2
+    double sym_bound;     // valid when sym_bounds: obs_lo[j] == -sym_bound, obs_hi[j] == sym_bound for j < 4
     double init_lo[2], init_span[2];
     double act_lo[2], act_span[2];
     double h1_thresh;  // 0.01 / dt^5 : select_initial_step's h1 >= dt  <=>  max(d1,d2) <= h1_thresh
     float h1_thresh2_f, dt2_f;
     int32_t substeps, reward_mode, max_timesteps, auto_reset, goal_K, goal_T;
-    int32_t integrator, pad;
+    int32_t integrator, sym_bounds;
     uint32_t seed_lo, seed_hi, step_lo, step_hi;
     uint32_t env_id0, pad2;
     long long n;
@@ -106,7 +107,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 __device__ __forceinline__ void philox_call(const Rng& R, uint32_t c0, uint32_t (&o)[4]) {
-    philox4x32_10(c0, R.step_lo, R.step_hi, R.env, R.k0, R.k1, o);
+    // The key is laundered through an empty asm so that the 20 round keys (k + r*W) are re-derived by
+    // two s_add per round at every call.  Otherwise they are hoisted out of the rollout's time loop as
+    // loop invariants, overflow the SGPR file and come back through v_readlane on the hot path.
+    uint32_t k0 = R.k0, k1 = R.k1;
+    asm volatile("" : "+s"(k0), "+s"(k1));
+    philox4x32_10(c0, R.step_lo, R.step_hi, R.env, k0, k1, o);
 }
 
 // ln(u), u in [2^-33, 1]; Cephes logf polynomial, explicit fma => bit-identical to the oracle.
@@ -367,7 +373,7 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
         const float TH2 = P.h1_thresh2_f;
         const bool fast = (D0 > 1e-9f) && (D1 > 1e-9f) && (D0 >= 1.05f * P.dt2_f * D1) && (D1 <= 1.9f * TH2) &&
                           (DD <= 1.9f * TH2 * P.dt2_f) && (DD * D1 <= 1.9e-4f * TH2 * D0);
-        if (fast) { h_abs = P.dt; return; }
+        if (__builtin_expect(fast, 1)) { h_abs = P.dt; return; }
     }
     // exact path: select_initial_step(fun, t0, y0, t_bound, inf, f0, +1, order=4, rtol, atol)
     const double d0 = rms2(x / sc0, y / sc1);
@@ -481,7 +487,7 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
     const double q = __builtin_fma(ex * ex, s11, (ey * ey) * s00);
     const double lim = 2.0 * s00 * s11;
     bool accepted;
-    if (last && q < 0.98 * lim) {
+    if (__builtin_expect(last && q < 0.98 * lim, 1)) {
         accepted = true;
     } else {
         const double error_norm = rms2(ex / sc0, ey / sc1);
@@ -496,7 +502,7 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
             accepted = false;
         }
     }
-    if (!accepted && S.attempt >= (uint32_t)kMaxAttempts) {
+    if (__builtin_expect(!accepted && S.attempt >= (uint32_t)kMaxAttempts, 0)) {
         // The reference would fail with TOO_SMALL_STEP / spin on NaN input: flag it and finish.
         fail |= 1;
         accepted = true;
@@ -519,7 +525,7 @@ __device__ __forceinline__ void rk45_integrate(const KParams& P, const RhsCtx<MI
     // first attempt peeled: its RNG counters are wave-uniform (attempt = 0), and in the common
     // regime (|y| >~ 1) it is the only one
     rk45_attempt<NZ, MIS, true>(P, C, R, S, x, y, f0x, f0y, fail, d0);
-    while (S.tau < P.dt) {
+    while (__builtin_expect(S.tau < P.dt, 0)) {
         rk45_attempt<NZ, MIS, false>(P, C, R, S, x, y, f0x, f0y, fail, nullptr);
         if (S.attempt >= (uint32_t)kMaxAttempts) { fail |= 1; break; }
     }
@@ -705,9 +711,17 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     const double dx = gx - e.x, dy = gy - e.y;
     const double d2 = __builtin_fma(dx, dx, dy * dy);
     // end (:136-152); Box.contains as a numeric bounds test; distances compared squared
-    const bool inb = (e.x >= P.obs_lo[0]) && (e.x <= P.obs_hi[0]) && (e.y >= P.obs_lo[1]) && (e.y <= P.obs_hi[1]) &&
-                     (gx >= P.obs_lo[2]) && (gx <= P.obs_hi[2]) && (gy >= P.obs_lo[3]) && (gy <= P.obs_hi[3]) &&
-                     (d2 <= P.dmax2) && (d2 >= P.dmin2);
+    bool inb;
+    if (__builtin_expect(P.sym_bounds != 0, 1)) {
+        // the reference's Box is symmetric and equal in x, y, goal_x, goal_y (+-5000): one bound, two
+        // SGPRs instead of sixteen (the per-component form below spills scalar registers in the loop)
+        inb = (fmax(__builtin_fabs(e.x), __builtin_fabs(e.y)) <= P.sym_bound) &&
+              (fmax(__builtin_fabs(gx), __builtin_fabs(gy)) <= P.sym_bound);
+    } else {
+        inb = (e.x >= P.obs_lo[0]) && (e.x <= P.obs_hi[0]) && (e.y >= P.obs_lo[1]) && (e.y <= P.obs_hi[1]) &&
+              (gx >= P.obs_lo[2]) && (gx <= P.obs_hi[2]) && (gy >= P.obs_lo[3]) && (gy <= P.obs_hi[3]);
+    }
+    inb = inb && (d2 <= P.dmax2) && (d2 >= P.dmin2);
     const bool timeout = e.counter > P.max_timesteps;
     const bool reached = d2 < P.min_dist2;
     const bool done = (!inb) || timeout || reached;
@@ -719,7 +733,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     o.done = done ? 1 : 0;
     o.spx = (float)spx; o.spy = (float)spy;
     o.has_final = false;
-    if (done && P.auto_reset) {
+    if (__builtin_expect(done && P.auto_reset, 0)) {
         // extension: same-step auto-reset; terminal values go to the final_* outputs
         o.has_final = true;
 #pragma unroll

@@ -261,6 +261,10 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
     for (int j = 0; j < 4; ++j) { K.obs_lo[j] = p->obs_low[j]; K.obs_hi[j] = p->obs_high[j]; }
     K.dmax2 = p->obs_high[4] * p->obs_high[4];
     K.dmin2 = p->obs_low[4] > 0.0 ? p->obs_low[4] * p->obs_low[4] : 0.0;
+    K.sym_bound = p->obs_high[0];
+    K.sym_bounds = 1;
+    for (int j = 0; j < 4; ++j)
+        if (!(p->obs_high[j] == K.sym_bound && p->obs_low[j] == -K.sym_bound)) K.sym_bounds = 0;
     for (int j = 0; j < 2; ++j) {
         K.init_lo[j] = p->init_low[j]; K.init_span[j] = p->init_high[j] - p->init_low[j];
         K.act_lo[j] = p->act_low[j]; K.act_span[j] = p->act_high[j] - p->act_low[j];
