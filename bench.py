@@ -82,6 +82,27 @@ def cpu_baseline(cfg, seed, target_seconds):
                       f"with OpenMP over {threads} host threads"}
 
 
+def committed_traffic(args, n_local):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes
+    (profiles/rNN/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    same command and corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from
+    inside the timed process, so this is null unless the run matches the profiled configuration."""
+    import glob
+    if not (args.sigma == 1.0 and args.noise_math == "fast" and n_local == 262144 and args.obs_layout == "aos"):
+        return None, None
+    key = "mr_rollout_kernel" if args.mode == "rollout" else "mr_step_kernel"
+    if args.mode == "rollout" and args.rollout_len != 51:
+        return None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            for name, k in json.load(open(f))["kernels"].items():
+                if name.startswith(key):
+                    return int(k["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     args = parse()
     import torch
@@ -200,8 +221,10 @@ def main():
                                                             args.obs_layout)
         avg_ms = sum(ms) / len(ms)
         ach = units * ALGO_BYTES_PER_ENV_STEP / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = committed_traffic(args, n_local)
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kname,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": kname,
                 "avg_kernel_us": round(avg_ms * 1e3, 3), "median_kernel_us": round(ms[len(ms) // 2] * 1e3, 3),
                 "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "env_steps_per_launch": units}
     cpu = None

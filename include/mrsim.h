@@ -142,19 +142,21 @@ int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float
  * one launch, state kept in registers.  actions: [T][n][2] per-env, or [T][2] shared by all envs
  * when shared_actions != 0, or NULL for the in-kernel random policy.  Outputs (each optional):
  * traj_xy [T][n][2] fp32 positions after each step, obs_T [T][n][5] / [T][5][n], rew_T [T][n],
- * done_T [T][n].  Honors auto_reset.  step_idx0 .. step_idx0+T-1 are consumed. */
+ * done_T [T][n], actions_out_T [T][n][2]; final_ret [n] / final_len [n]: return and length of the
+ * latest episode that ended inside the launch (auto_reset).  step_idx0 .. step_idx0+T-1 are consumed. */
 int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
                   int32_t T, const float* actions, int32_t shared_actions, const float* goal_table,
                   float* traj_xy, float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T,
-                  int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream);
+                  float* final_ret, int32_t* final_len, int32_t* status, uint64_t seed,
+                  uint64_t step_idx0, void* stream);
 
 /* mrsim_rollout with HIP events attached to the dispatch: *kernel_ms_host = kernel duration
  * (synchronises the stream; measurement aid for bench.py). */
 int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
                         int32_t T, const float* actions, int32_t shared_actions, const float* goal_table,
                         float* traj_xy, float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T,
-                        int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream,
-                        float* kernel_ms_host);
+                        float* final_ret, int32_t* final_len, int32_t* status, uint64_t seed,
+                        uint64_t step_idx0, void* stream, float* kernel_ms_host);
 
 /* *step_base += delta on `stream` (a one-lane kernel; graph-capturable). */
 int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream);

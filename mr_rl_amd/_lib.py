@@ -77,7 +77,7 @@ def lib():
     L.mrsim_step.argtypes = [PP, i64, u32, PS, PIO, u64, u64, vp]
     L.mrsim_step_timed.argtypes = [PP, i64, u32, PS, PIO, u64, u64, vp, C.POINTER(C.c_float)]
     L.mrsim_random_policy.argtypes = [PP, i64, u32, vp, u64, u64, vp]
-    L.mrsim_rollout.argtypes = [PP, i64, u32, PS, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, u64, u64, vp]
+    L.mrsim_rollout.argtypes = [PP, i64, u32, PS, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u64, vp]
     L.mrsim_rollout_timed.argtypes = L.mrsim_rollout.argtypes + [C.POINTER(C.c_float)]
     L.mrsim_rollout_timed.restype = C.c_int
     L.mrsim_advance_step_base.argtypes = [vp, u64, vp]

@@ -401,7 +401,8 @@ constexpr int kMaxAttempts = 4096;  // every lane leaves the loop: bounded spin
 // weighted noise sums of one rk_step attempt:  nb = sum_{2..5} B_i N_i,  ne = sum_{2..6} E_i N_i,
 // n6 = N_6 (f_new's noise; only matters when another sub-step follows)
 struct AttemptNoise {
-    double nbx, nby, nex, ney, n6x, n6y;
+    double nbx, nby, nex, ney;
+    float z6a, z6x, z6y;  // f_new's normals; only needed when another sub-step follows
 };
 
 template <int NZ, bool MIS, bool FIRST>
@@ -409,7 +410,8 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
                                                       uint32_t attempt, const uint32_t* d0) {
     AttemptNoise A;
     if constexpr (NZ == kNoNoise) {
-        A.nbx = A.nby = A.nex = A.ney = A.n6x = A.n6y = 0.0;
+        A.nbx = A.nby = A.nex = A.ney = 0.0;
+        A.z6a = A.z6x = A.z6y = 0.f;
         return A;
     } else {
         // Draw order inside the block (= the reference's: stages K1..K5, then f_new = K6):
@@ -435,7 +437,7 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         ex = __builtin_fmaf(kE6f, k6[O], ex); ey = __builtin_fmaf(kE6f, k6[O + 1], ey);
         A.nbx = P.sigma * (double)bx; A.nby = P.sigma * (double)by;
         A.nex = P.sigma * (double)ex; A.ney = P.sigma * (double)ey;
-        A.n6x = P.sigma * (double)k6[O]; A.n6y = P.sigma * (double)k6[O + 1];
+        A.z6a = MIS ? k6[0] : 0.f; A.z6x = k6[O]; A.z6y = k6[O + 1];
         if constexpr (MIS) {
             float ba = kB2f * k2[0], ea = kE2f * k2[0];
             ba = __builtin_fmaf(kB3f, k3[0], ba); ea = __builtin_fmaf(kE3f, k3[0], ea);
@@ -444,7 +446,6 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
             ea = __builtin_fmaf(kE6f, k6[0], ea);
             A.nbx = __builtin_fma(C.gx, (double)ba, A.nbx); A.nby = __builtin_fma(C.gy, (double)ba, A.nby);
             A.nex = __builtin_fma(C.gx, (double)ea, A.nex); A.ney = __builtin_fma(C.gy, (double)ea, A.ney);
-            A.n6x = __builtin_fma(C.gx, (double)k6[0], A.n6x); A.n6y = __builtin_fma(C.gy, (double)k6[0], A.n6y);
         }
         return A;
     }
@@ -510,8 +511,11 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
     }
     if (accepted) {
         S.tau = tn; x = xn; y = yn;
-        f0x = C.vx; f0y = C.vy;  // f = f_new
-        if constexpr (NZ != kNoNoise) { f0x += A.n6x; f0y += A.n6y; }
+        if (!last) {  // f = f_new = K[6]; after the last sub-step the constructor replaces f anyway
+            double n6x = 0.0, n6y = 0.0;
+            if constexpr (NZ != kNoNoise) noise_vec<MIS>(P, C, A.z6a, A.z6x, A.z6y, n6x, n6y);
+            f0x = C.vx + n6x; f0y = C.vy + n6y;
+        }
         S.rejected = false;
     }
     return accepted;

@@ -174,6 +174,8 @@ struct RolloutArgs {
     uint8_t* done_T;
     float* actions_out_T;
     int32_t* status;
+    float* final_ret;
+    int32_t* final_len;
 };
 
 template <bool RK45, int NZ, bool MIS>
@@ -216,6 +218,10 @@ __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, con
         if (ra.rew_T != nullptr) ra.rew_T[ti] = o.rew;
         if (ra.done_T != nullptr) ra.done_T[ti] = o.done;
         if (ra.actions_out_T != nullptr) reinterpret_cast<float2*>(ra.actions_out_T)[ti] = make_float2(af, aa);
+        if (o.has_final) {  // return / length of the episode that just ended (latest one wins)
+            if (ra.final_ret != nullptr) ra.final_ret[i] = o.fret;
+            if (ra.final_len != nullptr) ra.final_len[i] = o.flen;
+        }
     }
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
     if (fail && ra.status != nullptr) atomicOr(ra.status, fail);
@@ -462,8 +468,9 @@ int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float
 
 static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
                         const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy,
-                        float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T, int32_t* status,
-                        uint64_t seed, uint64_t step_idx0, void* stream, float* kernel_ms) {
+                        float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T, float* final_ret,
+                        int32_t* final_len, int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream,
+                        float* kernel_ms) {
     KParams K;
     int rc = make_kparams(p, n, env_id0, seed, step_idx0, K);
     if (rc) return rc;
@@ -476,7 +483,7 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     if ((rc = check_device())) return rc;
     const StateArgs S{st->pos, st->aux, st->ep_ret};
     const RolloutArgs ra{T, shared_actions, p->obs_layout, 0, actions, goal_table, traj_xy, obs_T, rew_T, done_T,
-                         actions_out_T, status};
+                         actions_out_T, status, final_ret, final_len};
     LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
     if (kernel_ms != nullptr && (hipEventCreate(&lc.start) != hipSuccess || hipEventCreate(&lc.stop) != hipSuccess))
         return MRSIM_ELAUNCH;
@@ -495,19 +502,20 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
 
 int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
                   const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy, float* obs_T,
-                  float* rew_T, uint8_t* done_T, float* actions_out_T, int32_t* status, uint64_t seed,
-                  uint64_t step_idx0, void* stream) {
+                  float* rew_T, uint8_t* done_T, float* actions_out_T, float* final_ret, int32_t* final_len,
+                  int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream) {
     return rollout_impl(p, n, env_id0, st, T, actions, shared_actions, goal_table, traj_xy, obs_T, rew_T, done_T,
-                        actions_out_T, status, seed, step_idx0, stream, nullptr);
+                        actions_out_T, final_ret, final_len, status, seed, step_idx0, stream, nullptr);
 }
 
 int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
                         const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy,
-                        float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T, int32_t* status,
-                        uint64_t seed, uint64_t step_idx0, void* stream, float* kernel_ms_host) {
+                        float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T, float* final_ret,
+                        int32_t* final_len, int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream,
+                        float* kernel_ms_host) {
     if (kernel_ms_host == nullptr) return MRSIM_EINVAL;
     return rollout_impl(p, n, env_id0, st, T, actions, shared_actions, goal_table, traj_xy, obs_T, rew_T, done_T,
-                        actions_out_T, status, seed, step_idx0, stream, kernel_ms_host);
+                        actions_out_T, final_ret, final_len, status, seed, step_idx0, stream, kernel_ms_host);
 }
 
 int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream) {

@@ -283,7 +283,8 @@ class MRVecEnv:
         out = buf
         args = [C.byref(self._params), n, self.env_id0, C.byref(self._st), int(T), self._p(act_t),
                 int(bool(shared_actions)), self._p(self.goal_table), self._p(traj), self._p(obs_T),
-                self._p(rew_T), self._p(done_T), self._p(acts_T), self._p(self.status),
+                self._p(rew_T), self._p(done_T), self._p(acts_T), self._p(self.final_ret), self._p(self.final_len),
+                self._p(self.status),
                 self.seed_value, self.step_idx, self._stream()]
         if timed:
             ms = C.c_float(0.0)

@@ -1,0 +1,92 @@
+"""CPU, world_size 2 over gloo: the N>1 path -- contiguous shards keyed by GLOBAL env id and the
+all-gather of episode returns (mr_rl_amd/dist.py).  The env compute of each rank is stood in for by
+the oracle here (tests may use it; the product path has no CPU compute)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mr_rl_amd.dist import all_shards, gather_returns, gather_returns_ragged, shard_of
+
+
+def test_shard_of_partitions_exactly():
+    for total, world in [(2097152, 8), (262144, 1), (10, 3), (7, 8), (1000, 6)]:
+        shards = all_shards(total, world)
+        assert shards[0][0] == 0 and sum(n for _, n in shards) == total
+        for (a, n), (b, _) in zip(shards, shards[1:]):
+            assert a + n == b
+        assert max(n for _, n in shards) - min(n for _, n in shards) <= 1
+    assert shard_of(2097152, 3, 8) == (3 * 262144, 262144)
+    with pytest.raises(ValueError):
+        shard_of(10, 4, 4)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        env_id0, n_local = shard_of(total, rank, world)
+        p = O.default_params(sigma=1.0, auto_reset=1)
+        v = O.VecOracle(n_local, p, seed=11, env_id0=env_id0)
+        v.reset(0)
+        lo, hi = [-20.0, -2 * np.pi], [20.0, 2 * np.pi]
+        for t in range(1, 52):  # one full episode: every env times out at step 51
+            v.step(v.random_policy(t, lo, hi), t)
+        local = torch.from_numpy(v.final_ret.astype(np.float32))
+        if total % world == 0:
+            allr = gather_returns(local)
+        else:
+            allr = gather_returns_ragged(local, total)
+        pos = torch.from_numpy(v.envs["y"].copy())
+        q.put((rank, allr.numpy().copy(), env_id0, pos.numpy().copy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [64, 37])
+def test_sharded_run_equals_unsharded_and_gathers_in_global_order(total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # unsharded reference run
+    from oracle import oracle as O
+    p = O.default_params(sigma=1.0, auto_reset=1)
+    v = O.VecOracle(total, p, seed=11)
+    v.reset(0)
+    lo, hi = [-20.0, -2 * np.pi], [20.0, 2 * np.pi]
+    for t in range(1, 52):
+        v.step(v.random_policy(t, lo, hi), t)
+    for rank, allr, env_id0, pos in got:
+        np.testing.assert_array_equal(allr, v.final_ret.astype(np.float32))      # same on every rank, global order
+        np.testing.assert_array_equal(pos, v.envs["y"][env_id0:env_id0 + len(pos)])  # bit-identical trajectories
+    assert np.all(v.final_ret == 510.0)
+
+
+def test_gather_returns_single_process_is_identity():
+    x = torch.arange(5, dtype=torch.float32)
+    assert gather_returns(x) is x
+    out = torch.zeros(5)
+    assert torch.equal(gather_returns(x, out=out), x)

@@ -304,6 +304,10 @@ def test_rollout_equals_steps():
     np.testing.assert_array_equal(e1.pos.cpu().numpy().view(np.uint64), e2.pos.cpu().numpy().view(np.uint64))
     np.testing.assert_array_equal(e1.aux.cpu().numpy().view(np.uint32), e2.aux.cpu().numpy().view(np.uint32))
     np.testing.assert_array_equal(e1.ep_ret.cpu().numpy(), e2.ep_ret.cpu().numpy())
+    # the episode that ended inside the launch (step 51): return 510, length 51, same as the step path
+    np.testing.assert_array_equal(e1.final_ret.cpu().numpy(), e2.final_ret.cpu().numpy())
+    np.testing.assert_array_equal(e1.final_len.cpu().numpy(), e2.final_len.cpu().numpy())
+    assert (e1.final_len == 51).all() and (e1.final_ret == 510).all()
 
 
 def test_sharding_invariance():
