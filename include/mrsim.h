@@ -138,25 +138,35 @@ int mrsim_step_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
 int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float* actions,
                         uint64_t seed, uint64_t step_idx, void* stream);
 
-/* Fused open-loop rollout, the batched utils.run_sim (utils.py:43-61): T steps of all n envs in
- * one launch, state kept in registers.  actions: [T][n][2] per-env, or [T][2] shared by all envs
- * when shared_actions != 0, or NULL for the in-kernel random policy.  Outputs (each optional):
- * traj_xy [T][n][2] fp32 positions after each step, obs_T [T][n][5] / [T][5][n], rew_T [T][n],
- * done_T [T][n], actions_out_T [T][n][2]; final_ret [n] / final_len [n]: return and length of the
- * latest episode that ended inside the launch (auto_reset).  step_idx0 .. step_idx0+T-1 are consumed. */
+/* Inputs / outputs of a fused rollout.  Optional pointers may be NULL. */
+typedef struct MrsimRolloutIO {
+    int32_t T;               /* steps in this launch; step_idx0 .. step_idx0+T-1 are consumed          */
+    int32_t shared_actions;  /* non-zero: actions is [T][2], one table for all envs (utils.run_sim)    */
+    const float* actions;    /* [T][n][2] per-env, [T][2] shared, or NULL = in-kernel random policy    */
+    const float* goal_table; /* optional [K][T'][2]                                                    */
+    double* traj_xy;         /* optional [T][n][2] fp64: position after each step, before any auto-    */
+                             /*   reset == what utils.run_sim records from env.last_pos (utils.py:53)  */
+    float* state_prime_T;    /* optional [T][n][2]: env.state_prime after each step (utils.py:54)      */
+    float* obs_T;            /* optional [T][n][5] or [T][5][n] (params.obs_layout)                    */
+    float* rew_T;            /* optional [T][n]                                                        */
+    uint8_t* done_T;         /* optional [T][n]                                                        */
+    float* actions_out_T;    /* optional [T][n][2]: the actions applied                                */
+    float* final_ret;        /* optional [n]: return of the latest episode that ended in the launch    */
+    int32_t* final_len;      /* optional [n]: its length                                               */
+    int32_t* status;         /* optional [1], as MrsimStepIO.status                                    */
+} MrsimRolloutIO;
+
+/* Fused open-loop rollout, the batched utils.run_sim (utils.py:43-61) and the DDPG rollout workload:
+ * T steps of all n envs in one launch, env state kept in registers, every requested per-step output
+ * written to [T][n][...] buffers.  Honors auto_reset.  Bit-identical to T calls of mrsim_step. */
 int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
-                  int32_t T, const float* actions, int32_t shared_actions, const float* goal_table,
-                  float* traj_xy, float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T,
-                  float* final_ret, int32_t* final_len, int32_t* status, uint64_t seed,
-                  uint64_t step_idx0, void* stream);
+                  const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream);
 
 /* mrsim_rollout with HIP events attached to the dispatch: *kernel_ms_host = kernel duration
  * (synchronises the stream; measurement aid for bench.py). */
 int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
-                        int32_t T, const float* actions, int32_t shared_actions, const float* goal_table,
-                        float* traj_xy, float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T,
-                        float* final_ret, int32_t* final_len, int32_t* status, uint64_t seed,
-                        uint64_t step_idx0, void* stream, float* kernel_ms_host);
+                        const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream,
+                        float* kernel_ms_host);
 
 /* *step_base += delta on `stream` (a one-lane kernel; graph-capturable). */
 int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream);

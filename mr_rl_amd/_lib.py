@@ -48,6 +48,15 @@ class MrsimStepIO(C.Structure):
     ]
 
 
+class MrsimRolloutIO(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("shared_actions", C.c_int32), ("actions", C.c_void_p), ("goal_table", C.c_void_p),
+        ("traj_xy", C.c_void_p), ("state_prime_T", C.c_void_p), ("obs_T", C.c_void_p), ("rew_T", C.c_void_p),
+        ("done_T", C.c_void_p), ("actions_out_T", C.c_void_p), ("final_ret", C.c_void_p),
+        ("final_len", C.c_void_p), ("status", C.c_void_p),
+    ]
+
+
 class MrsimError(RuntimeError):
     def __init__(self, code, what):
         self.code = code
@@ -77,7 +86,7 @@ def lib():
     L.mrsim_step.argtypes = [PP, i64, u32, PS, PIO, u64, u64, vp]
     L.mrsim_step_timed.argtypes = [PP, i64, u32, PS, PIO, u64, u64, vp, C.POINTER(C.c_float)]
     L.mrsim_random_policy.argtypes = [PP, i64, u32, vp, u64, u64, vp]
-    L.mrsim_rollout.argtypes = [PP, i64, u32, PS, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u64, vp]
+    L.mrsim_rollout.argtypes = [PP, i64, u32, PS, C.POINTER(MrsimRolloutIO), u64, u64, vp]
     L.mrsim_rollout_timed.argtypes = L.mrsim_rollout.argtypes + [C.POINTER(C.c_float)]
     L.mrsim_rollout_timed.restype = C.c_int
     L.mrsim_advance_step_base.argtypes = [vp, u64, vp]

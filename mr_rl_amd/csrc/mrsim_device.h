@@ -632,7 +632,9 @@ struct StepOut {
     float obs[5];
     float rew;
     uint8_t done;
-    float spx, spy;
+    float spx, spy;     // Simulator.state_prime = last RHS value evaluated (the reset's, after an auto-reset)
+    float spx0, spy0;   // state_prime of the step itself
+    double px, py;      // position after the step, before any auto-reset (MR_Env.last_pos)
     bool has_final;
     float fobs[5];
     float fret;
@@ -735,7 +737,8 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     pack_obs(e.x, e.y, gx, gy, d2, o.obs);
     o.rew = rew;
     o.done = done ? 1 : 0;
-    o.spx = (float)spx; o.spy = (float)spy;
+    o.spx = o.spx0 = (float)spx; o.spy = o.spy0 = (float)spy;
+    o.px = e.x; o.py = e.y;
     o.has_final = false;
     if (__builtin_expect(done && P.auto_reset, 0)) {
         // extension: same-step auto-reset; terminal values go to the final_* outputs

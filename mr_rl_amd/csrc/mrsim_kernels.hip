@@ -168,14 +168,15 @@ struct RolloutArgs {
     int32_t pad;
     const float* actions;
     const float* goal_table;
-    float* traj_xy;
+    double* traj_xy;
+    float* state_prime_T;
     float* obs_T;
     float* rew_T;
     uint8_t* done_T;
     float* actions_out_T;
-    int32_t* status;
     float* final_ret;
     int32_t* final_len;
+    int32_t* status;
 };
 
 template <bool RK45, int NZ, bool MIS>
@@ -202,12 +203,8 @@ __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, con
         env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, af, aa, d0, o, fail);
         quantise_env(P, e);
         const long long ti = (long long)t * P.n + i;
-        if (ra.traj_xy != nullptr) {
-            // position AFTER the step and BEFORE any auto-reset == what run_sim records (utils.py:53)
-            const float px = o.has_final ? o.fobs[0] : o.obs[0];
-            const float py = o.has_final ? o.fobs[1] : o.obs[1];
-            reinterpret_cast<float2*>(ra.traj_xy)[ti] = make_float2(px, py);
-        }
+        if (ra.traj_xy != nullptr) reinterpret_cast<double2*>(ra.traj_xy)[ti] = make_double2(o.px, o.py);
+        if (ra.state_prime_T != nullptr) reinterpret_cast<float2*>(ra.state_prime_T)[ti] = make_float2(o.spx0, o.spy0);
         if (ra.obs_T != nullptr) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
@@ -466,24 +463,23 @@ int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float
     return launch(lc, mr_policy_kernel, K.n, K, actions);
 }
 
-static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
-                        const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy,
-                        float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T, float* final_ret,
-                        int32_t* final_len, int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream,
-                        float* kernel_ms) {
+static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
+                        const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream, float* kernel_ms) {
     KParams K;
     int rc = make_kparams(p, n, env_id0, seed, step_idx0, K);
     if (rc) return rc;
     if ((rc = check_state(st))) return rc;
-    if (T < 0) return MRSIM_EINVAL;
-    if (T == 0) return MRSIM_OK;
-    if ((actions && !aligned16(actions)) || (traj_xy && !aligned16(traj_xy)) || (actions_out_T && !aligned16(actions_out_T)))
+    if (io == nullptr || io->T < 0) return MRSIM_EINVAL;
+    if (io->T == 0) return MRSIM_OK;
+    if ((io->actions && !aligned16(io->actions)) || (io->traj_xy && !aligned16(io->traj_xy)) ||
+        (io->actions_out_T && !aligned16(io->actions_out_T)) || (io->state_prime_T && !aligned16(io->state_prime_T)))
         return MRSIM_EALIGN;
-    if (goal_table != nullptr && (p->goal_K < 1 || p->goal_T < 1)) return MRSIM_EINVAL;
+    if (io->goal_table != nullptr && (p->goal_K < 1 || p->goal_T < 1)) return MRSIM_EINVAL;
     if ((rc = check_device())) return rc;
     const StateArgs S{st->pos, st->aux, st->ep_ret};
-    const RolloutArgs ra{T, shared_actions, p->obs_layout, 0, actions, goal_table, traj_xy, obs_T, rew_T, done_T,
-                         actions_out_T, status, final_ret, final_len};
+    const RolloutArgs ra{io->T, io->shared_actions, p->obs_layout, 0, io->actions, io->goal_table, io->traj_xy,
+                         io->state_prime_T, io->obs_T, io->rew_T, io->done_T, io->actions_out_T, io->final_ret,
+                         io->final_len, io->status};
     LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
     if (kernel_ms != nullptr && (hipEventCreate(&lc.start) != hipSuccess || hipEventCreate(&lc.stop) != hipSuccess))
         return MRSIM_ELAUNCH;
@@ -500,22 +496,16 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     return rc;
 }
 
-int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
-                  const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy, float* obs_T,
-                  float* rew_T, uint8_t* done_T, float* actions_out_T, float* final_ret, int32_t* final_len,
-                  int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream) {
-    return rollout_impl(p, n, env_id0, st, T, actions, shared_actions, goal_table, traj_xy, obs_T, rew_T, done_T,
-                        actions_out_T, final_ret, final_len, status, seed, step_idx0, stream, nullptr);
+int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, const MrsimRolloutIO* io,
+                  uint64_t seed, uint64_t step_idx0, void* stream) {
+    return rollout_impl(p, n, env_id0, st, io, seed, step_idx0, stream, nullptr);
 }
 
-int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, int32_t T,
-                        const float* actions, int32_t shared_actions, const float* goal_table, float* traj_xy,
-                        float* obs_T, float* rew_T, uint8_t* done_T, float* actions_out_T, float* final_ret,
-                        int32_t* final_len, int32_t* status, uint64_t seed, uint64_t step_idx0, void* stream,
+int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
+                        const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream,
                         float* kernel_ms_host) {
     if (kernel_ms_host == nullptr) return MRSIM_EINVAL;
-    return rollout_impl(p, n, env_id0, st, T, actions, shared_actions, goal_table, traj_xy, obs_T, rew_T, done_T,
-                        actions_out_T, final_ret, final_len, status, seed, step_idx0, stream, kernel_ms_host);
+    return rollout_impl(p, n, env_id0, st, io, seed, step_idx0, stream, kernel_ms_host);
 }
 
 int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream) {

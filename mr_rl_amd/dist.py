@@ -39,6 +39,12 @@ def gather_returns(local_returns, out=None, group=None):
     world = dist.get_world_size(group)
     if out is None:
         out = torch.empty(world * local_returns.numel(), dtype=local_returns.dtype, device=local_returns.device)
+    if dist.get_backend(group) == "gloo" and local_returns.is_cuda:
+        # rehearsal path only (gloo has no device all_gather_into_tensor): stage through the host
+        tmp = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(tmp, local_returns.cpu().contiguous(), group=group)
+        out.copy_(tmp)
+        return out
     dist.all_gather_into_tensor(out, local_returns.contiguous(), group=group)
     return out
 

@@ -256,54 +256,58 @@ class MRVecEnv:
         return out
 
     def rollout(self, T, actions=None, shared_actions=False, want=("traj",), out=None, timed=False):
-        """T fused steps in one launch (batched utils.run_sim).  actions: [T,N,2], or [T,2] with
-        shared_actions=True, or None for the on-device random policy.  Returns a dict of [T,...] tensors."""
+        """T fused steps in one launch (batched utils.run_sim / DDPG rollout).  actions: [T,N,2], or [T,2]
+        with shared_actions=True, or None for the on-device random policy.  want: any of "traj" (fp64
+        positions [T,N,2]), "state_prime", "obs", "rew", "done", "actions".  `out` lets a caller reuse the
+        [T,...] buffers of a previous call (the returned dict).  Returns a dict of [T,...] tensors."""
         torch = _torch()
         n, dev = self.num_envs, self.device
         act_t = None
         if actions is not None:
             act_t = torch.as_tensor(actions, dtype=torch.float32, device=dev).contiguous()
             assert act_t.shape == ((T, 2) if shared_actions else (T, n, 2))
-        # `out` lets a caller reuse preallocated [T,...] buffers (keys "_traj", "_obs", "_rew", "_done", "_actions")
         buf = out if out is not None else {}
 
         def get(key, shape, dtype):
-            if key[1:] not in want:
+            if key not in want:
                 return None
-            t = buf.get(key)
-            if t is None:
-                t = buf[key] = torch.empty(shape, dtype=dtype, device=dev)
+            t = buf.get("_" + key)
+            if t is None or tuple(t.shape) != tuple(shape):
+                t = buf["_" + key] = torch.empty(shape, dtype=dtype, device=dev)
             return t
 
-        traj = get("_traj", (T, n, 2), torch.float32)
-        obs_T = get("_obs", (T, 5, n) if self._soa else (T, n, 5), torch.float32)
-        rew_T = get("_rew", (T, n), torch.float32)
-        done_T = get("_done", (T, n), torch.uint8)
-        acts_T = get("_actions", (T, n, 2), torch.float32)
-        out = buf
-        args = [C.byref(self._params), n, self.env_id0, C.byref(self._st), int(T), self._p(act_t),
-                int(bool(shared_actions)), self._p(self.goal_table), self._p(traj), self._p(obs_T),
-                self._p(rew_T), self._p(done_T), self._p(acts_T), self._p(self.final_ret), self._p(self.final_len),
-                self._p(self.status),
-                self.seed_value, self.step_idx, self._stream()]
+        traj = get("traj", (T, n, 2), torch.float64)
+        sp_T = get("state_prime", (T, n, 2), torch.float32)
+        obs_T = get("obs", (T, 5, n) if self._soa else (T, n, 5), torch.float32)
+        rew_T = get("rew", (T, n), torch.float32)
+        done_T = get("done", (T, n), torch.uint8)
+        acts_T = get("actions", (T, n, 2), torch.float32)
+        P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        io = _lib.MrsimRolloutIO(int(T), int(bool(shared_actions)), P(act_t), P(self.goal_table), P(traj), P(sp_T),
+                                 P(obs_T), P(rew_T), P(done_T), P(acts_T), P(self.final_ret), P(self.final_len),
+                                 P(self.status))
+        args = [C.byref(self._params), n, self.env_id0, C.byref(self._st), C.byref(io), self.seed_value,
+                self.step_idx, self._stream()]
         if timed:
             ms = C.c_float(0.0)
             _lib.check(self._L.mrsim_rollout_timed(*args, C.byref(ms)), "mrsim_rollout_timed")
-            out["kernel_ms"] = ms.value
+            buf["kernel_ms"] = ms.value
         else:
             _lib.check(self._L.mrsim_rollout(*args), "mrsim_rollout")
         self.step_idx += int(T)
         if traj is not None:
-            out["traj"] = traj
+            buf["traj"] = traj
+        if sp_T is not None:
+            buf["state_prime"] = sp_T
         if obs_T is not None:
-            out["obs"] = obs_T.transpose(1, 2) if self._soa else obs_T
+            buf["obs"] = obs_T.transpose(1, 2) if self._soa else obs_T
         if rew_T is not None:
-            out["rew"] = rew_T
+            buf["rew"] = rew_T
         if done_T is not None:
-            out["done"] = done_T.view(torch.bool)
+            buf["done"] = done_T.view(torch.bool)
         if acts_T is not None:
-            out["actions"] = acts_T
-        return out
+            buf["actions"] = acts_T
+        return buf
 
     def capture_steps(self, G, policy="kernel"):
         """Capture G env steps into one hipGraph (torch.cuda.CUDAGraph is only the capture plumbing).

@@ -87,6 +87,12 @@ def actions_random(T, rng, idle_frac=0.1, wide=False):
 # --------------------------------------------------------------------------
 # drive the reference Simulator
 # --------------------------------------------------------------------------
+def f32(actions):
+    """The C ABI takes float32 actions, so every action table is rounded to float32 BEFORE it is fed to
+    the reference: reference, oracle and kernel then see bit-identical inputs."""
+    return np.asarray(actions, dtype=np.float64).astype(np.float32).astype(np.float64)
+
+
 def run_simulator(actions, init, a0, noise_var, mismatched, mismatch_at_reset=False):
     """MR_env.reset order (MR_env.py:179-183): noise_var, a0, reset_start_pos, then is_mismatched."""
     s = MR_simulator.Simulator()
@@ -116,6 +122,7 @@ def gen_sim():
     cases = {}
 
     def add(name, actions, init, a0, mismatched=False, mismatch_at_reset=False):
+        actions = f32(actions)
         r = run_simulator(actions, init, a0, 0.0, mismatched, mismatch_at_reset)
         cases[name] = dict(actions=actions, init=np.asarray(init, float), a0=a0,
                            mismatched=int(mismatched), mismatch_at_reset=int(mismatch_at_reset), **r)
@@ -173,6 +180,7 @@ def gen_noise():
         ("n_mis_origin_s1", actions_ramp()[:300], [0.0, 0.0], 1.5, 1.0, True),
     ]
     for i, (name, actions, init, a0, sigma, mis) in enumerate(specs):
+        actions = f32(actions)
         np.random.seed(1000 + i)
         with _Tape() as tape:
             r = run_simulator(actions, init, a0, sigma, mis)
@@ -232,6 +240,7 @@ def gen_env():
     flat = {}
 
     def episode(name, init, actions, a0=1.0, noise_var=0.0, mismatched=False, stop_on_done=False):
+        actions = f32(actions)
         env = MR_env.MR_Env()
         with contextlib.redirect_stdout(io.StringIO()):  # reset() prints (MR_env.py:175-176)
             obs0 = env.reset(init=np.asarray(init, dtype=np.float64), noise_var=noise_var, a0=a0,
@@ -272,7 +281,7 @@ def gen_env():
         ("g7_runsim_ramp", actions_ramp()[:300], [0.0, 0.0], 1.5, False),
         ("g7_runsim_mis", actions_figure8()[:300], [0.0, 0.0], 1.0, True),
     ]:
-        a3 = np.zeros((len(actions), 3)); a3[:, :2] = actions; a3[:, 2] = np.arange(len(actions)) * 0.030
+        a3 = np.zeros((len(actions), 3)); a3[:, :2] = f32(actions); a3[:, 2] = np.arange(len(actions)) * 0.030
         with contextlib.redirect_stdout(io.StringIO()):
             X, Y, alpha, time, freq = utils.run_sim(a3, init_pos=np.asarray(init, float), noise_var=0.0,
                                                     a0=a0, is_mismatched=mis)
