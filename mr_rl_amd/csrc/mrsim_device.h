@@ -44,12 +44,29 @@ struct KParams {
     double h1_thresh;  // 0.01 / dt^5 : select_initial_step's h1 >= dt  <=>  max(d1,d2) <= h1_thresh
     float h1_thresh2_f, dt2_f;
     int32_t substeps, reward_mode, max_timesteps, auto_reset, goal_K, goal_T;
-    int32_t integrator, sym_bounds;
+    int32_t integrator;
+    uint32_t flags;  // kF* bits: every wave-uniform yes/no of the launch in ONE scalar register
     uint32_t seed_lo, seed_hi, step_lo, step_hi;
     uint32_t env_id0, pad2;
     long long n;
     const unsigned long long* step_base;  // optional device word added to (step_hi:step_lo)
 };
+
+// Wave-uniform launch conditions.  Testing a bit of one SGPR at the point of use (s_bitcmp + branch) costs
+// nothing; letting the compiler hoist a dozen `ptr != nullptr` / `mode == x` comparisons out of the time
+// loop makes it keep each one as a 64-bit lane mask, which overflows the SGPR file and comes back through
+// v_readlane on the hot path.  live_flags() launders the word so the tests stay where they are written.
+enum : uint32_t {
+    kFAutoReset = 1u << 0, kFRewardGoal = 1u << 1, kFSymBounds = 1u << 2, kFGoalTable = 1u << 3,
+    kFStepBase = 1u << 4, kFActions = 1u << 5, kFSharedActions = 1u << 6, kFObsAos = 1u << 7,
+    kFOutTraj = 1u << 8, kFOutStatePrime = 1u << 9, kFOutObs = 1u << 10, kFOutRew = 1u << 11,
+    kFOutDone = 1u << 12, kFOutActions = 1u << 13, kFOutFinalRet = 1u << 14, kFOutFinalLen = 1u << 15,
+    kFOutFinalObs = 1u << 16, kFOutStatus = 1u << 17, kFRk4 = 1u << 18,
+};
+__device__ __forceinline__ uint32_t live_flags(uint32_t f) {
+    asm volatile("" : "+s"(f));
+    return f;
+}
 
 // ---------------------------------------------------------------------------
 // RNG: Philox4x32-10, counter = {c0, step lo, step hi, global env id}, key = seed
@@ -67,7 +84,7 @@ struct Rng {
 // effective 64-bit step index of this launch (+ t for the fused rollout)
 __device__ __forceinline__ void step_words(const KParams& P, unsigned long long t, uint32_t& lo, uint32_t& hi) {
     unsigned long long s = (((unsigned long long)P.step_hi << 32) | P.step_lo) + t;
-    if (P.step_base != nullptr) s += *P.step_base;  // uniform scalar load
+    if (P.flags & kFStepBase) s += *P.step_base;  // uniform scalar load
     lo = (uint32_t)s;
     hi = (uint32_t)(s >> 32);
 }
@@ -542,7 +559,7 @@ __device__ __forceinline__ void fixed_integrate(const KParams& P, const RhsCtx<M
                                                 double& y, double& spx, double& spy) {
     const int S = P.substeps > 0 ? P.substeps : 1;
     const double h = P.dt / S;
-    const bool rk4 = (P.integrator == 2);
+    const bool rk4 = (P.flags & kFRk4) != 0;
     spx = C.vx; spy = C.vy;
     for (int s = 0; s < S; ++s) {
         double n1x = 0, n1y = 0, n2x = 0, n2y = 0, n3x = 0, n3y = 0, n4x = 0, n4y = 0;
@@ -618,9 +635,9 @@ __device__ __forceinline__ void store_env(double* __restrict__ pos, float* __res
 }
 
 // goal of (env, episode step): MR_Env.init_goal = (0,0) (MR_env.py:57) or a trajectory table
-__device__ __forceinline__ void goal_at(const KParams& P, const float* __restrict__ goal_table, uint32_t env,
-                                        int32_t counter, double& gx, double& gy) {
-    if (goal_table == nullptr) { gx = 0.0; gy = 0.0; return; }
+__device__ __forceinline__ void goal_at(const KParams& P, uint32_t fl, const float* __restrict__ goal_table,
+                                        uint32_t env, int32_t counter, double& gx, double& gy) {
+    if (!(fl & kFGoalTable)) { gx = 0.0; gy = 0.0; return; }
     const int K = P.goal_K > 0 ? P.goal_K : 1, T = P.goal_T > 0 ? P.goal_T : 1;
     const int k = (K == 1) ? 0 : (int)(env % (uint32_t)K);
     const int r = counter < 0 ? 0 : (counter >= T ? T - 1 : counter);
@@ -694,14 +711,14 @@ __device__ __forceinline__ void step_prologue(const KParams& P, const Rng& R, bo
 __device__ __forceinline__ void pack_obs(double x, double y, double gx, double gy, double d2, float (&obs)[5]) {
     // convert_state (MR_env.py:100-116); dist emitted as the fp32 sqrt of the fp64 squared distance
     obs[0] = (float)x; obs[1] = (float)y; obs[2] = (float)gx; obs[3] = (float)gy;
-    obs[4] = __builtin_sqrtf((float)d2);
+    obs[4] = __builtin_amdgcn_sqrtf((float)d2);  // v_sqrt_f32 (1 ulp); inputs are >= 0 and far from denormal
 }
 
 // MR_Env.step for one env (MR_env.py:70-98)
 template <bool RK45, int NZ, bool MIS>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
-                                         EnvRegs& e, float act_f, float act_a, const uint32_t* d0, StepOut& o,
-                                         int& fail) {
+                                         EnvRegs& e, float act_f, float act_a, const uint32_t* d0, uint32_t fl,
+                                         StepOut& o, int& fail) {
     e.counter += 1;  // :80
     const RhsCtx<MIS> C = make_ctx<MIS>(P, (double)act_f, (double)act_a);
     double spx = 0.0, spy = 0.0;
@@ -713,12 +730,12 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         e.f0x = spx; e.f0y = spy; e.h_abs = P.dt;
     }
     double gx, gy;
-    goal_at(P, goal_table, R.env, e.counter, gx, gy);
+    goal_at(P, fl, goal_table, R.env, e.counter, gx, gy);
     const double dx = gx - e.x, dy = gy - e.y;
     const double d2 = __builtin_fma(dx, dx, dy * dy);
     // end (:136-152); Box.contains as a numeric bounds test; distances compared squared
     bool inb;
-    if (__builtin_expect(P.sym_bounds != 0, 1)) {
+    if (__builtin_expect((fl & kFSymBounds) != 0, 1)) {
         // the reference's Box is symmetric and equal in x, y, goal_x, goal_y (+-5000): one bound, two
         // SGPRs instead of sixteen (the per-component form below spills scalar registers in the loop)
         inb = (fmax(__builtin_fabs(e.x), __builtin_fabs(e.y)) <= P.sym_bound) &&
@@ -732,7 +749,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     const bool reached = d2 < P.min_dist2;
     const bool done = (!inb) || timeout || reached;
     float rew = 10.0f;  // :89
-    if (P.reward_mode == 1) rew = reached ? 100.0f : ((!inb || timeout) ? -100.0f : -0.1f);  // :118-134
+    if (fl & kFRewardGoal) rew = reached ? 100.0f : ((!inb || timeout) ? -100.0f : -0.1f);  // :118-134
     e.ep_ret += rew;
     pack_obs(e.x, e.y, gx, gy, d2, o.obs);
     o.rew = rew;
@@ -740,7 +757,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     o.spx = o.spx0 = (float)spx; o.spy = o.spy0 = (float)spy;
     o.px = e.x; o.py = e.y;
     o.has_final = false;
-    if (__builtin_expect(done && P.auto_reset, 0)) {
+    if (__builtin_expect(done && (fl & kFAutoReset), 0)) {
         // extension: same-step auto-reset; terminal values go to the final_* outputs
         o.has_final = true;
 #pragma unroll
@@ -751,7 +768,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         sample_init(P, R, x0, y0);
         reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry);
         if constexpr (RK45) { o.spx = (float)rx; o.spy = (float)ry; }  // state_prime = last RHS value
-        goal_at(P, goal_table, R.env, 0, gx, gy);
+        goal_at(P, fl, goal_table, R.env, 0, gx, gy);
         const double ex = gx - e.x, ey = gy - e.y;
         pack_obs(e.x, e.y, gx, gy, __builtin_fma(ex, ex, ey * ey), o.obs);
     }

@@ -51,36 +51,37 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
     const long long i = base + threadIdx.x;
     const bool active = i < P.n;
     StepOut o;
+    const uint32_t fl = P.flags;
     if (active) {
         EnvRegs e;
         load_env(st.pos, st.aux, st.ep_ret, i, P, e);
         const Rng R = make_rng(P, i);
         float af = 0.f, aa = 0.f;
         uint32_t d0[4];
-        if (io.actions != nullptr) {
+        if (fl & kFActions) {
             const float2 a = reinterpret_cast<const float2*>(io.actions)[i];
             af = a.x; aa = a.y;
         }
-        step_prologue<RK45, NZ>(P, R, io.actions == nullptr, d0, af, aa);
+        step_prologue<RK45, NZ>(P, R, !(fl & kFActions), d0, af, aa);
         int fail = 0;
-        env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, af, aa, d0, o, fail);
+        env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, af, aa, d0, fl, o, fail);
         store_env(st.pos, st.aux, st.ep_ret, i, P, e);
         io.rew[i] = o.rew;
         io.done[i] = o.done;
-        if (io.actions_out != nullptr) reinterpret_cast<float2*>(io.actions_out)[i] = make_float2(af, aa);
-        if (io.state_prime != nullptr) reinterpret_cast<float2*>(io.state_prime)[i] = make_float2(o.spx, o.spy);
+        if (fl & kFOutActions) reinterpret_cast<float2*>(io.actions_out)[i] = make_float2(af, aa);
+        if (fl & kFOutStatePrime) reinterpret_cast<float2*>(io.state_prime)[i] = make_float2(o.spx, o.spy);
         if (o.has_final) {
-            if (io.final_obs != nullptr) {
+            if (fl & kFOutFinalObs) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                     if constexpr (AOS) io.final_obs[i * 5 + j] = o.fobs[j];
                     else io.final_obs[(long long)j * P.n + i] = o.fobs[j];
                 }
             }
-            if (io.final_ret != nullptr) io.final_ret[i] = o.fret;
-            if (io.final_len != nullptr) io.final_len[i] = o.flen;
+            if (fl & kFOutFinalRet) io.final_ret[i] = o.fret;
+            if (fl & kFOutFinalLen) io.final_len[i] = o.flen;
         }
-        if (fail && io.status != nullptr) atomicOr(io.status, fail);
+        if (fail && (fl & kFOutStatus)) atomicOr(io.status, fail);
         if constexpr (!AOS) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) io.obs[(long long)j * P.n + i] = o.obs[j];
@@ -133,9 +134,9 @@ __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
     if (obs != nullptr) {
         double gx, gy;
-        goal_at(P, goal_table, R.env, 0, gx, gy);
+        goal_at(P, P.flags, goal_table, R.env, 0, gx, gy);
         const double dx = gx - e.x, dy = gy - e.y;
-        const float v[5] = {(float)e.x, (float)e.y, (float)gx, (float)gy, __builtin_sqrtf((float)(dx * dx + dy * dy))};
+        const float v[5] = {(float)e.x, (float)e.y, (float)gx, (float)gy, __builtin_amdgcn_sqrtf((float)(dx * dx + dy * dy))};
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             if (obs_layout == MRSIM_OBS_AOS) obs[i * 5 + j] = v[j];
@@ -181,47 +182,55 @@ struct RolloutArgs {
 
 template <bool RK45, int NZ, bool MIS>
 __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, const StateArgs st, const RolloutArgs ra) {
-    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    // All per-step stores use a wave-uniform base (block start of row t, kept in SGPRs) plus a 32-bit
+    // per-lane offset, so no 64-bit address arithmetic runs on the vector unit inside the time loop.
+    const long long blk0 = (long long)blockIdx.x * kBlock;
+    const unsigned tid = threadIdx.x;
+    const long long i = blk0 + tid;
     if (i >= P.n) return;
     EnvRegs e;
     load_env(st.pos, st.aux, st.ep_ret, i, P, e);
     int fail = 0;
     for (int t = 0; t < ra.T; ++t) {
+        const uint32_t fl = live_flags(P.flags);  // one SGPR; every uniform yes/no below is a bit test
         const Rng R = make_rng(P, i, (unsigned long long)t);
+        const long long row = (long long)t * P.n + blk0;  // uniform
         float af = 0.f, aa = 0.f;
         uint32_t d0[4];
-        if (ra.actions == nullptr) {
-        } else if (ra.shared_actions) {
+        if (!(fl & kFActions)) {
+        } else if (fl & kFSharedActions) {
             const float2 a = reinterpret_cast<const float2*>(ra.actions)[t];
             af = a.x; aa = a.y;
         } else {
-            const float2 a = reinterpret_cast<const float2*>(ra.actions)[(long long)t * P.n + i];
+            const float2 a = (reinterpret_cast<const float2*>(ra.actions) + row)[tid];
             af = a.x; aa = a.y;
         }
-        step_prologue<RK45, NZ>(P, R, ra.actions == nullptr, d0, af, aa);
+        step_prologue<RK45, NZ>(P, R, !(fl & kFActions), d0, af, aa);
         StepOut o;
-        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, af, aa, d0, o, fail);
+        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, af, aa, d0, fl, o, fail);
         quantise_env(P, e);
-        const long long ti = (long long)t * P.n + i;
-        if (ra.traj_xy != nullptr) reinterpret_cast<double2*>(ra.traj_xy)[ti] = make_double2(o.px, o.py);
-        if (ra.state_prime_T != nullptr) reinterpret_cast<float2*>(ra.state_prime_T)[ti] = make_float2(o.spx0, o.spy0);
-        if (ra.obs_T != nullptr) {
+        if (fl & kFOutTraj) (reinterpret_cast<double2*>(ra.traj_xy) + row)[tid] = make_double2(o.px, o.py);
+        if (fl & kFOutStatePrime) (reinterpret_cast<float2*>(ra.state_prime_T) + row)[tid] = make_float2(o.spx0, o.spy0);
+        if (fl & kFOutObs) {
+            if (fl & kFObsAos) {
+                float* __restrict__ b = ra.obs_T + row * 5;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                if (ra.obs_layout == MRSIM_OBS_AOS) ra.obs_T[ti * 5 + j] = o.obs[j];
-                else ra.obs_T[((long long)t * 5 + j) * P.n + i] = o.obs[j];
+                for (int j = 0; j < 5; ++j) b[tid * 5u + j] = o.obs[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) (ra.obs_T + ((long long)t * 5 + j) * P.n + blk0)[tid] = o.obs[j];
             }
         }
-        if (ra.rew_T != nullptr) ra.rew_T[ti] = o.rew;
-        if (ra.done_T != nullptr) ra.done_T[ti] = o.done;
-        if (ra.actions_out_T != nullptr) reinterpret_cast<float2*>(ra.actions_out_T)[ti] = make_float2(af, aa);
+        if (fl & kFOutRew) (ra.rew_T + row)[tid] = o.rew;
+        if (fl & kFOutDone) (ra.done_T + row)[tid] = o.done;
+        if (fl & kFOutActions) (reinterpret_cast<float2*>(ra.actions_out_T) + row)[tid] = make_float2(af, aa);
         if (o.has_final) {  // return / length of the episode that just ended (latest one wins)
-            if (ra.final_ret != nullptr) ra.final_ret[i] = o.fret;
-            if (ra.final_len != nullptr) ra.final_len[i] = o.flen;
+            if (fl & kFOutFinalRet) ra.final_ret[i] = o.fret;
+            if (fl & kFOutFinalLen) ra.final_len[i] = o.flen;
         }
     }
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
-    if (fail && ra.status != nullptr) atomicOr(ra.status, fail);
+    if (fail && (P.flags & kFOutStatus)) atomicOr(ra.status, fail);
 }
 
 __global__ void mr_advance_kernel(unsigned long long* step_base, unsigned long long delta) {
@@ -265,9 +274,12 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
     K.dmax2 = p->obs_high[4] * p->obs_high[4];
     K.dmin2 = p->obs_low[4] > 0.0 ? p->obs_low[4] * p->obs_low[4] : 0.0;
     K.sym_bound = p->obs_high[0];
-    K.sym_bounds = 1;
+    bool sym = true;
     for (int j = 0; j < 4; ++j)
-        if (!(p->obs_high[j] == K.sym_bound && p->obs_low[j] == -K.sym_bound)) K.sym_bounds = 0;
+        if (!(p->obs_high[j] == K.sym_bound && p->obs_low[j] == -K.sym_bound)) sym = false;
+    K.flags = (sym ? kFSymBounds : 0u) | (p->auto_reset ? kFAutoReset : 0u) |
+              (p->reward_mode == MRSIM_REW_GOAL ? kFRewardGoal : 0u) | (p->step_base ? kFStepBase : 0u) |
+              (p->obs_layout == MRSIM_OBS_AOS ? kFObsAos : 0u) | (p->integrator == MRSIM_INT_RK4 ? kFRk4 : 0u);
     for (int j = 0; j < 2; ++j) {
         K.init_lo[j] = p->init_low[j]; K.init_span[j] = p->init_high[j] - p->init_low[j];
         K.act_lo[j] = p->act_low[j]; K.act_span[j] = p->act_high[j] - p->act_low[j];
@@ -358,6 +370,10 @@ static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
     const StateArgs S{st->pos, st->aux, st->ep_ret};
     const IOArgs IO{io->actions, io->actions_out, io->goal_table, io->obs, io->rew, io->done, io->state_prime,
                     io->final_obs, io->final_ret, io->final_len, io->status};
+    K.flags |= (io->actions ? kFActions : 0u) | (io->goal_table ? kFGoalTable : 0u) |
+               (io->actions_out ? kFOutActions : 0u) | (io->state_prime ? kFOutStatePrime : 0u) |
+               (io->final_obs ? kFOutFinalObs : 0u) | (io->final_ret ? kFOutFinalRet : 0u) |
+               (io->final_len ? kFOutFinalLen : 0u) | (io->status ? kFOutStatus : 0u);
     LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
     if (kernel_ms == nullptr) return launch_step(lc, p, K, S, IO);
     // timed variant: events attached to this one dispatch (hipExtLaunchKernelGGL)
@@ -432,6 +448,7 @@ int mrsim_reset(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimSt
     if ((rc = check_device())) return rc;
     const StateArgs S{st->pos, st->aux, st->ep_ret};
     const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    if (goal_table != nullptr) K.flags |= kFGoalTable;
     const bool rk45 = p->integrator == MRSIM_INT_RK45;
     // fixed-step modes carry no RK45 object: nothing stochastic happens in their reset
     return dispatch(rk45, rk45 ? noise_variant(p) : kNoNoise, rk45 && ctor_mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
@@ -477,6 +494,12 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     if (io->goal_table != nullptr && (p->goal_K < 1 || p->goal_T < 1)) return MRSIM_EINVAL;
     if ((rc = check_device())) return rc;
     const StateArgs S{st->pos, st->aux, st->ep_ret};
+    K.flags |= (io->actions ? kFActions : 0u) | (io->shared_actions ? kFSharedActions : 0u) |
+               (io->goal_table ? kFGoalTable : 0u) | (io->traj_xy ? kFOutTraj : 0u) |
+               (io->state_prime_T ? kFOutStatePrime : 0u) | (io->obs_T ? kFOutObs : 0u) | (io->rew_T ? kFOutRew : 0u) |
+               (io->done_T ? kFOutDone : 0u) | (io->actions_out_T ? kFOutActions : 0u) |
+               (io->final_ret ? kFOutFinalRet : 0u) | (io->final_len ? kFOutFinalLen : 0u) |
+               (io->status ? kFOutStatus : 0u);
     const RolloutArgs ra{io->T, io->shared_actions, p->obs_layout, 0, io->actions, io->goal_table, io->traj_xy,
                          io->state_prime_T, io->obs_T, io->rew_T, io->done_T, io->actions_out_T, io->final_ret,
                          io->final_len, io->status};
