@@ -40,7 +40,7 @@ struct KParams {
     double dmin2, dmax2;  // obs_low[4]^2 (0 if <= 0), obs_high[4]^2
     double sym_bound;     // valid when sym_bounds: obs_lo[j] == -sym_bound, obs_hi[j] == sym_bound for j < 4
     double init_lo[2], init_span[2];
-    double act_lo[2], act_span[2];
+    float act_lo_f[2], act_span_f[2];
     double h1_thresh;  // 0.01 / dt^5 : select_initial_step's h1 >= dt  <=>  max(d1,d2) <= h1_thresh
     float h1_thresh2_f, dt2_f;
     int32_t substeps, reward_mode, max_timesteps, auto_reset, goal_K, goal_T;
@@ -255,34 +255,40 @@ __device__ __forceinline__ double fifth_root(double x) {
     return x * (r2 * r2);
 }
 
-// sin and cos of a double: two-term fma Cody-Waite reduction by pi/2 (exact products, so the
-// reduced argument is good to ~2e-16 absolute for |a| < 1e15) + fdlibm __kernel_sin/__kernel_cos
-// polynomials on [-pi/4, pi/4].  Non-finite or |a| >= 1e15: NaN (numpy would Payne-Hanek).
+// a*b + c with the wave-uniform constant c read straight from a scalar register pair: hipcc otherwise
+// emits v_fmac_f64 and has to v_mov every 64-bit Horner coefficient into the accumulator first.
+__device__ __forceinline__ double fma_sc(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
+// sin and cos of a double: two-term fma Cody-Waite reduction by pi/2 (exact products, so the reduced
+// argument is good to ~2e-16 absolute for |a| < 2^30) + fdlibm __kernel_sin/__kernel_cos polynomials on
+// [-pi/4, pi/4].  NaN/inf give NaN; |a| >= 2^30 rad is outside the supported range (the quadrant
+// conversion saturates) -- numpy would Payne-Hanek there.
 __device__ __forceinline__ void sincos_f64(double a, double& s, double& c) {
     const double k = __builtin_rint(a * 0.63661977236758138);
     double r = __builtin_fma(-k, 1.5707963267948966, a);
     r = __builtin_fma(-k, 6.123233995736766e-17, r);
     const double z = r * r;
-    double ps = 1.58969099521155010221e-10;
-    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
-    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
-    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
-    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
-    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    double ps = fma_sc(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma_sc(ps, z, 2.75573137070700676789e-06);
+    ps = fma_sc(ps, z, -1.98412698298579493134e-04);
+    ps = fma_sc(ps, z, 8.33333333332248946124e-03);
+    ps = fma_sc(ps, z, -1.66666666666666324348e-01);
     const double sr = __builtin_fma(ps * z, r, r);
-    double pc = -1.13596475577881948265e-11;
-    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
-    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
-    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
-    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
-    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    double pc = fma_sc(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma_sc(pc, z, -2.75573143513906633035e-07);
+    pc = fma_sc(pc, z, 2.48015872894767294178e-05);
+    pc = fma_sc(pc, z, -1.38888888888741095749e-03);
+    pc = fma_sc(pc, z, 4.16666666666666019037e-02);
     const double cr = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
-    const int q = (int)(long long)k & 3;
+    const int q = (int)k;
     const double s0 = (q & 1) ? cr : sr;
     const double c0 = (q & 1) ? sr : cr;
     s = (q & 2) ? -s0 : s0;
     c = ((q + 1) & 2) ? -c0 : c0;
-    if (!(__builtin_fabs(a) < 1e15)) { s = __builtin_nan(""); c = s; }
 }
 
 // scipy common.norm of a 2-vector
@@ -692,10 +698,11 @@ __device__ __forceinline__ constexpr uint32_t policy_c0(bool rk45) {
     return rk45 ? c0_of(kStreamDyn, 0, 0) : c0_of(kStreamPolicy, 0, 0);
 }
 __device__ __forceinline__ void action_from_words(const KParams& P, const uint32_t* w, float& f_t, float& al) {
-    const double u0 = ((double)w[0] + 0.5) * 2.3283064365386963e-10;
-    const double u1 = ((double)w[1] + 0.5) * 2.3283064365386963e-10;
-    f_t = (float)(P.act_lo[0] + P.act_span[0] * u0);
-    al = (float)(P.act_lo[1] + P.act_span[1] * u1);
+    // fp32 on purpose (actions are float32 at the ABI): u = fma(float(w), 2^-32, 2^-33), a = fma(span, u, lo)
+    const float u0 = __builtin_fmaf((float)w[0], 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float u1 = __builtin_fmaf((float)w[1], 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    f_t = __builtin_fmaf(P.act_span_f[0], u0, P.act_lo_f[0]);
+    al = __builtin_fmaf(P.act_span_f[1], u1, P.act_lo_f[1]);
 }
 // Philox words the step needs up front: the policy's (when the policy is drawn in-kernel) and/or
 // the first noise call of the RK45 integrator.  Returns whether d0 holds DYN block 0 call 0.

@@ -282,7 +282,7 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
               (p->obs_layout == MRSIM_OBS_AOS ? kFObsAos : 0u) | (p->integrator == MRSIM_INT_RK4 ? kFRk4 : 0u);
     for (int j = 0; j < 2; ++j) {
         K.init_lo[j] = p->init_low[j]; K.init_span[j] = p->init_high[j] - p->init_low[j];
-        K.act_lo[j] = p->act_low[j]; K.act_span[j] = p->act_high[j] - p->act_low[j];
+        K.act_lo_f[j] = (float)p->act_low[j]; K.act_span_f[j] = (float)(p->act_high[j] - p->act_low[j]);
     }
     K.h1_thresh = 0.01 / std::pow(p->time_span, 5.0);
     K.h1_thresh2_f = (float)(K.h1_thresh * K.h1_thresh);

@@ -426,11 +426,13 @@ void orc_sample_init(const OrcParams* p, uint64_t seed, uint32_t env_id, uint64_
  * less per step.  Fixed-step modes consume those words for noise and give the policy its own call. */
 void orc_random_action(int integrator, uint64_t seed, uint32_t env_id, uint64_t step_idx, const double lo[2],
                        const double hi[2], float act[2]) {
-    double u[2];
-    orc_uniform2(seed, env_id, step_idx,
-                 integrator == ORC_INT_RK45 ? C0(STREAM_DYN, 0, 0) : C0(STREAM_POLICY, 0, 0), u);
-    act[0] = (float)(lo[0] + (hi[0] - lo[0]) * u[0]);
-    act[1] = (float)(lo[1] + (hi[1] - lo[1]) * u[1]);
+    /* fp32 on purpose (actions are float32 at the ABI): u = fma(float(w), 2^-32, 2^-33), a = fma(span, u, lo) */
+    uint32_t r[4];
+    philox_call(seed, env_id, step_idx, integrator == ORC_INT_RK45 ? C0(STREAM_DYN, 0, 0) : C0(STREAM_POLICY, 0, 0), r);
+    for (int j = 0; j < 2; ++j) {
+        const float u = fmaf((float)r[j], 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+        act[j] = fmaf((float)(hi[j] - lo[j]), u, (float)lo[j]);
+    }
 }
 
 /* reset.  MR_env.py:164-201 (prints and the unused second sample() omitted) */
