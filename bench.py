@@ -199,6 +199,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(K)
+    gatherer.finish()  # outstanding async all-gathers belong to the timed region
     torch.cuda.synchronize(dev)
     barrier()
     el = time.perf_counter() - t0

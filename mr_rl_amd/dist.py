@@ -66,18 +66,62 @@ def gather_returns_ragged(local_returns, total_envs, group=None):
 
 
 class ReturnGatherer:
-    """Episode-return reduction for a sharded MRVecEnv: keeps the gathered [total] tensor resident."""
+    """Episode-return reduction for a sharded MRVecEnv.
+
+    gather() is called at an episode boundary.  It stages the [n_local] returns (a 1 MiB device copy on the
+    compute stream) and starts an ASYNCHRONOUS all-gather into one of two resident [total] buffers; the
+    compute stream never waits for it, so the next episode's kernels overlap the collective (xGMI is
+    point-to-point and 4 B/env is latency-bound: ~tens of us that would otherwise sit on the critical path
+    of a ~250 us episode).  A buffer is only reused after the collective that last used it has been
+    waited on (stream-side wait, no host block).  latest() / last_mean() wait for the newest gather.
+    """
 
     def __init__(self, env, world_size=1, group=None):
         import torch
         self.env, self.world, self.group = env, int(world_size), group
-        self.all_returns = torch.zeros(self.world * env.num_envs, dtype=torch.float32, device=env.device)
+        n = env.num_envs
+        self._stage = [torch.zeros(n, dtype=torch.float32, device=env.device) for _ in range(2)]
+        self._all = [torch.zeros(self.world * n, dtype=torch.float32, device=env.device) for _ in range(2)]
+        self._pending = [None, None]
         self.n_gathers = 0
 
+    def _distributed(self):
+        import torch.distributed as dist
+        return self.world > 1 and dist.is_available() and dist.is_initialized()
+
     def gather(self):
-        gather_returns(self.env.final_ret, out=self.all_returns, group=self.group)
+        import torch.distributed as dist
+        k = self.n_gathers % 2
+        if self._pending[k] is not None:
+            self._pending[k].wait()  # the collective that used these buffers two episodes ago
+            self._pending[k] = None
+        self._stage[k].copy_(self.env.final_ret)
+        if not self._distributed():
+            self._all[k][: self.env.num_envs].copy_(self._stage[k])
+        elif dist.get_backend(self.group) == "gloo" and self._stage[k].is_cuda:
+            gather_returns(self._stage[k], out=self._all[k], group=self.group)  # rehearsal path, synchronous
+        else:
+            self._pending[k] = dist.all_gather_into_tensor(self._all[k], self._stage[k], group=self.group,
+                                                           async_op=True)
         self.n_gathers += 1
-        return self.all_returns
+
+    def latest(self):
+        """[total] returns of the most recent gather, in global env order (waits for that collective)."""
+        if self.n_gathers == 0:
+            return None
+        k = (self.n_gathers - 1) % 2
+        if self._pending[k] is not None:
+            self._pending[k].wait()
+            self._pending[k] = None
+        return self._all[k]
+
+    def finish(self):
+        """Wait (stream-side) for every outstanding collective; call before the final synchronize."""
+        for k in range(2):
+            if self._pending[k] is not None:
+                self._pending[k].wait()
+                self._pending[k] = None
 
     def last_mean(self):
-        return float(self.all_returns.mean().item()) if self.n_gathers else None
+        r = self.latest()
+        return None if r is None else float(r.mean().item())

@@ -90,3 +90,48 @@ def test_gather_returns_single_process_is_identity():
     assert gather_returns(x) is x
     out = torch.zeros(5)
     assert torch.equal(gather_returns(x, out=out), x)
+
+
+def _gatherer_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mr_rl_amd.dist import ReturnGatherer
+
+        class FakeEnv:  # the only members ReturnGatherer touches
+            num_envs = 5
+            device = torch.device("cpu")
+            final_ret = torch.zeros(5)
+
+        env = FakeEnv()
+        g = ReturnGatherer(env, world)
+        outs = []
+        for ep in range(5):  # more episodes than buffers: exercises buffer reuse
+            env.final_ret = torch.arange(5, dtype=torch.float32) + 100 * rank + 1000 * ep
+            g.gather()
+            outs.append(g.latest().clone().numpy())
+        g.finish()
+        q.put((rank, outs, g.last_mean()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_return_gatherer_double_buffering_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gatherer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs, mean in got:
+        for ep, o in enumerate(outs):
+            want = np.concatenate([np.arange(5) + 100 * r + 1000 * ep for r in range(world)]).astype(np.float32)
+            np.testing.assert_array_equal(o, want)
+        assert mean == pytest.approx(float(np.concatenate([np.arange(5) + 100 * r + 4000 for r in range(world)]).mean()))
