@@ -132,6 +132,39 @@ __device__ __forceinline__ void philox_call(const Rng& R, uint32_t c0, uint32_t 
     philox4x32_10(c0, R.step_lo, R.step_hi, R.env, k0, k1, o);
 }
 
+// N independent Philox calls advanced round by round, call-innermost: 2N multiplies are in flight per round,
+// which hides the v_mad_u64_u32 -> v_bitop3 -> v_mad dependency chain that a single call (ILP 2) exposes at
+// 4 waves per SIMD.  Same words as N separate philox_call()s.
+template <int N>
+__device__ __forceinline__ void philox_multi(const Rng& R, const uint32_t (&c0s)[N], uint32_t (&o)[N][4]) {
+    uint32_t k0 = R.k0, k1 = R.k1;
+    asm volatile("" : "+s"(k0), "+s"(k1));  // see philox_call
+    uint32_t c[N][4];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { c[j][0] = c0s[j]; c[j][1] = R.step_lo; c[j][2] = R.step_hi; c[j][3] = R.env; }
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c[j][0];
+            const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[j][2];
+            uint32_t n0, n2;
+            if (r < 3) {
+                n0 = (uint32_t)(p1 >> 32) ^ c[j][1] ^ k0;
+                n2 = (uint32_t)(p0 >> 32) ^ c[j][3] ^ k1;
+            } else {
+                n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c[j][1], k0, 0x96);
+                n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c[j][3], k1, 0x96);
+            }
+            c[j][1] = (uint32_t)p1; c[j][3] = (uint32_t)p0; c[j][0] = n0; c[j][2] = n2;
+        }
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) { o[j][0] = c[j][0]; o[j][1] = c[j][1]; o[j][2] = c[j][2]; o[j][3] = c[j][3]; }
+}
+
 // ln(u), u in [2^-33, 1]; Cephes logf polynomial, explicit fma => bit-identical to the oracle.
 __device__ __forceinline__ float spec_logf(float u) {
     const uint32_t b = __float_as_uint(u);
@@ -219,6 +252,16 @@ __device__ __forceinline__ void block_normals(const Rng& R, uint32_t c0base, flo
         else philox_call(R, c0base | (uint32_t)j, o);
         box_muller<NZ>(o[0], o[1], z[4 * j + 0], z[4 * j + 1]);
         box_muller<NZ>(o[2], o[3], z[4 * j + 2], z[4 * j + 3]);
+    }
+}
+
+// normals of NCALLS calls whose Philox words are already there
+template <int NZ, int NCALLS>
+__device__ __forceinline__ void normals_from_words(const uint32_t (*w)[4], float (&z)[NCALLS * 4]) {
+#pragma unroll
+    for (int j = 0; j < NCALLS; ++j) {
+        box_muller<NZ>(w[j][0], w[j][1], z[4 * j + 0], z[4 * j + 1]);
+        box_muller<NZ>(w[j][2], w[j][3], z[4 * j + 2], z[4 * j + 3]);
     }
 }
 
@@ -361,12 +404,13 @@ __device__ __forceinline__ void noise_vec(const KParams& P, const RhsCtx<MIS>& C
 template <int NZ, bool MIS>
 __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, uint32_t stream,
                                                double x, double y, double& f0x, double& f0y, double& h_abs,
-                                               double& spx, double& spy) {
+                                               double& spx, double& spy, const uint32_t (*cw)[4] = nullptr) {
     double n0x = 0.0, n0y = 0.0, n1x = 0.0, n1y = 0.0;
     if constexpr (NZ != kNoNoise) {
         constexpr int NC = MIS ? 2 : 1;
         float z[NC * 4];
-        block_normals<NZ, NC>(R, c0_of(stream, 0, 0), z);
+        if (cw != nullptr) normals_from_words<NZ, NC>(cw, z);  // words drawn up front by step_prologue
+        else block_normals<NZ, NC>(R, c0_of(stream, 0, 0), z);
         if constexpr (MIS) {
             noise_vec<MIS>(P, C, z[0], z[1], z[2], n0x, n0y);
             noise_vec<MIS>(P, C, z[3], z[4], z[5], n1x, n1y);
@@ -444,7 +488,7 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         constexpr int NC = MIS ? 5 : 3;
         float z[NC * 4];
         // FIRST: attempt 0, whose call 0 (= DYN block 0 call 0) the caller already computed
-        if constexpr (FIRST) block_normals<NZ, NC, true>(R, c0_of(kStreamDyn, 0, 0), z, d0);
+        if constexpr (FIRST) normals_from_words<NZ, NC>(reinterpret_cast<const uint32_t (*)[4]>(d0), z);
         else block_normals<NZ, NC>(R, c0_of(kStreamDyn, attempt, 0), z);
         constexpr int D = MIS ? 3 : 2;
         constexpr int O = MIS ? 1 : 0;  // offset of z_x inside an eval's draws
@@ -704,15 +748,33 @@ __device__ __forceinline__ void action_from_words(const KParams& P, const uint32
     f_t = __builtin_fmaf(P.act_span_f[0], u0, P.act_lo_f[0]);
     al = __builtin_fmaf(P.act_span_f[1], u1, P.act_lo_f[1]);
 }
-// Philox words the step needs up front: the policy's (when the policy is drawn in-kernel) and/or
-// the first noise call of the RK45 integrator.  Returns whether d0 holds DYN block 0 call 0.
-template <bool RK45, int NZ>
-__device__ __forceinline__ void step_prologue(const KParams& P, const Rng& R, bool random_policy, uint32_t (&d0)[4],
-                                              float& af, float& aa) {
-    constexpr bool NEED0 = RK45 && NZ != kNoNoise;
-    d0[0] = d0[1] = d0[2] = d0[3] = 0u;
-    if (NEED0 || random_policy) philox_call(R, policy_c0(RK45), d0);
-    if (random_policy) action_from_words(P, d0, af, aa);
+// Philox words of the step's hot path, drawn together up front (philox_multi): in RK45 mode the first
+// rk_step attempt's calls DYN(0, 0..NDYN-1) followed by the constructor's CTOR(0, 0..NCTOR-1); slot 0 also
+// carries the exploration policy's two words.  Later attempts (rare) and resets draw their own.
+template <bool RK45, int NZ, bool MIS>
+struct StepWords {
+    static constexpr int NDYN = (RK45 && NZ != kNoNoise) ? (MIS ? 5 : 3) : 0;
+    static constexpr int NCTOR = (RK45 && NZ != kNoNoise) ? (MIS ? 2 : 1) : 0;
+    static constexpr int N = (NDYN + NCTOR) > 0 ? (NDYN + NCTOR) : 1;
+    uint32_t w[N][4];
+};
+
+template <bool RK45, int NZ, bool MIS>
+__device__ __forceinline__ void step_prologue(const KParams& P, const Rng& R, bool random_policy,
+                                              StepWords<RK45, NZ, MIS>& W, float& af, float& aa) {
+    using SW = StepWords<RK45, NZ, MIS>;
+    if constexpr (SW::NDYN > 0) {
+        uint32_t c0s[SW::N];
+#pragma unroll
+        for (int j = 0; j < SW::NDYN; ++j) c0s[j] = c0_of(kStreamDyn, 0, (uint32_t)j);
+#pragma unroll
+        for (int j = 0; j < SW::NCTOR; ++j) c0s[SW::NDYN + j] = c0_of(kStreamCtor, 0, (uint32_t)j);
+        philox_multi<SW::N>(R, c0s, W.w);
+    } else {
+        W.w[0][0] = W.w[0][1] = W.w[0][2] = W.w[0][3] = 0u;
+        if (random_policy) philox_call(R, policy_c0(RK45), W.w[0]);
+    }
+    if (random_policy) action_from_words(P, W.w[0], af, aa);
 }
 
 __device__ __forceinline__ void pack_obs(double x, double y, double gx, double gy, double d2, float (&obs)[5]) {
@@ -724,14 +786,16 @@ __device__ __forceinline__ void pack_obs(double x, double y, double gx, double g
 // MR_Env.step for one env (MR_env.py:70-98)
 template <bool RK45, int NZ, bool MIS>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
-                                         EnvRegs& e, float act_f, float act_a, const uint32_t* d0, uint32_t fl,
-                                         StepOut& o, int& fail) {
+                                         EnvRegs& e, float act_f, float act_a, const StepWords<RK45, NZ, MIS>& W,
+                                         uint32_t fl, StepOut& o, int& fail) {
+    using SW = StepWords<RK45, NZ, MIS>;
     e.counter += 1;  // :80
     const RhsCtx<MIS> C = make_ctx<MIS>(P, (double)act_f, (double)act_a);
     double spx = 0.0, spy = 0.0;
     if constexpr (RK45) {
-        rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, d0);              // MR_simulator.py:42-45
-        rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy);  // :46-50
+        rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, &W.w[0][0]);      // MR_simulator.py:42-45
+        rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy,  // :46-50
+                                SW::NCTOR > 0 ? &W.w[SW::NDYN] : nullptr);
     } else {
         fixed_integrate<NZ, MIS>(P, C, R, e.x, e.y, spx, spy);
         e.f0x = spx; e.f0y = spy; e.h_abs = P.dt;

@@ -57,14 +57,14 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
         load_env(st.pos, st.aux, st.ep_ret, i, P, e);
         const Rng R = make_rng(P, i);
         float af = 0.f, aa = 0.f;
-        uint32_t d0[4];
+        StepWords<RK45, NZ, MIS> W;
         if (fl & kFActions) {
             const float2 a = reinterpret_cast<const float2*>(io.actions)[i];
             af = a.x; aa = a.y;
         }
-        step_prologue<RK45, NZ>(P, R, !(fl & kFActions), d0, af, aa);
+        step_prologue<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa);
         int fail = 0;
-        env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, af, aa, d0, fl, o, fail);
+        env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, af, aa, W, fl, o, fail);
         store_env(st.pos, st.aux, st.ep_ret, i, P, e);
         io.rew[i] = o.rew;
         io.done[i] = o.done;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, con
         const Rng R = make_rng(P, i, (unsigned long long)t);
         const long long row = (long long)t * P.n + blk0;  // uniform
         float af = 0.f, aa = 0.f;
-        uint32_t d0[4];
+        StepWords<RK45, NZ, MIS> W;
         if (!(fl & kFActions)) {
         } else if (fl & kFSharedActions) {
             const float2 a = reinterpret_cast<const float2*>(ra.actions)[t];
@@ -205,9 +205,9 @@ __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, con
             const float2 a = (reinterpret_cast<const float2*>(ra.actions) + row)[tid];
             af = a.x; aa = a.y;
         }
-        step_prologue<RK45, NZ>(P, R, !(fl & kFActions), d0, af, aa);
+        step_prologue<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa);
         StepOut o;
-        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, af, aa, d0, fl, o, fail);
+        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, af, aa, W, fl, o, fail);
         quantise_env(P, e);
         if (fl & kFOutTraj) (reinterpret_cast<double2*>(ra.traj_xy) + row)[tid] = make_double2(o.px, o.py);
         if (fl & kFOutStatePrime) (reinterpret_cast<float2*>(ra.state_prime_T) + row)[tid] = make_float2(o.spx0, o.spy0);
