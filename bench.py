@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=510)     # 10 episodes
-    ap.add_argument("--warmup", type=int, default=51)
+    ap.add_argument("--steps", type=int, default=5100)    # 100 episodes
+    ap.add_argument("--warmup", type=int, default=510)
     ap.add_argument("--envs-per-gpu", type=int, default=262144)
     ap.add_argument("--mode", choices=["rollout", "step"], default="rollout")
     ap.add_argument("--rollout-len", type=int, default=51)

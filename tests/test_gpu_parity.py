@@ -443,3 +443,20 @@ def test_run_sim_batched_matches_golden_tuple():
     # f0 is non-zero, so the step is not split and the stale stage weighs b1 -- the reference does the same)
     dX, dX0 = X[-1] - X[0], X0[-1] - X0[0]
     assert abs(dX.mean() - dX0) < 6 * sd / np.sqrt(4096) and abs(dX.std() / sd - 1) < 0.05
+
+
+def test_ddpg_consumer_runs_on_device_env():
+    """the PyTorch DDPG twin consumes MRVecEnv on the GPU end to end (goal reward,
+    reachable goal so that episodes end by reaching it)."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.ddpg import DDPG
+    cfg = MRConfig(noise_var=0.1, reward_mode="goal", auto_reset=True, init_low=(20.0, 20.0), init_high=(30.0, 30.0),
+                   min_dist2goal=25.0)
+    env = MRVecEnv(256, cfg=cfg, seed=0)
+    agent = DDPG(env, seed=0, obs_scale=[0.01] * 5)
+    rets = agent.train(120)
+    assert agent.buffer.size() == 10000 and len(rets) > 0 and all(np.isfinite(rets))
+    a = agent.act(env.obs, explore=False)
+    assert a.shape == (256, 2) and torch.isfinite(a).all()
+    env.check_status()
