@@ -168,6 +168,18 @@ int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const
                         const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream,
                         float* kernel_ms_host);
 
+/* Velocity post-processing that every consumer of run_sim applies to the recorded positions
+ * (Learning_module.py:46-59,72-93; main.py:102-109):
+ *     p  = uniform_filter1d(p, N, mode="nearest")           (running mean, window [t - N/2, t + N - N/2 - 1])
+ *     v  = np.gradient(p, time)                             (second-order interior, first-order edges)
+ *     v  = uniform_filter1d(v, N/2, mode="nearest")
+ *     D  = mean(v[N:-N])                                    (estimateDisturbance's drift; 0 if T <= 2N)
+ * for n trajectories at once, one lane per trajectory streaming along t.  traj_xy: [T][n][2] fp64 (the
+ * layout mrsim_rollout writes); time: [T] fp64; v_xy: [T][n][2] fp64 out; scratch_xy: [T][n][2] fp64 work
+ * buffer; drift_xy: optional [n][2] fp64 out.  n_filter = N (the reference uses int(1/0.035/2) = 14). */
+int mrsim_velocity(int64_t n, int32_t T, int32_t n_filter, const double* traj_xy, const double* time,
+                   double* v_xy, double* scratch_xy, double* drift_xy, void* stream);
+
 /* *step_base += delta on `stream` (a one-lane kernel; graph-capturable). */
 int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream);
 

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 # every symbol include/mrsim.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
     "mrsim_abi_version", "mrsim_strerror", "mrsim_default_params", "mrsim_reset", "mrsim_step",
-    "mrsim_step_timed", "mrsim_random_policy", "mrsim_rollout", "mrsim_rollout_timed", "mrsim_advance_step_base", "mrsim_debug_normals",
+    "mrsim_step_timed", "mrsim_random_policy", "mrsim_rollout", "mrsim_rollout_timed", "mrsim_advance_step_base", "mrsim_velocity", "mrsim_debug_normals",
     "mrsim_device_count", "mrsim_device_name",
 )
 
@@ -89,6 +89,8 @@ def lib():
     L.mrsim_rollout.argtypes = [PP, i64, u32, PS, C.POINTER(MrsimRolloutIO), u64, u64, vp]
     L.mrsim_rollout_timed.argtypes = L.mrsim_rollout.argtypes + [C.POINTER(C.c_float)]
     L.mrsim_rollout_timed.restype = C.c_int
+    L.mrsim_velocity.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.mrsim_velocity.restype = C.c_int
     L.mrsim_advance_step_base.argtypes = [vp, u64, vp]
     L.mrsim_advance_step_base.restype = C.c_int
     L.mrsim_debug_normals.argtypes = [i64, u32, u64, u64, u32, i32, vp, vp]

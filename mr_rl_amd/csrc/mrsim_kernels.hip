@@ -233,6 +233,63 @@ __global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, con
     if (fail && (P.flags & kFOutStatus)) atomicOr(ra.status, fail);
 }
 
+// ---------------------------------------------------------------------------
+// velocity post-processing (Learning_module.py:46-59): three streaming passes over [T][n][2]
+// ---------------------------------------------------------------------------
+// scipy.ndimage.uniform_filter1d(x, size, mode="nearest") along t: window [t - size/2, t + size - size/2 - 1],
+// indices clamped to [0, T-1]; running sum like scipy's own C loop.  Optionally also the mean of out[lo:hi).
+__global__ __launch_bounds__(kBlock) void mr_boxfilter_kernel(long long n, int T, int size, const double2* __restrict__ in,
+                                                              double2* __restrict__ out, double2* __restrict__ mean_out,
+                                                              int mean_lo, int mean_hi) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int left = size / 2, right = size - left - 1;
+    auto at = [&](int t) { t = t < 0 ? 0 : (t >= T ? T - 1 : t); return in[(long long)t * n + i]; };
+    double sx = 0.0, sy = 0.0;
+    for (int k = -left; k <= right; ++k) { const double2 v = at(k); sx += v.x; sy += v.y; }
+    const double inv = 1.0 / size;
+    double mx = 0.0, my = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double ox = sx * inv, oy = sy * inv;
+        out[(long long)t * n + i] = make_double2(ox, oy);
+        if (t >= mean_lo && t < mean_hi) { mx += ox; my += oy; }
+        const double2 a = at(t + right + 1), b = at(t - left);
+        sx += a.x - b.x; sy += a.y - b.y;
+    }
+    if (mean_out != nullptr) {
+        const int cnt = mean_hi - mean_lo;
+        mean_out[i] = cnt > 0 ? make_double2(mx / cnt, my / cnt) : make_double2(0.0, 0.0);
+    }
+}
+
+// numpy.gradient(f, time) along t for non-uniform coordinates (numpy/lib/function_base.py: gradient,
+// edge_order=1): interior  a f[t-1] + b f[t] + c f[t+1] with hs = x[t]-x[t-1], hd = x[t+1]-x[t],
+// a = -hd/(hs(hd+hs)), b = (hd-hs)/(hd hs), c = hs/(hd(hd+hs)); edges are one-sided differences.
+__global__ __launch_bounds__(kBlock) void mr_gradient_kernel(long long n, int T, const double2* __restrict__ f,
+                                                             const double* __restrict__ x, double2* __restrict__ g) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (T == 1) { g[i] = make_double2(0.0, 0.0); return; }
+    double2 fm = f[i], f0 = f[i], fp = f[n + i];
+    for (int t = 0; t < T; ++t) {
+        double2 o;
+        if (t == 0) {
+            const double h = x[1] - x[0];
+            o = make_double2((fp.x - f0.x) / h, (fp.y - f0.y) / h);
+        } else if (t == T - 1) {
+            const double h = x[T - 1] - x[T - 2];
+            o = make_double2((f0.x - fm.x) / h, (f0.y - fm.y) / h);
+        } else {
+            const double hs = x[t] - x[t - 1], hd = x[t + 1] - x[t];
+            const double a = -hd / (hs * (hd + hs)), b = (hd - hs) / (hd * hs), c = hs / (hd * (hd + hs));
+            o = make_double2(a * fm.x + b * f0.x + c * fp.x, a * fm.y + b * f0.y + c * fp.y);
+        }
+        g[(long long)t * n + i] = o;
+        fm = f0; f0 = fp;
+        if (t + 2 < T) fp = f[(long long)(t + 2) * n + i];
+    }
+}
+
 __global__ void mr_advance_kernel(unsigned long long* step_base, unsigned long long delta) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *step_base += delta;
 }
@@ -529,6 +586,30 @@ int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const
                         float* kernel_ms_host) {
     if (kernel_ms_host == nullptr) return MRSIM_EINVAL;
     return rollout_impl(p, n, env_id0, st, io, seed, step_idx0, stream, kernel_ms_host);
+}
+
+int mrsim_velocity(int64_t n, int32_t T, int32_t n_filter, const double* traj_xy, const double* time, double* v_xy,
+                   double* scratch_xy, double* drift_xy, void* stream) {
+    if (n < 0 || T < 1 || n_filter < 1 || traj_xy == nullptr || time == nullptr || v_xy == nullptr ||
+        scratch_xy == nullptr)
+        return MRSIM_EINVAL;
+    if (!aligned16(traj_xy) || !aligned16(v_xy) || !aligned16(scratch_xy) || (drift_xy && !aligned16(drift_xy)))
+        return MRSIM_EALIGN;
+    int rc = check_device();
+    if (rc) return rc;
+    if (n == 0) return MRSIM_OK;
+    const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    const int n2 = n_filter / 2 > 0 ? n_filter / 2 : 1;
+    const int lo = n_filter, hi = T - n_filter;  // v[N:-N]
+    auto P2 = [](const double* p) { return reinterpret_cast<const double2*>(p); };
+    auto Q2 = [](double* p) { return reinterpret_cast<double2*>(p); };
+    if ((rc = launch(lc, mr_boxfilter_kernel, (long long)n, (long long)n, (int)T, (int)n_filter, P2(traj_xy), Q2(v_xy),
+                     (double2*)nullptr, 0, 0)))
+        return rc;
+    if ((rc = launch(lc, mr_gradient_kernel, (long long)n, (long long)n, (int)T, P2(v_xy), time, Q2(scratch_xy))))
+        return rc;
+    return launch(lc, mr_boxfilter_kernel, (long long)n, (long long)n, (int)T, n2, P2(scratch_xy), Q2(v_xy),
+                  Q2(drift_xy), lo, hi > lo ? hi : lo);
 }
 
 int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream) {

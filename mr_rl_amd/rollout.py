@@ -104,3 +104,31 @@ def run_sim(actions, init_pos=None, noise_var=1, a0=1, is_mismatched=False, num_
         sp = out["state_prime"].cpu().numpy()
         return X, Y, alpha, time, freq, (sp[:, 0, :] if num_envs == 1 else sp)
     return X, Y, alpha, time, freq
+
+
+def estimate_velocity(traj, time, n_filter=14):
+    """Batched `LearningModule` velocity pipeline (Learning_module.py:46-59,72-93) on the GPU:
+    uniform_filter1d(N) -> np.gradient(., time) -> uniform_filter1d(N/2), plus the drift D = mean(v[N:-N]).
+    traj: [T,n,2] fp64 device tensor (MRVecEnv.rollout's "traj"); time: [T].  Returns (v [T,n,2], D [n,2])."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    traj = traj.contiguous()
+    assert traj.dtype == torch.float64 and traj.dim() == 3 and traj.shape[2] == 2 and traj.is_cuda
+    T, n = int(traj.shape[0]), int(traj.shape[1])
+    t = torch.as_tensor(time, dtype=torch.float64, device=traj.device).contiguous()
+    assert t.shape == (T,)
+    v = torch.empty_like(traj); scratch = torch.empty_like(traj)
+    drift = torch.empty((n, 2), dtype=torch.float64, device=traj.device)
+    P = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    rc = _lib.lib().mrsim_velocity(n, T, int(n_filter), P(traj), P(t), P(v), P(scratch), P(drift),
+                                   C.c_void_p(torch.cuda.current_stream(traj.device).cuda_stream))
+    _lib.check(rc, "mrsim_velocity")
+    return v, drift
+
+
+def estimate_a0(v, drift, freq, n_filter=14):
+    """a0 = median(speed / freq) over v[N:-N] with the drift removed (Learning_module.py:96,112-123)."""
+    import torch
+    sp = torch.sqrt((v[..., 0] - drift[None, :, 0]) ** 2 + (v[..., 1] - drift[None, :, 1]) ** 2)
+    return torch.median(sp[n_filter:-n_filter] / freq, dim=0).values

@@ -460,3 +460,46 @@ def test_ddpg_consumer_runs_on_device_env():
     a = agent.act(env.obs, explore=False)
     assert a.shape == (256, 2) and torch.isfinite(a).all()
     env.check_status()
+
+
+def test_velocity_pipeline_matches_scipy_numpy():
+    """mrsim_velocity == uniform_filter1d -> np.gradient -> uniform_filter1d and the drift /
+    a0 estimates of Learning_module.py:46-59,72-123, computed here with scipy/numpy as the reference does."""
+    import torch
+    from scipy.ndimage import uniform_filter1d
+    from mr_rl_amd.rollout import estimate_a0, estimate_velocity
+    rng = np.random.default_rng(0)
+    for T, n, N in [(400, 37, 14), (60, 5, 14), (29, 3, 14), (5, 2, 4), (300, 300, 9)]:
+        traj = np.cumsum(rng.normal(0.1, 0.05, (T, n, 2)), axis=0)
+        time = np.linspace(0, (T - 1) / 30.0, T) + rng.uniform(0, 1e-3, T).cumsum() * (T > 100)  # also non-uniform
+        v, D = estimate_velocity(torch.as_tensor(traj, device="cuda"), time, n_filter=N)
+        want = np.zeros_like(traj)
+        for e in range(n):
+            for d in range(2):
+                p = uniform_filter1d(traj[:, e, d], N, mode="nearest")
+                g = np.gradient(p, time)
+                want[:, e, d] = uniform_filter1d(g, int(N / 2), mode="nearest")
+        np.testing.assert_allclose(v.cpu().numpy(), want, rtol=1e-9, atol=1e-9)
+        if T > 2 * N:
+            np.testing.assert_allclose(D.cpu().numpy(), want[N:-N].mean(0), rtol=1e-9, atol=1e-12)
+            a0 = estimate_a0(v, D, 4.0, N).cpu().numpy()
+            sp = np.sqrt(((want - want[N:-N].mean(0)[None]) ** 2).sum(-1))[N:-N] / 4.0
+            lo = np.sort(sp, axis=0)[(sp.shape[0] - 1) // 2]  # torch.median returns the lower middle element
+            np.testing.assert_allclose(a0, lo, rtol=1e-9)
+
+
+def test_learn_a0_from_simulated_circles():
+    """End to end, the `main.py` workflow on the GPU: idle run -> drift, circle run -> a0 (main.py:55-75)."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.rollout import actions_circle, estimate_a0, estimate_velocity
+    acts = actions_circle(1800, 3, 4.0)
+    env = MRVecEnv(64, cfg=MRConfig(noise_var=0.5, a0=1.5), seed=1)
+    env.reset(init=np.zeros((64, 2)))
+    out = env.rollout(len(acts), actions=acts[:, :2].astype(np.float32), shared_actions=True, want=("traj",))
+    time = np.linspace(0, (len(acts) - 1) / 30.0, len(acts))
+    v, D = estimate_velocity(out["traj"], time)
+    # one env step is 30 ms of simulated time but run_sim's time axis is 1/30 s per sample (utils.py:59): speed
+    # estimates scale by 0.03 * 30 = 0.9
+    a0 = estimate_a0(v, torch.zeros_like(D), 4.0)
+    assert abs(float(a0.mean()) / (1.5 * 0.9) - 1) < 0.02
