@@ -107,6 +107,16 @@ def committed_traffic(args, n_local):
 
 def main():
     args = parse()
+    lib_so = os.path.join(ROOT, "mr_rl_amd", "libmrsim.so")
+    if not os.path.exists(lib_so):  # git-ignored build product missing in this checkout: build it (no fallback path)
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(lib_so) and time.time() - t_wait < 600:
+                time.sleep(1.0)
+            time.sleep(2.0)
     import torch
     import torch.distributed as dist
     from mr_rl_amd import MRConfig, MRVecEnv
