@@ -91,6 +91,9 @@ class ReturnGatherer:
 
     def gather(self):
         import torch.distributed as dist
+        if not self._distributed():
+            self.n_gathers += 1  # single process: env.final_ret already IS the global array (see latest())
+            return
         k = self.n_gathers % 2
         if self._pending[k] is not None:
             self._pending[k].wait()  # the collective that used these buffers two episodes ago
@@ -109,6 +112,8 @@ class ReturnGatherer:
         """[total] returns of the most recent gather, in global env order (waits for that collective)."""
         if self.n_gathers == 0:
             return None
+        if not self._distributed():
+            return self.env.final_ret
         k = (self.n_gathers - 1) % 2
         if self._pending[k] is not None:
             self._pending[k].wait()

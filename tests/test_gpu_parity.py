@@ -503,3 +503,46 @@ def test_learn_a0_from_simulated_circles():
     # estimates scale by 0.03 * 30 = 0.9
     a0 = estimate_a0(v, torch.zeros_like(D), 4.0)
     assert abs(float(a0.mean()) / (1.5 * 0.9) - 1) < 0.02
+
+
+def test_graph_replay_draws_fresh_noise_and_matches_eager():
+    """hipGraph-captured steps: kernel arguments are frozen at capture, the RNG step index lives in a device
+    word (MrsimParams.step_base) advanced inside the graph -> every replay draws new noise, and the sequence
+    is bit-identical to the same steps launched eagerly."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    n, G = 2048, 17
+    cfg = dict(noise_var=1.0, auto_reset=True)
+    e1 = MRVecEnv(n, cfg=MRConfig(**cfg), seed=5); e1.reset()
+    e2 = MRVecEnv(n, cfg=MRConfig(**cfg), seed=5); e2.reset()
+    g = e1.capture_steps(G, policy="kernel")     # warm-up inside capture_steps already ran G real steps
+    for _ in range(G):
+        e2.step(e2.random_policy())
+    assert torch.equal(e1.pos, e2.pos)
+    snaps = []
+    for rep in range(3):
+        g.replay()
+        for _ in range(G):
+            e2.step(e2.random_policy())
+        torch.cuda.synchronize()
+        assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.obs, e2.obs) and torch.equal(e1.aux, e2.aux)
+        snaps.append(e1.pos.clone())
+    assert not torch.equal(snaps[0] - snaps[1], snaps[1] - snaps[2])  # different noise each replay
+    assert int(e1._step_base.item()) == 1 + 4 * G
+
+
+def test_state_dict_roundtrip_resumes_bitwise():
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    n = 1000
+    a = MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=9); a.reset()
+    for _ in range(30):
+        a.step(None)
+    sd = a.state_dict()
+    for _ in range(40):
+        a.step(None)
+    b = MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=0)
+    b.load_state_dict(sd)
+    for _ in range(40):
+        b.step(None)
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.aux, b.aux) and torch.equal(a.ep_ret, b.ep_ret)
