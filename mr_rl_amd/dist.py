@@ -99,9 +99,7 @@ class ReturnGatherer:
             self._pending[k].wait()  # the collective that used these buffers two episodes ago
             self._pending[k] = None
         self._stage[k].copy_(self.env.final_ret)
-        if not self._distributed():
-            self._all[k][: self.env.num_envs].copy_(self._stage[k])
-        elif dist.get_backend(self.group) == "gloo" and self._stage[k].is_cuda:
+        if dist.get_backend(self.group) == "gloo" and self._stage[k].is_cuda:
             gather_returns(self._stage[k], out=self._all[k], group=self.group)  # rehearsal path, synchronous
         else:
             self._pending[k] = dist.all_gather_into_tensor(self._all[k], self._stage[k], group=self.group,
