@@ -584,3 +584,21 @@ def test_config3_rk4_figure8_full_size():
     r = out["rew"]
     assert set(torch.unique(r).tolist()) <= {100.0, -0.1, -100.0} and (r == 100.0).any()
     env.check_status()
+
+
+def test_nan_action_terminates_and_raises_status():
+    """A NaN action makes SciPy's step-size control fail in the reference (it would raise / spin); the kernel's
+    attempt loop is bounded, flags the env in the status word and the wave still drains."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    env = MRVecEnv(300, cfg=MRConfig(noise_var=0.0), seed=1)
+    env.reset()
+    a = torch.zeros((300, 2), device="cuda"); a[:, 0] = 4.0
+    a[7, 1] = float("nan")
+    env.step(a)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):
+        env.check_status()
+    pos = env.pos.cpu().numpy()
+    assert np.isnan(pos[7]).any() and np.isfinite(np.delete(pos, 7, axis=0)).all()
+    assert bool(env.done[7])  # NaN fails the bounds test, as Box.contains would
