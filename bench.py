@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-samples", type=int, default=0, help="0 = auto")
+    ap.add_argument("--no-step-path", action="store_true", help="skip the extra one-launch-per-step measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
@@ -103,6 +104,35 @@ def committed_traffic(args, n_local):
         except Exception:
             continue
     return None, None
+
+
+def measure_step_path(cfg, n_local, dev, seed, steps=510, samples=102):
+    """Secondary figure reported beside the headline: the same workload driven through the drop-in gym loop,
+    one launch per MR_Env.step() ([policy kernel -> actions in HBM] + [step kernel], hipGraph of 51 steps)."""
+    import torch
+    from mr_rl_amd import MRVecEnv
+    env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed)
+    env.reset()
+    ep = cfg.max_timesteps + 1
+    graph = env.capture_steps(ep, policy="kernel")
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps // ep):
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    k = (steps // ep) * ep
+    act = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
+    ms = sorted(env.step_timed(env.random_policy(out=act)) for _ in range(samples))
+    avg_ms = sum(ms) / len(ms)
+    ach = n_local * ALGO_BYTES_PER_ENV_STEP / (avg_ms * 1e-3) / 1e9
+    env.check_status()
+    return {"mode": "step (one launch per env.step, hipGraph of 51 steps, policy kernel + step kernel)",
+            "value": n_local * k / el, "unit": "env-steps/s", "steps": k, "ms_per_step": el / k * 1e3,
+            "kernel": "mr_step_kernel", "avg_kernel_us": round(avg_ms * 1e3, 3),
+            "roofline_frac": round(ach / HBM_PEAK_GBS, 4)}
 
 
 def main():
@@ -248,6 +278,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, seed, args.cpu_seconds)
+    step_path = None
+    if rank == 0 and world == 1 and args.mode == "rollout" and not args.no_step_path:
+        step_path = measure_step_path(cfg, n_local, dev, seed)
 
     if world > 1:
         dist.barrier()
@@ -265,6 +298,8 @@ def main():
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic", "config": config, "roofline": roof, "cpu_baseline": cpu}
+        if step_path is not None:
+            out["step_path"] = step_path
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -240,16 +240,13 @@ __device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float& z0, 
     }
 }
 
-// the first NCALLS*4 normals of one block (rk_step attempt / constructor / fixed sub-step).
-// HAVE0: the Philox words of call 0 were already computed by the caller (w0).
-template <int NZ, int NCALLS, bool HAVE0 = false>
-__device__ __forceinline__ void block_normals(const Rng& R, uint32_t c0base, float (&z)[NCALLS * 4],
-                                              const uint32_t* w0 = nullptr) {
+// the first NCALLS*4 normals of one block (rk_step attempt / constructor / fixed sub-step)
+template <int NZ, int NCALLS>
+__device__ __forceinline__ void block_normals(const Rng& R, uint32_t c0base, float (&z)[NCALLS * 4]) {
 #pragma unroll
     for (int j = 0; j < NCALLS; ++j) {
         uint32_t o[4];
-        if (HAVE0 && j == 0) { o[0] = w0[0]; o[1] = w0[1]; o[2] = w0[2]; o[3] = w0[3]; }
-        else philox_call(R, c0base | (uint32_t)j, o);
+        philox_call(R, c0base | (uint32_t)j, o);
         box_muller<NZ>(o[0], o[1], z[4 * j + 0], z[4 * j + 1]);
         box_muller<NZ>(o[2], o[3], z[4 * j + 2], z[4 * j + 3]);
     }
