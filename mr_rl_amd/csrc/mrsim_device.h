@@ -401,9 +401,26 @@ __device__ __forceinline__ void noise_vec(const KParams& P, const RhsCtx<MIS>& C
 template <int NZ, bool MIS>
 __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, uint32_t stream,
                                                double x, double y, double& f0x, double& f0y, double& h_abs,
-                                               double& spx, double& spy, const uint32_t (*cw)[4] = nullptr) {
+                                               double& spx, double& spy, const uint32_t (*cw)[4] = nullptr,
+                                               bool need_f1 = true) {
     double n0x = 0.0, n0y = 0.0, n1x = 0.0, n1y = 0.0;
-    if constexpr (NZ != kNoNoise) {
+    bool have1 = true;
+    if constexpr (NZ != kNoNoise && !MIS) {
+        if (cw != nullptr) {
+            // nominal law on the hot path: f0 <- pair 0 of the call; f1's pair is only evaluated when
+            // Simulator.state_prime is wanted or when the bound below cannot certify h_abs == interval
+            float z0, z1;
+            box_muller<NZ>(cw[0][0], cw[0][1], z0, z1);
+            noise_vec<MIS>(P, C, 0.f, z0, z1, n0x, n0y);
+            have1 = need_f1;
+            if (have1) {
+                float z2, z3;
+                box_muller<NZ>(cw[0][2], cw[0][3], z2, z3);
+                noise_vec<MIS>(P, C, 0.f, z2, z3, n1x, n1y);
+            }
+        }
+    }
+    if constexpr (NZ != kNoNoise) if (MIS || cw == nullptr) {
         constexpr int NC = MIS ? 2 : 1;
         float z[NC * 4];
         if (cw != nullptr) normals_from_words<NZ, NC>(cw, z);  // words drawn up front by step_prologue
@@ -430,13 +447,29 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
         const float r0 = __builtin_amdgcn_rcpf((float)sc0), r1 = __builtin_amdgcn_rcpf((float)sc1);
         const float y0s = (float)x * r0, y1s = (float)y * r1;
         const float g0 = (float)f0x * r0, g1 = (float)f0y * r1;
-        const float e0 = (float)(n1x - n0x) * r0, e1 = (float)(n1y - n0y) * r1;
         const float D0 = __builtin_fmaf(y0s, y0s, y1s * y1s);
         const float D1 = __builtin_fmaf(g0, g0, g1 * g1);
-        const float DD = __builtin_fmaf(e0, e0, e1 * e1);
         const float TH2 = P.h1_thresh2_f;
-        const bool fast = (D0 > 1e-9f) && (D1 > 1e-9f) && (D0 >= 1.05f * P.dt2_f * D1) && (D1 <= 1.9f * TH2) &&
-                          (DD <= 1.9f * TH2 * P.dt2_f) && (DD * D1 <= 1.9e-4f * TH2 * D0);
+        const bool fast01 = (D0 > 1e-9f) && (D1 > 1e-9f) && (D0 >= 1.05f * P.dt2_f * D1) && (D1 <= 1.9f * TH2);
+        if (!have1) {
+            // f1 not evaluated yet: worst case |n1 - n0| <= |n0| + sigma*Zmax per axis (|z| <= 6.763)
+            const float zb = (float)(P.sigma * 6.78);
+            const float w0 = ((float)__builtin_fabs(n0x) + zb) * r0, w1 = ((float)__builtin_fabs(n0y) + zb) * r1;
+            const float DW = __builtin_fmaf(w0, w0, w1 * w1);
+            if (__builtin_expect(fast01 && (DW <= 1.9f * TH2 * P.dt2_f) && (DW * D1 <= 1.9e-4f * TH2 * D0), 1)) {
+                h_abs = P.dt;  // same outcome as with f1 evaluated: every admissible f1 passes the test
+                return;
+            }
+            if constexpr (NZ != kNoNoise && !MIS) {  // the bound cannot decide: evaluate f1 after all
+                float z2, z3;
+                box_muller<NZ>(cw[0][2], cw[0][3], z2, z3);
+                noise_vec<MIS>(P, C, 0.f, z2, z3, n1x, n1y);
+                spx = C.vx + n1x; spy = C.vy + n1y;
+            }
+        }
+        const float e0 = (float)(n1x - n0x) * r0, e1 = (float)(n1y - n0y) * r1;
+        const float DD = __builtin_fmaf(e0, e0, e1 * e1);
+        const bool fast = fast01 && (DD <= 1.9f * TH2 * P.dt2_f) && (DD * D1 <= 1.9e-4f * TH2 * D0);
         if (__builtin_expect(fast, 1)) { h_abs = P.dt; return; }
     }
     // exact path: select_initial_step(fun, t0, y0, t_bound, inf, f0, +1, order=4, rtol, atol)
@@ -467,6 +500,11 @@ constexpr int kMaxAttempts = 4096;  // every lane leaves the loop: bounded spin
 struct AttemptNoise {
     double nbx, nby, nex, ney;
     float z6a, z6x, z6y;  // f_new's normals; only needed when another sub-step follows
+    // lazy K6 (nominal law, first attempt): error sums WITHOUT the E6*z6 term and the two Philox words of
+    // K6's Box-Muller pair; nex/ney/z6* are filled by finish_k6() only if the bound test cannot decide
+    float ex32, ey32;
+    uint32_t w6a, w6b;
+    bool lazy6;
 };
 
 template <int NZ, bool MIS, bool FIRST>
@@ -476,8 +514,33 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
     if constexpr (NZ == kNoNoise) {
         A.nbx = A.nby = A.nex = A.ney = 0.0;
         A.z6a = A.z6x = A.z6y = 0.f;
+        A.ex32 = A.ey32 = 0.f; A.w6a = A.w6b = 0u; A.lazy6 = false;
+        return A;
+    } else if constexpr (!MIS && FIRST) {
+        // nominal law, first attempt, words already drawn: K1 = call 0 pair 0 (dead), K2 = call 0 pair 1,
+        // K3, K4 = call 1, K5 = call 2 pair 0, K6 = call 2 pair 1 (left as words: see finish_k6)
+        const uint32_t (*w)[4] = reinterpret_cast<const uint32_t (*)[4]>(d0);
+        float k2x, k2y, k3x, k3y, k4x, k4y, k5x, k5y;
+        box_muller<NZ>(w[0][2], w[0][3], k2x, k2y);
+        box_muller<NZ>(w[1][0], w[1][1], k3x, k3y);
+        box_muller<NZ>(w[1][2], w[1][3], k4x, k4y);
+        box_muller<NZ>(w[2][0], w[2][1], k5x, k5y);
+        float bx = kB2f * k2x, by = kB2f * k2y;
+        bx = __builtin_fmaf(kB3f, k3x, bx); by = __builtin_fmaf(kB3f, k3y, by);
+        bx = __builtin_fmaf(kB4f, k4x, bx); by = __builtin_fmaf(kB4f, k4y, by);
+        bx = __builtin_fmaf(kB5f, k5x, bx); by = __builtin_fmaf(kB5f, k5y, by);
+        float ex = kE2f * k2x, ey = kE2f * k2y;
+        ex = __builtin_fmaf(kE3f, k3x, ex); ey = __builtin_fmaf(kE3f, k3y, ey);
+        ex = __builtin_fmaf(kE4f, k4x, ex); ey = __builtin_fmaf(kE4f, k4y, ey);
+        ex = __builtin_fmaf(kE5f, k5x, ex); ey = __builtin_fmaf(kE5f, k5y, ey);
+        A.nbx = P.sigma * (double)bx; A.nby = P.sigma * (double)by;
+        A.ex32 = ex; A.ey32 = ey;
+        A.nex = A.ney = 0.0; A.z6a = A.z6x = A.z6y = 0.f;
+        A.w6a = w[2][2]; A.w6b = w[2][3];
+        A.lazy6 = true;
         return A;
     } else {
+        A.ex32 = A.ey32 = 0.f; A.w6a = A.w6b = 0u; A.lazy6 = false;
         // Draw order inside the block (= the reference's: stages K1..K5, then f_new = K6):
         //   nominal     K_i <- normals (2(i-1), 2(i-1)+1) = (z_x, z_y)
         //   mismatched  K_i <- normals (3(i-1) .. 3(i-1)+2) = (z_a, z_x, z_y)
@@ -515,6 +578,18 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
     }
 }
 
+// |z| of this generator never exceeds sqrt(-2 ln 2^-33) = 6.763 (u >= 2^-33); bound with margin
+constexpr double kZmaxE6 = 6.78 * (1.0 / 40);  // Zmax * E6
+
+// evaluate K6's Box-Muller pair and complete the error sums (same fp32 chain as the eager form: E6 is its last term)
+template <int NZ>
+__device__ __forceinline__ void finish_k6(const KParams& P, AttemptNoise& A) {
+    box_muller<NZ>(A.w6a, A.w6b, A.z6x, A.z6y);
+    A.nex = P.sigma * (double)__builtin_fmaf(kE6f, A.z6x, A.ex32);
+    A.ney = P.sigma * (double)__builtin_fmaf(kE6f, A.z6y, A.ey32);
+    A.lazy6 = false;
+}
+
 struct SubStep {
     double tau, h_abs;
     uint32_t attempt;
@@ -531,28 +606,43 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
     if (tn > P.dt) tn = P.dt;
     const double h = tn - S.tau;
     S.h_abs = h;
-    const AttemptNoise A = attempt_noise<NZ, MIS, FIRST>(P, C, R, S.attempt, d0);
+    AttemptNoise A = attempt_noise<NZ, MIS, FIRST>(P, C, R, S.attempt, d0);
     S.attempt += 1;
     const double dfx = f0x - C.vx, dfy = f0y - C.vy;
     double sx = __builtin_fma(kB0, dfx, C.vx), sy = __builtin_fma(kB0, dfy, C.vy);
-    double ex = kE0 * dfx, ey = kE0 * dfy;
-    if constexpr (NZ != kNoNoise) {
-        sx += A.nbx; sy += A.nby;
-        ex += A.nex; ey += A.ney;
-    }
+    if constexpr (NZ != kNoNoise) { sx += A.nbx; sy += A.nby; }
     const double xn = __builtin_fma(h, sx, x);
     const double yn = __builtin_fma(h, sy, y);
-    ex *= h; ey *= h;
     const double sc0 = __builtin_fma(fmax(__builtin_fabs(x), __builtin_fabs(xn)), P.rtol, P.atol);
     const double sc1 = __builtin_fma(fmax(__builtin_fabs(y), __builtin_fabs(yn)), P.rtol, P.atol);
     const bool last = !(tn < P.dt);
+    const double s00 = sc0 * sc0, s11 = sc1 * sc1;
+    const double lim = 2.0 * s00 * s11;
+    bool accepted = false, decided = false;
+    if constexpr (NZ != kNoNoise) {
+        if (A.lazy6) {
+            // K6 (= f_new) only enters the error estimate (weight E6) and, when another sub-step follows, the
+            // next K0.  On the last sub-step, bound its contribution by |z| <= Zmax: if even the worst case
+            // passes the accept test, the outcome is the eager one and K6's Box-Muller pair is never evaluated.
+            if (last) {
+                const double b6 = h * (P.sigma * kZmaxE6);
+                const double axw = __builtin_fabs(h * __builtin_fma(P.sigma, (double)A.ex32, kE0 * dfx)) + b6;
+                const double ayw = __builtin_fabs(h * __builtin_fma(P.sigma, (double)A.ey32, kE0 * dfy)) + b6;
+                if (__builtin_expect(__builtin_fma(axw * axw, s11, (ayw * ayw) * s00) < 0.98 * lim, 1)) {
+                    accepted = true; decided = true;
+                }
+            }
+            if (!decided) finish_k6<NZ>(P, A);
+        }
+    }
+    double ex = kE0 * dfx, ey = kE0 * dfy;
+    if constexpr (NZ != kNoNoise) { ex += A.nex; ey += A.ney; }
+    ex *= h; ey *= h;
     // fast accept (no division / sqrt / pow): error_norm^2 = q / lim, 2 % margin; the step-size
     // factor is only needed when another sub-step follows.
-    const double s00 = sc0 * sc0, s11 = sc1 * sc1;
     const double q = __builtin_fma(ex * ex, s11, (ey * ey) * s00);
-    const double lim = 2.0 * s00 * s11;
-    bool accepted;
-    if (__builtin_expect(last && q < 0.98 * lim, 1)) {
+    if (decided) {
+    } else if (__builtin_expect(last && q < 0.98 * lim, 1)) {
         accepted = true;
     } else {
         const double error_norm = rms2(ex / sc0, ey / sc1);
@@ -792,7 +882,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     if constexpr (RK45) {
         rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, &W.w[0][0]);      // MR_simulator.py:42-45
         rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy,  // :46-50
-                                SW::NCTOR > 0 ? &W.w[SW::NDYN] : nullptr);
+                                SW::NCTOR > 0 ? &W.w[SW::NDYN] : nullptr, (fl & kFOutStatePrime) != 0);
     } else {
         fixed_integrate<NZ, MIS>(P, C, R, e.x, e.y, spx, spy);
         e.f0x = spx; e.f0y = spy; e.h_abs = P.dt;
