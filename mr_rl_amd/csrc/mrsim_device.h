@@ -393,6 +393,16 @@ __device__ __forceinline__ void noise_vec(const KParams& P, const RhsCtx<MIS>& C
     }
 }
 
+// progress of the sub-step loop of one env step (+ what the constructor needs from its last attempt)
+struct SubStep {
+    double tau, h_abs;
+    uint32_t attempt;
+    bool rejected;
+    // nominal law: F0 / F1 words of the last accepted attempt's block (see attempt_noise)
+    uint32_t last_attempt, f0a, f0b, w3[4];
+    bool have3;
+};
+
 // ---------------------------------------------------------------------------
 // RungeKutta.__init__ + select_initial_step: what Simulator.step does after integrating
 // (MR_simulator.py:46-50) and what reset_start_pos does (:31-34).  Two RHS evaluations:
@@ -402,25 +412,30 @@ template <int NZ, bool MIS>
 __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, uint32_t stream,
                                                double x, double y, double& f0x, double& f0y, double& h_abs,
                                                double& spx, double& spy, const uint32_t (*cw)[4] = nullptr,
-                                               bool need_f1 = true) {
+                                               bool need_f1 = true, SubStep* LS = nullptr) {
     double n0x = 0.0, n0y = 0.0, n1x = 0.0, n1y = 0.0;
     bool have1 = true;
+    // nominal law after a step (LS != nullptr): F0 = words 2,3 of call 2 of the last attempt's block, F1 =
+    // words 2,3 of its call 3; F1 (and with it call 3) is only evaluated when Simulator.state_prime is wanted
+    // or when the bound below cannot certify h_abs == interval
+    auto eval_f1 = [&]() {
+        if constexpr (NZ != kNoNoise && !MIS) {
+            if (!LS->have3) { philox_call(R, c0_of(kStreamDyn, LS->last_attempt, 3), LS->w3); LS->have3 = true; }
+            float z2, z3;
+            box_muller<NZ>(LS->w3[2], LS->w3[3], z2, z3);
+            noise_vec<MIS>(P, C, 0.f, z2, z3, n1x, n1y);
+        }
+    };
     if constexpr (NZ != kNoNoise && !MIS) {
-        if (cw != nullptr) {
-            // nominal law on the hot path: f0 <- pair 0 of the call; f1's pair is only evaluated when
-            // Simulator.state_prime is wanted or when the bound below cannot certify h_abs == interval
+        if (LS != nullptr) {
             float z0, z1;
-            box_muller<NZ>(cw[0][0], cw[0][1], z0, z1);
+            box_muller<NZ>(LS->f0a, LS->f0b, z0, z1);
             noise_vec<MIS>(P, C, 0.f, z0, z1, n0x, n0y);
             have1 = need_f1;
-            if (have1) {
-                float z2, z3;
-                box_muller<NZ>(cw[0][2], cw[0][3], z2, z3);
-                noise_vec<MIS>(P, C, 0.f, z2, z3, n1x, n1y);
-            }
+            if (have1) eval_f1();
         }
     }
-    if constexpr (NZ != kNoNoise) if (MIS || cw == nullptr) {
+    if constexpr (NZ != kNoNoise) if (MIS || LS == nullptr) {
         constexpr int NC = MIS ? 2 : 1;
         float z[NC * 4];
         if (cw != nullptr) normals_from_words<NZ, NC>(cw, z);  // words drawn up front by step_prologue
@@ -460,12 +475,8 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
                 h_abs = P.dt;  // same outcome as with f1 evaluated: every admissible f1 passes the test
                 return;
             }
-            if constexpr (NZ != kNoNoise && !MIS) {  // the bound cannot decide: evaluate f1 after all
-                float z2, z3;
-                box_muller<NZ>(cw[0][2], cw[0][3], z2, z3);
-                noise_vec<MIS>(P, C, 0.f, z2, z3, n1x, n1y);
-                spx = C.vx + n1x; spy = C.vy + n1y;
-            }
+            eval_f1();  // the bound cannot decide: evaluate F1 after all
+            spx = C.vx + n1x; spy = C.vy + n1y;
         }
         const float e0 = (float)(n1x - n0x) * r0, e1 = (float)(n1y - n0y) * r1;
         const float DD = __builtin_fmaf(e0, e0, e1 * e1);
@@ -503,8 +514,11 @@ struct AttemptNoise {
     // lazy K6 (nominal law, first attempt): error sums WITHOUT the E6*z6 term and the two Philox words of
     // K6's Box-Muller pair; nex/ney/z6* are filled by finish_k6() only if the bound test cannot decide
     float ex32, ey32;
-    uint32_t w6a, w6b;
     bool lazy6;
+    // nominal-law block layout (see oracle/mrsim_oracle.c): call 2 = [K5 | F0], call 3 = [K6 | F1]
+    uint32_t f0a, f0b;   // F0's two words (call 2, words 2 and 3)
+    uint32_t w3[4];      // call 3, valid when have3
+    bool have3;
 };
 
 template <int NZ, bool MIS, bool FIRST>
@@ -514,12 +528,28 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
     if constexpr (NZ == kNoNoise) {
         A.nbx = A.nby = A.nex = A.ney = 0.0;
         A.z6a = A.z6x = A.z6y = 0.f;
-        A.ex32 = A.ey32 = 0.f; A.w6a = A.w6b = 0u; A.lazy6 = false;
+        A.ex32 = A.ey32 = 0.f; A.lazy6 = false;
+        A.f0a = A.f0b = 0u; A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u; A.have3 = false;
         return A;
-    } else if constexpr (!MIS && FIRST) {
-        // nominal law, first attempt, words already drawn: K1 = call 0 pair 0 (dead), K2 = call 0 pair 1,
-        // K3, K4 = call 1, K5 = call 2 pair 0, K6 = call 2 pair 1 (left as words: see finish_k6)
-        const uint32_t (*w)[4] = reinterpret_cast<const uint32_t (*)[4]>(d0);
+    } else if constexpr (!MIS) {
+        // nominal law: call 0 = [K1 (dead) | K2], call 1 = [K3 | K4], call 2 = [K5 | F0], call 3 = [K6 | F1].
+        // First attempt: calls 0..2 were drawn up front (d0) and call 3 is fetched only if K6 or F1 is ever
+        // needed (finish_k6 / rk45_construct).  Later attempts (rare) draw all four calls here.
+        uint32_t wl[4][4];
+        const uint32_t (*w)[4];
+        if constexpr (FIRST) {
+            w = reinterpret_cast<const uint32_t (*)[4]>(d0);
+            A.have3 = false;
+            A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u;
+        } else {
+            const uint32_t c0s[4] = {c0_of(kStreamDyn, attempt, 0), c0_of(kStreamDyn, attempt, 1),
+                                     c0_of(kStreamDyn, attempt, 2), c0_of(kStreamDyn, attempt, 3)};
+            philox_multi<4>(R, c0s, wl);
+            w = wl;
+            A.have3 = true;
+            A.w3[0] = wl[3][0]; A.w3[1] = wl[3][1]; A.w3[2] = wl[3][2]; A.w3[3] = wl[3][3];
+        }
+        A.f0a = w[2][2]; A.f0b = w[2][3];
         float k2x, k2y, k3x, k3y, k4x, k4y, k5x, k5y;
         box_muller<NZ>(w[0][2], w[0][3], k2x, k2y);
         box_muller<NZ>(w[1][0], w[1][1], k3x, k3y);
@@ -536,11 +566,11 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         A.nbx = P.sigma * (double)bx; A.nby = P.sigma * (double)by;
         A.ex32 = ex; A.ey32 = ey;
         A.nex = A.ney = 0.0; A.z6a = A.z6x = A.z6y = 0.f;
-        A.w6a = w[2][2]; A.w6b = w[2][3];
         A.lazy6 = true;
         return A;
     } else {
-        A.ex32 = A.ey32 = 0.f; A.w6a = A.w6b = 0u; A.lazy6 = false;
+        A.ex32 = A.ey32 = 0.f; A.lazy6 = false;
+        A.f0a = A.f0b = 0u; A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u; A.have3 = false;
         // Draw order inside the block (= the reference's: stages K1..K5, then f_new = K6):
         //   nominal     K_i <- normals (2(i-1), 2(i-1)+1) = (z_x, z_y)
         //   mismatched  K_i <- normals (3(i-1) .. 3(i-1)+2) = (z_a, z_x, z_y)
@@ -583,18 +613,14 @@ constexpr double kZmaxE6 = 6.78 * (1.0 / 40);  // Zmax * E6
 
 // evaluate K6's Box-Muller pair and complete the error sums (same fp32 chain as the eager form: E6 is its last term)
 template <int NZ>
-__device__ __forceinline__ void finish_k6(const KParams& P, AttemptNoise& A) {
-    box_muller<NZ>(A.w6a, A.w6b, A.z6x, A.z6y);
+__device__ __forceinline__ void finish_k6(const KParams& P, const Rng& R, uint32_t attempt, AttemptNoise& A) {
+    if (!A.have3) { philox_call(R, c0_of(kStreamDyn, attempt, 3), A.w3); A.have3 = true; }
+    box_muller<NZ>(A.w3[0], A.w3[1], A.z6x, A.z6y);
     A.nex = P.sigma * (double)__builtin_fmaf(kE6f, A.z6x, A.ex32);
     A.ney = P.sigma * (double)__builtin_fmaf(kE6f, A.z6y, A.ey32);
     A.lazy6 = false;
 }
 
-struct SubStep {
-    double tau, h_abs;
-    uint32_t attempt;
-    bool rejected;
-};
 
 // one rk_step attempt + the accept / reject decision of _step_impl.  Returns true when the
 // attempt was accepted (state advanced to tau = tn).
@@ -632,7 +658,7 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
                     accepted = true; decided = true;
                 }
             }
-            if (!decided) finish_k6<NZ>(P, A);
+            if (!decided) finish_k6<NZ>(P, R, S.attempt - 1, A);
         }
     }
     double ex = kE0 * dfx, ey = kE0 * dfy;
@@ -665,6 +691,10 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
     }
     if (accepted) {
         S.tau = tn; x = xn; y = yn;
+        if constexpr (NZ != kNoNoise && !MIS) {
+            S.last_attempt = S.attempt - 1; S.f0a = A.f0a; S.f0b = A.f0b; S.have3 = A.have3;
+            S.w3[0] = A.w3[0]; S.w3[1] = A.w3[1]; S.w3[2] = A.w3[2]; S.w3[3] = A.w3[3];
+        }
         if (!last) {  // f = f_new = K[6]; after the last sub-step the constructor replaces f anyway
             double n6x = 0.0, n6y = 0.0;
             if constexpr (NZ != kNoNoise) noise_vec<MIS>(P, C, A.z6a, A.z6x, A.z6y, n6x, n6y);
@@ -676,10 +706,12 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
 }
 
 template <int NZ, bool MIS>
-__device__ __forceinline__ void rk45_integrate(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, double& x,
-                                               double& y, double f0x, double f0y, double h_abs, int& fail,
-                                               const uint32_t* d0) {
-    SubStep S{0.0, h_abs, 0u, false};
+__device__ __forceinline__ SubStep rk45_integrate(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, double& x,
+                                                  double& y, double f0x, double f0y, double h_abs, int& fail,
+                                                  const uint32_t* d0) {
+    SubStep S;
+    S.tau = 0.0; S.h_abs = h_abs; S.attempt = 0u; S.rejected = false;
+    S.last_attempt = 0u; S.f0a = S.f0b = 0u; S.w3[0] = S.w3[1] = S.w3[2] = S.w3[3] = 0u; S.have3 = false;
     // first attempt peeled: its RNG counters are wave-uniform (attempt = 0), and in the common
     // regime (|y| >~ 1) it is the only one
     rk45_attempt<NZ, MIS, true>(P, C, R, S, x, y, f0x, f0y, fail, d0);
@@ -687,6 +719,7 @@ __device__ __forceinline__ void rk45_integrate(const KParams& P, const RhsCtx<MI
         rk45_attempt<NZ, MIS, false>(P, C, R, S, x, y, f0x, f0y, fail, nullptr);
         if (S.attempt >= (uint32_t)kMaxAttempts) { fail |= 1; break; }
     }
+    return S;
 }
 
 // Build extension (BASELINE configs 2/3): fixed-step Euler / classical RK4, noise added to the
@@ -841,7 +874,7 @@ __device__ __forceinline__ void action_from_words(const KParams& P, const uint32
 template <bool RK45, int NZ, bool MIS>
 struct StepWords {
     static constexpr int NDYN = (RK45 && NZ != kNoNoise) ? (MIS ? 5 : 3) : 0;
-    static constexpr int NCTOR = (RK45 && NZ != kNoNoise) ? (MIS ? 2 : 1) : 0;
+    static constexpr int NCTOR = (RK45 && NZ != kNoNoise && MIS) ? 2 : 0;  // nominal: F0/F1 live in the DYN block
     static constexpr int N = (NDYN + NCTOR) > 0 ? (NDYN + NCTOR) : 1;
     uint32_t w[N][4];
 };
@@ -880,9 +913,10 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     const RhsCtx<MIS> C = make_ctx<MIS>(P, (double)act_f, (double)act_a);
     double spx = 0.0, spy = 0.0;
     if constexpr (RK45) {
-        rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, &W.w[0][0]);      // MR_simulator.py:42-45
-        rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy,  // :46-50
-                                SW::NCTOR > 0 ? &W.w[SW::NDYN] : nullptr, (fl & kFOutStatePrime) != 0);
+        SubStep LS = rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, &W.w[0][0]);  // MR_simulator.py:42-45
+        rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy,           // :46-50
+                                SW::NCTOR > 0 ? &W.w[SW::NDYN] : nullptr, (fl & kFOutStatePrime) != 0,
+                                (NZ != kNoNoise && !MIS) ? &LS : nullptr);
     } else {
         fixed_integrate<NZ, MIS>(P, C, R, e.x, e.y, spx, spy);
         e.f0x = spx; e.f0y = spy; e.h_abs = P.dt;

@@ -176,12 +176,16 @@ typedef struct {
     uint32_t env_id;
     uint32_t base; /* C0(stream, block, 0) */
     int pos;
+    int cached_call; /* call whose 4 normals are in z[], -1 = none */
     float z[4];
 } NStream;
 
 static void ns_open(NStream* s, OrcNoise* nz, uint32_t env_id, int stream, uint32_t block) {
-    s->nz = nz; s->env_id = env_id; s->base = C0(stream, block, 0); s->pos = 0;
+    s->nz = nz; s->env_id = env_id; s->base = C0(stream, block, 0); s->pos = 0; s->cached_call = -1;
 }
+
+/* jump to draw index `pos` of the block (PHILOX source only; a tape is always consumed in order) */
+static void ns_seek(NStream* s, int pos) { s->pos = pos; }
 
 /* numpy.random.normal(0, scale, 1)[0] == 0 + scale * z   (MR_simulator.py:56,79-83) */
 static double ns_normal(NStream* s, double scale) {
@@ -191,8 +195,10 @@ static double ns_normal(NStream* s, double scale) {
         return nz->tape[nz->tape_pos++]; /* already loc + scale*z */
     }
     if (nz->kind == ORC_NOISE_NONE || scale == 0.0) { s->pos++; return 0.0; }
-    if ((s->pos & 3) == 0)
-        orc_normals4(nz->seed, s->env_id, nz->step_idx, s->base | (uint32_t)(s->pos >> 2), s->z);
+    if ((s->pos >> 2) != s->cached_call) {
+        s->cached_call = s->pos >> 2;
+        orc_normals4(nz->seed, s->env_id, nz->step_idx, s->base | (uint32_t)s->cached_call, s->z);
+    }
     double z = (double)s->z[s->pos & 3];
     s->pos++;
     return scale * z;
@@ -237,12 +243,27 @@ static const double RK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 172
 
 /* RungeKutta.__init__ (rk.py) as run by Simulator.scipy_runge_kutta (MR_simulator.py:90-91):
  *   self.f = fun(t0, y0); self.h_abs = select_initial_step(...)  (common.py)          */
+/* Where the Philox-sourced draws of an RK45 env step live (layout chosen so that the GPU needs three
+ * Philox calls per step in the common case; a tape replay ignores it and consumes draws in order).
+ *   NOMINAL law (2 draws per RHS evaluation), block = DYN(attempt a), draw index = 4*call + lane:
+ *     call 0: [K1 (never reaches a result; for a = 0 its two WORDS carry the exploration policy) | K2]
+ *     call 1: [K3 | K4]        call 2: [K5 | F0]        call 3: [K6 | F1]
+ *   F0, F1 = the two RHS evaluations of the constructor that runs after the step's LAST attempt; they are
+ *   taken from that attempt's block.  K6 (= f_new) and F1 rarely influence a result (K6: only the error
+ *   estimate and the next sub-step's K0; F1: only d2 and Simulator.state_prime).
+ *   MISMATCHED law (3 draws per evaluation): K1..K6 sequential in DYN(attempt), constructor sequential in
+ *   CTOR(0).  Reset constructors: sequential in RESET_CTOR(0) for both laws. */
+#define NOM_POS_K6 12
+#define NOM_POS_F0 10
+#define NOM_POS_F1 14
+
 static void rk45_construct(const OrcParams* p, int mismatched, OrcEnv* e, const double act[2], OrcNoise* nz,
-                           uint32_t env_id, int stream) {
+                           uint32_t env_id, int stream, uint32_t block, int pos_f0, int pos_f1) {
     NStream ns;
-    ns_open(&ns, nz, env_id, stream, 0);
+    ns_open(&ns, nz, env_id, stream, block);
     const double t0 = e->t, t_bound = e->t + p->time_span;
     double f0[2], f1[2];
+    if (pos_f0 >= 0) ns_seek(&ns, pos_f0);
     simulate(p, mismatched, e, act, &ns, f0);
     e->f[0] = f0[0]; e->f[1] = f0[1];
     /* select_initial_step(fun, t0, y0, t_bound, max_step=inf, f0, direction=1, order=4, rtol, atol) */
@@ -254,6 +275,7 @@ static void rk45_construct(const OrcParams* p, int mismatched, OrcEnv* e, const 
     double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
     h0 = fmin(h0, interval_length);
     /* y1 = y0 + h0*f0 is formed and passed to fun, which ignores it */
+    if (pos_f1 >= 0) ns_seek(&ns, pos_f1);
     simulate(p, mismatched, e, act, &ns, f1);
     const double d2 = rms2((f1[0] - f0[0]) / sc0, (f1[1] - f0[1]) / sc1) / h0;
     double h1;
@@ -269,7 +291,7 @@ void orc_sim_reset(const OrcParams* p, OrcEnv* e, double x0, double y0, int ctor
     e->t = 0.0;                           /* scipy_runge_kutta default t0 = 0, :90 */
     const double zero[2] = {0.0, 0.0};    /* :30 */
     e->n_rhs = 0; e->n_attempts = 0; e->status = 0;
-    rk45_construct(p, ctor_mismatched, e, zero, nz, env_id, ctor_stream ? ctor_stream : STREAM_RESET_CTOR);
+    rk45_construct(p, ctor_mismatched, e, zero, nz, env_id, ctor_stream ? ctor_stream : STREAM_RESET_CTOR, 0, -1, -1);
 }
 
 /* Simulator.step.  MR_simulator.py:36-52 */
@@ -337,6 +359,7 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
             for (int i = 0; i < 6; ++i) { s0 += K[i][0] * RK_B[i]; s1 += K[i][1] * RK_B[i]; }
             yn0 = y0 + h * s0;
             yn1 = y1 + h * s1;
+            if (!mis) ns_seek(&ns, NOM_POS_K6);
             simulate(p, mis, e, act, &ns, fn);
             K[6][0] = fn[0]; K[6][1] = fn[1];
             attempt++; e->n_attempts++;
@@ -363,7 +386,8 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
         if (e->t - t_bound >= 0) break; /* status = 'finished' */
     }
     /* last_state = integrator.y (:45); new RK45 from (t, y) to t + time_span (:46-50) */
-    rk45_construct(p, mis, e, act, nz, env_id, STREAM_CTOR);
+    if (mis) rk45_construct(p, mis, e, act, nz, env_id, STREAM_CTOR, 0, -1, -1);
+    else rk45_construct(p, mis, e, act, nz, env_id, STREAM_DYN, attempt ? attempt - 1 : 0, NOM_POS_F0, NOM_POS_F1);
     return 0;
 }
 
