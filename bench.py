@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-samples", type=int, default=0, help="0 = auto")
+    ap.add_argument("--workload", choices=["ddpg", "mixed"], default="ddpg",
+                    help="ddpg = BASELINE config 4 (default); mixed = config 5's trajectory set: goal = reference-"
+                         "trajectory table[env_id mod 3] (straight line / figure-eight / random), tracking reward")
     ap.add_argument("--no-step-path", action="store_true", help="skip the extra one-launch-per-step measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -91,7 +94,8 @@ def committed_traffic(args, n_local):
     same command and corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from
     inside the timed process, so this is null unless the run matches the profiled configuration."""
     import glob
-    if not (args.sigma == 1.0 and args.noise_math == "fast" and n_local == 262144 and args.obs_layout == "aos"):
+    if not (args.sigma == 1.0 and args.noise_math == "fast" and n_local == 262144 and args.obs_layout == "aos"
+            and args.workload == "ddpg"):
         return None, None
     key = "mr_rollout_kernel" if args.mode == "rollout" else "mr_step_kernel"
     if args.mode == "rollout" and args.rollout_len != 51:
@@ -175,7 +179,19 @@ def main():
     seed = 7
     cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math,
                    seed=seed)
-    env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0)
+    goal_table = None
+    if args.workload == "mixed":
+        import numpy as np
+        Tg = cfg.max_timesteps + 2
+        k = np.arange(Tg)
+        th = 2 * np.pi * k / Tg
+        tab = np.zeros((3, Tg, 2), dtype=np.float32)
+        tab[0, :, 0] = 110 + 0.3 * k; tab[0, :, 1] = 110 + 0.3 * k                           # straight line
+        tab[1, :, 0] = 110 + 8 * np.sin(th); tab[1, :, 1] = 110 + 8 * np.sin(th) * np.cos(th)  # figure eight
+        tab[2] = np.random.default_rng(seed).uniform(100, 120, (Tg, 2))                        # random waypoints
+        goal_table = tab
+        cfg.reward_mode, cfg.min_dist2goal = "goal", 1.0
+    env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0, goal_table=goal_table)
     env.reset()
     gatherer = ReturnGatherer(env, world)
     K, W = args.steps, args.warmup
@@ -279,7 +295,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, seed, args.cpu_seconds)
     step_path = None
-    if rank == 0 and world == 1 and args.mode == "rollout" and not args.no_step_path:
+    if rank == 0 and world == 1 and args.mode == "rollout" and not args.no_step_path and args.workload == "ddpg":
         step_path = measure_step_path(cfg, n_local, dev, seed)
 
     if world > 1:
@@ -289,7 +305,7 @@ def main():
         config = {"workload": "BASELINE config 4: DDPG rollout, uniform random policy in the actor range drawn on "
                               "device, sigma=%g, integrator=reference(RK45), reward+done on device, auto-reset, all "
                               "transitions written to HBM" % args.sigma,
-                  "mode": args.mode, "envs_per_gpu": n_local, "total_envs": total, "obs_layout": args.obs_layout,
+                  "trajectory_set": args.workload, "mode": args.mode, "envs_per_gpu": n_local, "total_envs": total, "obs_layout": args.obs_layout,
                   "noise_math": args.noise_math, "sigma": args.sigma, "seed": seed,
                   "mean_episode_return": mean_ret,
                   "returns_allgather": "rccl every 51 steps" if world > 1 else "local"}

@@ -88,3 +88,35 @@ def test_argument_validation():
     p.integrator = 7
     assert L.mrsim_step(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EINVAL
     assert "align" in _lib.strerror(_lib.EALIGN)
+
+
+def test_rollout_and_velocity_argument_validation():
+    from mr_rl_amd import _lib
+    L = _lib.lib()
+    p = _lib.default_params()
+    buf = np.zeros(256, dtype=np.float64)
+    st = _lib.MrsimState(buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)
+    io = _lib.MrsimRolloutIO(-1, 0, None, None, None, None, None, None, None, None, None, None, None)
+    assert L.mrsim_rollout(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EINVAL      # T < 0
+    io.T = 0
+    assert L.mrsim_rollout(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.OK          # T == 0: no-op
+    assert L.mrsim_rollout(C.byref(p), 4, 0, C.byref(st), None, 0, 0, None) == _lib.EINVAL
+    io.T = 3
+    io.traj_xy = buf.ctypes.data + 8
+    assert L.mrsim_rollout(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EALIGN
+    io.traj_xy = None
+    io.goal_table = buf.ctypes.data
+    p.goal_K = 0
+    assert L.mrsim_rollout(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EINVAL      # table without K/T
+    p = _lib.default_params()
+    p.noise_math = 9
+    io.goal_table = None
+    assert L.mrsim_rollout(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EINVAL
+    p = _lib.default_params()
+    p.sigma = -1.0
+    assert L.mrsim_rollout(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EINVAL
+    d = buf.ctypes.data
+    assert L.mrsim_velocity(4, 0, 14, d, d, d, d, None, None) == _lib.EINVAL                            # T < 1
+    assert L.mrsim_velocity(4, 8, 14, None, d, d, d, None, None) == _lib.EINVAL
+    assert L.mrsim_velocity(4, 8, 14, d + 8, d, d, d, None, None) == _lib.EALIGN
+    assert L.mrsim_advance_step_base(None, 1, None) == _lib.EINVAL
