@@ -139,6 +139,28 @@ def measure_step_path(cfg, n_local, dev, seed, steps=510, samples=102):
             "roofline_frac": round(ach / HBM_PEAK_GBS, 4)}
 
 
+def trajectory_rmse(dev):
+    """Second half of BASELINE's metric: trajectory RMSE vs the CPU reference, on the committed golden trajectories
+    the reference itself produced (tests/golden/ref_sim.npz, sigma = 0, 1000-2000 steps each), through the same
+    fused kernel the timed region runs."""
+    import numpy as np
+    from mr_rl_amd import MRConfig, MRVecEnv
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_sim.npz"))
+    names = sorted({k.split("/")[0] for k in g.files})
+    worst, per = 0.0, {}
+    for name in names:
+        G = {k.split("/")[1]: g[k] for k in g.files if k.startswith(name + "/")}
+        env = MRVecEnv(64, cfg=MRConfig(noise_var=0.0, a0=float(G["a0"]), is_mismatched=bool(G["mismatched"])), device=dev)
+        env._prev_mismatched = bool(G["mismatch_at_reset"])
+        env.reset(init=np.tile(G["init"][None, :], (64, 1)), is_mismatched=bool(G["mismatched"]))
+        traj = env.rollout(len(G["actions"]), actions=G["actions"].astype(np.float32), shared_actions=True,
+                           want=("traj",))["traj"][:, 0, :].cpu().numpy()
+        per[name] = float(np.sqrt(np.mean(np.sum((traj - G["pos"]) ** 2, axis=1))))
+        worst = max(worst, per[name])
+    return {"value": worst, "unit": "position units (max over %d golden trajectories)" % len(names), "target": 1e-5,
+            "fixtures": "tests/golden/ref_sim.npz"}
+
+
 def main():
     args = parse()
     lib_so = os.path.join(ROOT, "mr_rl_amd", "libmrsim.so")
@@ -294,6 +316,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, seed, args.cpu_seconds)
+    rmse = trajectory_rmse(dev) if rank == 0 and world == 1 else None
     step_path = None
     if rank == 0 and world == 1 and args.mode == "rollout" and not args.no_step_path and args.workload == "ddpg":
         step_path = measure_step_path(cfg, n_local, dev, seed)
@@ -310,10 +333,12 @@ def main():
                   "mean_episode_return": mean_ret,
                   "returns_allgather": "rccl every 51 steps" if world > 1 else "local"}
         config.update(launch_desc)
-        out = {"metric": "env-steps/sec at N parallel envs", "value": value, "unit": "env-steps/s",
+        out = {"metric": "env-steps/sec at N parallel envs; trajectory RMSE vs CPU ref", "value": value, "unit": "env-steps/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic", "config": config, "roofline": roof, "cpu_baseline": cpu}
+        if rmse is not None:
+            out["trajectory_rmse_vs_cpu_ref"] = rmse
         if step_path is not None:
             out["step_path"] = step_path
         print(json.dumps(out), flush=True)
