@@ -18,6 +18,13 @@
  *     a shard [env_id0, env_id0+n) produces the same trajectories on any rank.
  *   - there is NO CPU fallback: without a HIP device every compute entry point
  *     returns MRSIM_ENODEVICE.
+ *
+ * seed / step_idx contract.  All randomness (noise at every RHS evaluation, sampled start
+ * positions, the exploration policy) is a pure function of (seed, GLOBAL env id, step_idx) through
+ * Philox4x32-10 (definition: DESIGN.md section 5, oracle/mrsim_oracle.c).  The caller owns the step
+ * counter: pass a fresh step_idx to every mrsim_reset / mrsim_step call (mrsim_rollout consumes
+ * step_idx0 .. step_idx0 + T - 1); passing the same (seed, step_idx) again reproduces the same draws.
+ * MrsimParams.step_base lets that counter live in device memory for hipGraph replay.
  */
 #ifndef MRSIM_H
 #define MRSIM_H
