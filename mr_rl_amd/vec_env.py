@@ -201,6 +201,12 @@ class MRVecEnv:
         self.step_idx += 1
         return self.obs
 
+    def _step_io(self, act_t):
+        return _lib.MrsimStepIO(
+            self._p(act_t), self._p(self._actions_out), self._p(self.goal_table), self._p(self._obs),
+            self._p(self.rew), self._p(self._done_u8), self._p(self._state_prime), self._p(self._final_obs),
+            self._p(self.final_ret), self._p(self.final_len), self._p(self.status))
+
     def step(self, actions=None):
         """MR_Env.step for all envs.  actions: [N,2] float32 device tensor {f_t, alpha_t}, or None to
         draw the uniform random policy in-kernel (cfg.policy_low/high)."""
@@ -215,10 +221,7 @@ class MRVecEnv:
             self.last_action = act_t
         elif self._actions_out is not None:
             self.last_action = self._actions_out
-        io = _lib.MrsimStepIO(
-            self._p(act_t), self._p(self._actions_out), self._p(self.goal_table), self._p(self._obs),
-            self._p(self.rew), self._p(self._done_u8), self._p(self._state_prime), self._p(self._final_obs),
-            self._p(self.final_ret), self._p(self.final_len), self._p(self.status))
+        io = self._step_io(act_t)
         rc = self._L.mrsim_step(C.byref(self._params), self.num_envs, self.env_id0, C.byref(self._st), C.byref(io),
                                 self.seed_value, self.step_idx, self._stream())
         _lib.check(rc, "mrsim_step")
@@ -233,10 +236,7 @@ class MRVecEnv:
         Measurement aid for bench.py; synchronises the stream."""
         torch = _torch()
         act_t = None if actions is None else torch.as_tensor(actions, dtype=torch.float32, device=self.device).contiguous()
-        io = _lib.MrsimStepIO(
-            self._p(act_t), self._p(self._actions_out), self._p(self.goal_table), self._p(self._obs),
-            self._p(self.rew), self._p(self._done_u8), self._p(self._state_prime), self._p(self._final_obs),
-            self._p(self.final_ret), self._p(self.final_len), self._p(self.status))
+        io = self._step_io(act_t)
         ms = C.c_float(0.0)
         rc = self._L.mrsim_step_timed(C.byref(self._params), self.num_envs, self.env_id0, C.byref(self._st),
                                       C.byref(io), self.seed_value, self.step_idx, self._stream(), C.byref(ms))
