@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--obs-layout", choices=["aos", "soa"], default="aos")
     ap.add_argument("--noise-math", choices=["fast", "spec"], default="fast")
     ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--mismatched", action="store_true", help="non-default: the reference's is_mismatched=True law")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-samples", type=int, default=0, help="0 = auto")
@@ -200,7 +201,7 @@ def main():
     env_id0, _ = shard_of(total, rank, world)
     seed = 7
     cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math,
-                   seed=seed)
+                   seed=seed, is_mismatched=args.mismatched)
     goal_table = None
     if args.workload == "mixed":
         import numpy as np
@@ -297,13 +298,15 @@ def main():
             ns = args.kernel_samples or 10
             ms = sorted(env.rollout(T, actions=None, want=WANT, out=bufs, timed=True)["kernel_ms"] for _ in range(ns))
             units = n_local * T
-            kname = "mr_rollout_kernel<RK45,%s,nominal>" % ("nonoise" if args.sigma == 0 else args.noise_math)
+            law = "mismatched" if args.mismatched else "nominal"
+            kname = "mr_rollout_kernel<RK45,%s,%s>" % ("nonoise" if args.sigma == 0 else args.noise_math, law)
         else:
             ns = args.kernel_samples or 102
             ms = sorted(env.step_timed(env.random_policy(out=act) if args.policy == "kernel" else None)
                         for _ in range(ns))
             units = n_local
-            kname = "mr_step_kernel<RK45,%s,nominal,%s>" % ("nonoise" if args.sigma == 0 else args.noise_math,
+            law = "mismatched" if args.mismatched else "nominal"
+            kname = "mr_step_kernel<RK45,%s,%s,%s>" % ("nonoise" if args.sigma == 0 else args.noise_math, law,
                                                             args.obs_layout)
         avg_ms = sum(ms) / len(ms)
         ach = units * ALGO_BYTES_PER_ENV_STEP / (avg_ms * 1e-3) / 1e9
@@ -330,6 +333,7 @@ def main():
                               "transitions written to HBM" % args.sigma,
                   "trajectory_set": args.workload, "mode": args.mode, "envs_per_gpu": n_local, "total_envs": total, "obs_layout": args.obs_layout,
                   "noise_math": args.noise_math, "sigma": args.sigma, "seed": seed,
+                  "is_mismatched": bool(args.mismatched),
                   "mean_episode_return": mean_ret,
                   "returns_allgather": "rccl every 51 steps" if world > 1 else "local"}
         config.update(launch_desc)

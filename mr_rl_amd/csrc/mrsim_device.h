@@ -352,9 +352,14 @@ __device__ __forceinline__ RhsCtx<MIS> make_ctx(const KParams& P, double f_t, do
     RhsCtx<MIS> C;
     if constexpr (MIS) {
         const double a0b = P.a0 + (f_t / 4) * 0.8;
-        double t0, t1, cA, sB;
-        sincos_f64(al + 0.1, t0, cA);
-        sincos_f64(al - 0.15, sB, t1);
+        // cos(al + 0.1) and sin(al - 0.15) from ONE sincos by the angle-addition formulas (<= 2 ulp from the
+        // direct evaluation; an fp64 sincos costs about as much as a Philox call)
+        constexpr double kC01 = 0.99500416527802577, kS01 = 0.099833416646828152;   // cos, sin of 0.1
+        constexpr double kC015 = 0.98877107793604229, kS015 = 0.14943813247359922;  // cos, sin of 0.15
+        double s, c;
+        sincos_f64(al, s, c);
+        const double cA = __builtin_fma(c, kC01, -(s * kS01));
+        const double sB = __builtin_fma(s, kC015, -(c * kS015));
         const double af = a0b * f_t;
         C.vx = af * cA + 0.2;
         C.vy = af * sB - 0.1;
@@ -398,8 +403,11 @@ struct SubStep {
     double tau, h_abs;
     uint32_t attempt;
     bool rejected;
-    // nominal law: F0 / F1 words of the last accepted attempt's block (see attempt_noise)
+    // F0 / F1 of the last accepted attempt's block (see attempt_noise): (f0a, f0b) = the words of F0's first
+    // Box-Muller pair, f0y = F0's third normal (mismatched law only, already evaluated by the attempt);
+    // w3 = the block's lazily fetched last call (call 3 nominal, call 5 mismatched)
     uint32_t last_attempt, f0a, f0b, w3[4];
+    float f0y;
     bool have3;
 };
 
@@ -411,35 +419,49 @@ struct SubStep {
 template <int NZ, bool MIS>
 __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, uint32_t stream,
                                                double x, double y, double& f0x, double& f0y, double& h_abs,
-                                               double& spx, double& spy, const uint32_t (*cw)[4] = nullptr,
-                                               bool need_f1 = true, SubStep* LS = nullptr) {
+                                               double& spx, double& spy, bool need_f1 = true,
+                                               SubStep* LS = nullptr) {
     double n0x = 0.0, n0y = 0.0, n1x = 0.0, n1y = 0.0;
     bool have1 = true;
-    // nominal law after a step (LS != nullptr): F0 = words 2,3 of call 2 of the last attempt's block, F1 =
-    // words 2,3 of its call 3; F1 (and with it call 3) is only evaluated when Simulator.state_prime is wanted
-    // or when the bound below cannot certify h_abs == interval
+    // After a step (LS != nullptr) F0 and F1 live in the last attempt's block.  Nominal law: F0 = words 2,3 of
+    // call 2, F1 = words 2,3 of call 3.  Mismatched law: F0 = draws 14..16 (call 3 words 2,3 + call 4 words 0,1),
+    // F1 = draws 20..22 (call 5).  F1 (and with it the block's last call) is only evaluated when
+    // Simulator.state_prime is wanted or when the bound below cannot certify h_abs == interval.
     auto eval_f1 = [&]() {
-        if constexpr (NZ != kNoNoise && !MIS) {
-            if (!LS->have3) { philox_call(R, c0_of(kStreamDyn, LS->last_attempt, 3), LS->w3); LS->have3 = true; }
-            float z2, z3;
-            box_muller<NZ>(LS->w3[2], LS->w3[3], z2, z3);
-            noise_vec<MIS>(P, C, 0.f, z2, z3, n1x, n1y);
+        if constexpr (NZ != kNoNoise) {
+            if (!LS->have3) {
+                philox_call(R, c0_of(kStreamDyn, LS->last_attempt, MIS ? 5u : 3u), LS->w3);
+                LS->have3 = true;
+            }
+            if constexpr (MIS) {
+                float za, zx, zy, zs;
+                box_muller<NZ>(LS->w3[0], LS->w3[1], za, zx);
+                box_muller<NZ>(LS->w3[2], LS->w3[3], zy, zs);
+                noise_vec<MIS>(P, C, za, zx, zy, n1x, n1y);
+            } else {
+                float z2, z3;
+                box_muller<NZ>(LS->w3[2], LS->w3[3], z2, z3);
+                noise_vec<MIS>(P, C, 0.f, z2, z3, n1x, n1y);
+            }
         }
     };
-    if constexpr (NZ != kNoNoise && !MIS) {
+    if constexpr (NZ != kNoNoise) {
         if (LS != nullptr) {
             float z0, z1;
             box_muller<NZ>(LS->f0a, LS->f0b, z0, z1);
-            noise_vec<MIS>(P, C, 0.f, z0, z1, n0x, n0y);
+            if constexpr (MIS) {
+                noise_vec<MIS>(P, C, z0, z1, LS->f0y, n0x, n0y);
+            } else {
+                noise_vec<MIS>(P, C, 0.f, z0, z1, n0x, n0y);
+            }
             have1 = need_f1;
             if (have1) eval_f1();
         }
     }
-    if constexpr (NZ != kNoNoise) if (MIS || LS == nullptr) {
+    if constexpr (NZ != kNoNoise) if (LS == nullptr) {  // reset constructor: sequential draws of its own block
         constexpr int NC = MIS ? 2 : 1;
         float z[NC * 4];
-        if (cw != nullptr) normals_from_words<NZ, NC>(cw, z);  // words drawn up front by step_prologue
-        else block_normals<NZ, NC>(R, c0_of(stream, 0, 0), z);
+        block_normals<NZ, NC>(R, c0_of(stream, 0, 0), z);
         if constexpr (MIS) {
             noise_vec<MIS>(P, C, z[0], z[1], z[2], n0x, n0y);
             noise_vec<MIS>(P, C, z[3], z[4], z[5], n1x, n1y);
@@ -467,9 +489,11 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
         const float TH2 = P.h1_thresh2_f;
         const bool fast01 = (D0 > 1e-9f) && (D1 > 1e-9f) && (D0 >= 1.05f * P.dt2_f * D1) && (D1 <= 1.9f * TH2);
         if (!have1) {
-            // f1 not evaluated yet: worst case |n1 - n0| <= |n0| + sigma*Zmax per axis (|z| <= 6.763)
-            const float zb = (float)(P.sigma * 6.78);
-            const float w0 = ((float)__builtin_fabs(n0x) + zb) * r0, w1 = ((float)__builtin_fabs(n0y) + zb) * r1;
+            // f1 not evaluated yet: worst case |n1 - n0| <= |n0| + amp*Zmax per axis (|z| <= 6.763), amp = sigma
+            // (+ |g| in the mismatched law)
+            const float zbx = (float)((MIS ? P.sigma + __builtin_fabs(C.gx) : P.sigma) * 6.78);
+            const float zby = (float)((MIS ? P.sigma + __builtin_fabs(C.gy) : P.sigma) * 6.78);
+            const float w0 = ((float)__builtin_fabs(n0x) + zbx) * r0, w1 = ((float)__builtin_fabs(n0y) + zby) * r1;
             const float DW = __builtin_fmaf(w0, w0, w1 * w1);
             if (__builtin_expect(fast01 && (DW <= 1.9f * TH2 * P.dt2_f) && (DW * D1 <= 1.9e-4f * TH2 * D0), 1)) {
                 h_abs = P.dt;  // same outcome as with f1 evaluated: every admissible f1 passes the test
@@ -513,11 +537,14 @@ struct AttemptNoise {
     float z6a, z6x, z6y;  // f_new's normals; only needed when another sub-step follows
     // lazy K6 (nominal law, first attempt): error sums WITHOUT the E6*z6 term and the two Philox words of
     // K6's Box-Muller pair; nex/ney/z6* are filled by finish_k6() only if the bound test cannot decide
-    float ex32, ey32;
+    float ex32, ey32, ea32;
     bool lazy6;
-    // nominal-law block layout (see oracle/mrsim_oracle.c): call 2 = [K5 | F0], call 3 = [K6 | F1]
-    uint32_t f0a, f0b;   // F0's two words (call 2, words 2 and 3)
-    uint32_t w3[4];      // call 3, valid when have3
+    // block layout (see oracle/mrsim_oracle.c).  nominal: call 2 = [K5 | F0], call 3 = [K6 | F1];
+    // mismatched: call 3 = [K5x K5y | F0a F0x], call 4 = [F0y K6a | K6x K6y], call 5 = [F1a F1x | F1y -]
+    uint32_t f0a, f0b;   // F0's first pair of words
+    float f0y;           // mismatched: F0's third normal (its pair also yields K6a, which is needed eagerly)
+    uint32_t k6a, k6b;   // mismatched: the words of the pair (K6x, K6y)
+    uint32_t w3[4];      // the block's last call (3 nominal / 5 mismatched), valid when have3
     bool have3;
 };
 
@@ -528,8 +555,9 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
     if constexpr (NZ == kNoNoise) {
         A.nbx = A.nby = A.nex = A.ney = 0.0;
         A.z6a = A.z6x = A.z6y = 0.f;
-        A.ex32 = A.ey32 = 0.f; A.lazy6 = false;
-        A.f0a = A.f0b = 0u; A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u; A.have3 = false;
+        A.ex32 = A.ey32 = A.ea32 = 0.f; A.lazy6 = false;
+        A.f0a = A.f0b = A.k6a = A.k6b = 0u; A.f0y = 0.f;
+        A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u; A.have3 = false;
         return A;
     } else if constexpr (!MIS) {
         // nominal law: call 0 = [K1 (dead) | K2], call 1 = [K3 | K4], call 2 = [K5 | F0], call 3 = [K6 | F1].
@@ -550,6 +578,7 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
             A.w3[0] = wl[3][0]; A.w3[1] = wl[3][1]; A.w3[2] = wl[3][2]; A.w3[3] = wl[3][3];
         }
         A.f0a = w[2][2]; A.f0b = w[2][3];
+        A.k6a = A.k6b = 0u; A.f0y = 0.f; A.ea32 = 0.f;
         float k2x, k2y, k3x, k3y, k4x, k4y, k5x, k5y;
         box_muller<NZ>(w[0][2], w[0][3], k2x, k2y);
         box_muller<NZ>(w[1][0], w[1][1], k3x, k3y);
@@ -569,41 +598,49 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         A.lazy6 = true;
         return A;
     } else {
-        A.ex32 = A.ey32 = 0.f; A.lazy6 = false;
-        A.f0a = A.f0b = 0u; A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u; A.have3 = false;
-        // Draw order inside the block (= the reference's: stages K1..K5, then f_new = K6):
-        //   nominal     K_i <- normals (2(i-1), 2(i-1)+1) = (z_x, z_y)
-        //   mismatched  K_i <- normals (3(i-1) .. 3(i-1)+2) = (z_a, z_x, z_y)
-        // K1's draws never reach a result (B1 = E1 = 0).
-        constexpr int NC = MIS ? 5 : 3;
-        float z[NC * 4];
-        // FIRST: attempt 0, whose call 0 (= DYN block 0 call 0) the caller already computed
-        if constexpr (FIRST) normals_from_words<NZ, NC>(reinterpret_cast<const uint32_t (*)[4]>(d0), z);
-        else block_normals<NZ, NC>(R, c0_of(kStreamDyn, attempt, 0), z);
-        constexpr int D = MIS ? 3 : 2;
-        constexpr int O = MIS ? 1 : 0;  // offset of z_x inside an eval's draws
-        const float* k2 = z + D * 1, *k3 = z + D * 2, *k4 = z + D * 3, *k5 = z + D * 4, *k6 = z + D * 5;
-        float bx = kB2f * k2[O], by = kB2f * k2[O + 1];
-        bx = __builtin_fmaf(kB3f, k3[O], bx); by = __builtin_fmaf(kB3f, k3[O + 1], by);
-        bx = __builtin_fmaf(kB4f, k4[O], bx); by = __builtin_fmaf(kB4f, k4[O + 1], by);
-        bx = __builtin_fmaf(kB5f, k5[O], bx); by = __builtin_fmaf(kB5f, k5[O + 1], by);
-        float ex = kE2f * k2[O], ey = kE2f * k2[O + 1];
-        ex = __builtin_fmaf(kE3f, k3[O], ex); ey = __builtin_fmaf(kE3f, k3[O + 1], ey);
-        ex = __builtin_fmaf(kE4f, k4[O], ex); ey = __builtin_fmaf(kE4f, k4[O + 1], ey);
-        ex = __builtin_fmaf(kE5f, k5[O], ex); ey = __builtin_fmaf(kE5f, k5[O + 1], ey);
-        ex = __builtin_fmaf(kE6f, k6[O], ex); ey = __builtin_fmaf(kE6f, k6[O + 1], ey);
-        A.nbx = P.sigma * (double)bx; A.nby = P.sigma * (double)by;
-        A.nex = P.sigma * (double)ex; A.ney = P.sigma * (double)ey;
-        A.z6a = MIS ? k6[0] : 0.f; A.z6x = k6[O]; A.z6y = k6[O + 1];
-        if constexpr (MIS) {
-            float ba = kB2f * k2[0], ea = kE2f * k2[0];
-            ba = __builtin_fmaf(kB3f, k3[0], ba); ea = __builtin_fmaf(kE3f, k3[0], ea);
-            ba = __builtin_fmaf(kB4f, k4[0], ba); ea = __builtin_fmaf(kE4f, k4[0], ea);
-            ba = __builtin_fmaf(kB5f, k5[0], ba); ea = __builtin_fmaf(kE5f, k5[0], ea);
-            ea = __builtin_fmaf(kE6f, k6[0], ea);
-            A.nbx = __builtin_fma(C.gx, (double)ba, A.nbx); A.nby = __builtin_fma(C.gy, (double)ba, A.nby);
-            A.nex = __builtin_fma(C.gx, (double)ea, A.nex); A.ney = __builtin_fma(C.gy, (double)ea, A.ney);
+        // mismatched law, draws (z_a, z_x, z_y) per evaluation, draw index = 4*call + lane:
+        //   0..1 K1 (dead; policy words)  2..4 K2  5..7 K3  8..10 K4  11..13 K5  14..16 F0  17..19 K6  20..22 F1
+        // Calls 0..4 are drawn here (first attempt: up front, d0).  The pair (F0y, K6a) is evaluated eagerly, so
+        // K6's g*z_a term is exact in the error sum and only sigma*(K6x, K6y) is left to the lazy bound (as in
+        // the nominal law); K6's (x, y) pair is only Box-Muller'd by finish_k6 and call 5 only fetched by
+        // rk45_construct when F1 is needed.
+        uint32_t wl[5][4];
+        const uint32_t (*w)[4];
+        if constexpr (FIRST) {
+            w = reinterpret_cast<const uint32_t (*)[4]>(d0);
+        } else {
+            const uint32_t c0s[5] = {c0_of(kStreamDyn, attempt, 0), c0_of(kStreamDyn, attempt, 1),
+                                     c0_of(kStreamDyn, attempt, 2), c0_of(kStreamDyn, attempt, 3),
+                                     c0_of(kStreamDyn, attempt, 4)};
+            philox_multi<5>(R, c0s, wl);
+            w = wl;
         }
+        A.have3 = false;
+        A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u;
+        A.f0a = w[3][2]; A.f0b = w[3][3]; A.k6a = w[4][2]; A.k6b = w[4][3];
+        box_muller<NZ>(w[4][0], w[4][1], A.f0y, A.z6a);
+        float z[12];  // draws 2..13
+        box_muller<NZ>(w[0][2], w[0][3], z[0], z[1]);
+        box_muller<NZ>(w[1][0], w[1][1], z[2], z[3]);
+        box_muller<NZ>(w[1][2], w[1][3], z[4], z[5]);
+        box_muller<NZ>(w[2][0], w[2][1], z[6], z[7]);
+        box_muller<NZ>(w[2][2], w[2][3], z[8], z[9]);
+        box_muller<NZ>(w[3][0], w[3][1], z[10], z[11]);
+        const float *k2 = z, *k3 = z + 3, *k4 = z + 6, *k5 = z + 9;
+        float ba = kB2f * k2[0], bx = kB2f * k2[1], by = kB2f * k2[2];
+        ba = __builtin_fmaf(kB3f, k3[0], ba); bx = __builtin_fmaf(kB3f, k3[1], bx); by = __builtin_fmaf(kB3f, k3[2], by);
+        ba = __builtin_fmaf(kB4f, k4[0], ba); bx = __builtin_fmaf(kB4f, k4[1], bx); by = __builtin_fmaf(kB4f, k4[2], by);
+        ba = __builtin_fmaf(kB5f, k5[0], ba); bx = __builtin_fmaf(kB5f, k5[1], bx); by = __builtin_fmaf(kB5f, k5[2], by);
+        float ea = kE2f * k2[0], ex = kE2f * k2[1], ey = kE2f * k2[2];
+        ea = __builtin_fmaf(kE3f, k3[0], ea); ex = __builtin_fmaf(kE3f, k3[1], ex); ey = __builtin_fmaf(kE3f, k3[2], ey);
+        ea = __builtin_fmaf(kE4f, k4[0], ea); ex = __builtin_fmaf(kE4f, k4[1], ex); ey = __builtin_fmaf(kE4f, k4[2], ey);
+        ea = __builtin_fmaf(kE5f, k5[0], ea); ex = __builtin_fmaf(kE5f, k5[1], ex); ey = __builtin_fmaf(kE5f, k5[2], ey);
+        ea = __builtin_fmaf(kE6f, A.z6a, ea);
+        A.nbx = __builtin_fma(C.gx, (double)ba, P.sigma * (double)bx);
+        A.nby = __builtin_fma(C.gy, (double)ba, P.sigma * (double)by);
+        A.ex32 = ex; A.ey32 = ey; A.ea32 = ea;
+        A.nex = A.ney = 0.0; A.z6x = A.z6y = 0.f;
+        A.lazy6 = true;
         return A;
     }
 }
@@ -612,12 +649,19 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
 constexpr double kZmaxE6 = 6.78 * (1.0 / 40);  // Zmax * E6
 
 // evaluate K6's Box-Muller pair and complete the error sums (same fp32 chain as the eager form: E6 is its last term)
-template <int NZ>
-__device__ __forceinline__ void finish_k6(const KParams& P, const Rng& R, uint32_t attempt, AttemptNoise& A) {
-    if (!A.have3) { philox_call(R, c0_of(kStreamDyn, attempt, 3), A.w3); A.have3 = true; }
-    box_muller<NZ>(A.w3[0], A.w3[1], A.z6x, A.z6y);
-    A.nex = P.sigma * (double)__builtin_fmaf(kE6f, A.z6x, A.ex32);
-    A.ney = P.sigma * (double)__builtin_fmaf(kE6f, A.z6y, A.ey32);
+template <int NZ, bool MIS>
+__device__ __forceinline__ void finish_k6(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, uint32_t attempt,
+                                          AttemptNoise& A) {
+    if constexpr (MIS) {
+        box_muller<NZ>(A.k6a, A.k6b, A.z6x, A.z6y);
+        A.nex = __builtin_fma(C.gx, (double)A.ea32, P.sigma * (double)__builtin_fmaf(kE6f, A.z6x, A.ex32));
+        A.ney = __builtin_fma(C.gy, (double)A.ea32, P.sigma * (double)__builtin_fmaf(kE6f, A.z6y, A.ey32));
+    } else {
+        if (!A.have3) { philox_call(R, c0_of(kStreamDyn, attempt, 3), A.w3); A.have3 = true; }
+        box_muller<NZ>(A.w3[0], A.w3[1], A.z6x, A.z6y);
+        A.nex = P.sigma * (double)__builtin_fmaf(kE6f, A.z6x, A.ex32);
+        A.ney = P.sigma * (double)__builtin_fmaf(kE6f, A.z6y, A.ey32);
+    }
     A.lazy6 = false;
 }
 
@@ -651,14 +695,20 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
             // next K0.  On the last sub-step, bound its contribution by |z| <= Zmax: if even the worst case
             // passes the accept test, the outcome is the eager one and K6's Box-Muller pair is never evaluated.
             if (last) {
+                double pex = __builtin_fma(P.sigma, (double)A.ex32, kE0 * dfx);
+                double pey = __builtin_fma(P.sigma, (double)A.ey32, kE0 * dfy);
                 const double b6 = h * (P.sigma * kZmaxE6);
-                const double axw = __builtin_fabs(h * __builtin_fma(P.sigma, (double)A.ex32, kE0 * dfx)) + b6;
-                const double ayw = __builtin_fabs(h * __builtin_fma(P.sigma, (double)A.ey32, kE0 * dfy)) + b6;
+                if constexpr (MIS) {  // the g*z_a terms (K6a included) are already exact in ea32
+                    pex = __builtin_fma(C.gx, (double)A.ea32, pex);
+                    pey = __builtin_fma(C.gy, (double)A.ea32, pey);
+                }
+                const double axw = __builtin_fabs(h * pex) + b6;
+                const double ayw = __builtin_fabs(h * pey) + b6;
                 if (__builtin_expect(__builtin_fma(axw * axw, s11, (ayw * ayw) * s00) < 0.98 * lim, 1)) {
                     accepted = true; decided = true;
                 }
             }
-            if (!decided) finish_k6<NZ>(P, R, S.attempt - 1, A);
+            if (!decided) finish_k6<NZ, MIS>(P, C, R, S.attempt - 1, A);
         }
     }
     double ex = kE0 * dfx, ey = kE0 * dfy;
@@ -691,8 +741,9 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
     }
     if (accepted) {
         S.tau = tn; x = xn; y = yn;
-        if constexpr (NZ != kNoNoise && !MIS) {
-            S.last_attempt = S.attempt - 1; S.f0a = A.f0a; S.f0b = A.f0b; S.have3 = A.have3;
+        if constexpr (NZ != kNoNoise) {
+            S.last_attempt = S.attempt - 1; S.f0a = A.f0a; S.f0b = A.f0b; S.f0y = A.f0y;
+            S.have3 = A.have3;
             S.w3[0] = A.w3[0]; S.w3[1] = A.w3[1]; S.w3[2] = A.w3[2]; S.w3[3] = A.w3[3];
         }
         if (!last) {  // f = f_new = K[6]; after the last sub-step the constructor replaces f anyway
@@ -711,7 +762,7 @@ __device__ __forceinline__ SubStep rk45_integrate(const KParams& P, const RhsCtx
                                                   const uint32_t* d0) {
     SubStep S;
     S.tau = 0.0; S.h_abs = h_abs; S.attempt = 0u; S.rejected = false;
-    S.last_attempt = 0u; S.f0a = S.f0b = 0u; S.w3[0] = S.w3[1] = S.w3[2] = S.w3[3] = 0u; S.have3 = false;
+    S.last_attempt = 0u; S.f0a = S.f0b = 0u; S.f0y = 0.f; S.w3[0] = S.w3[1] = S.w3[2] = S.w3[3] = 0u; S.have3 = false;
     // first attempt peeled: its RNG counters are wave-uniform (attempt = 0), and in the common
     // regime (|y| >~ 1) it is the only one
     rk45_attempt<NZ, MIS, true>(P, C, R, S, x, y, f0x, f0y, fail, d0);
@@ -869,13 +920,12 @@ __device__ __forceinline__ void action_from_words(const KParams& P, const uint32
     al = __builtin_fmaf(P.act_span_f[1], u1, P.act_lo_f[1]);
 }
 // Philox words of the step's hot path, drawn together up front (philox_multi): in RK45 mode the first
-// rk_step attempt's calls DYN(0, 0..NDYN-1) followed by the constructor's CTOR(0, 0..NCTOR-1); slot 0 also
+// rk_step attempt's calls DYN(0, 0..NDYN-1); slot 0 also
 // carries the exploration policy's two words.  Later attempts (rare) and resets draw their own.
 template <bool RK45, int NZ, bool MIS>
 struct StepWords {
     static constexpr int NDYN = (RK45 && NZ != kNoNoise) ? (MIS ? 5 : 3) : 0;
-    static constexpr int NCTOR = (RK45 && NZ != kNoNoise && MIS) ? 2 : 0;  // nominal: F0/F1 live in the DYN block
-    static constexpr int N = (NDYN + NCTOR) > 0 ? (NDYN + NCTOR) : 1;
+    static constexpr int N = NDYN > 0 ? NDYN : 1;  // the constructor's F0/F1 live in the DYN block too
     uint32_t w[N][4];
 };
 
@@ -887,8 +937,6 @@ __device__ __forceinline__ void step_prologue(const KParams& P, const Rng& R, bo
         uint32_t c0s[SW::N];
 #pragma unroll
         for (int j = 0; j < SW::NDYN; ++j) c0s[j] = c0_of(kStreamDyn, 0, (uint32_t)j);
-#pragma unroll
-        for (int j = 0; j < SW::NCTOR; ++j) c0s[SW::NDYN + j] = c0_of(kStreamCtor, 0, (uint32_t)j);
         philox_multi<SW::N>(R, c0s, W.w);
     } else {
         W.w[0][0] = W.w[0][1] = W.w[0][2] = W.w[0][3] = 0u;
@@ -908,15 +956,13 @@ template <bool RK45, int NZ, bool MIS>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
                                          EnvRegs& e, float act_f, float act_a, const StepWords<RK45, NZ, MIS>& W,
                                          uint32_t fl, StepOut& o, int& fail) {
-    using SW = StepWords<RK45, NZ, MIS>;
     e.counter += 1;  // :80
     const RhsCtx<MIS> C = make_ctx<MIS>(P, (double)act_f, (double)act_a);
     double spx = 0.0, spy = 0.0;
     if constexpr (RK45) {
         SubStep LS = rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, &W.w[0][0]);  // MR_simulator.py:42-45
         rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy,           // :46-50
-                                SW::NCTOR > 0 ? &W.w[SW::NDYN] : nullptr, (fl & kFOutStatePrime) != 0,
-                                (NZ != kNoNoise && !MIS) ? &LS : nullptr);
+                                (fl & kFOutStatePrime) != 0, NZ != kNoNoise ? &LS : nullptr);
     } else {
         fixed_integrate<NZ, MIS>(P, C, R, e.x, e.y, spx, spy);
         e.f0x = spx; e.f0y = spy; e.h_abs = P.dt;

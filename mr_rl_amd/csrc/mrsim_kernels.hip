@@ -181,7 +181,7 @@ struct RolloutArgs {
 };
 
 template <bool RK45, int NZ, bool MIS>
-__global__ __launch_bounds__(kBlock) void mr_rollout_kernel(const KParams P, const StateArgs st, const RolloutArgs ra) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void mr_rollout_kernel(const KParams P, const StateArgs st, const RolloutArgs ra) {
     // All per-step stores use a wave-uniform base (block start of row t, kept in SGPRs) plus a 32-bit
     // per-lane offset, so no 64-bit address arithmetic runs on the vector unit inside the time loop.
     const long long blk0 = (long long)blockIdx.x * kBlock;

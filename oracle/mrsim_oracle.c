@@ -251,11 +251,18 @@ static const double RK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 172
  *   F0, F1 = the two RHS evaluations of the constructor that runs after the step's LAST attempt; they are
  *   taken from that attempt's block.  K6 (= f_new) and F1 rarely influence a result (K6: only the error
  *   estimate and the next sub-step's K0; F1: only d2 and Simulator.state_prime).
- *   MISMATCHED law (3 draws per evaluation): K1..K6 sequential in DYN(attempt), constructor sequential in
- *   CTOR(0).  Reset constructors: sequential in RESET_CTOR(0) for both laws. */
+ *   MISMATCHED law (3 draws (z_a, z_x, z_y) per evaluation), same idea over six calls of DYN(attempt a):
+ *     draws 0..1: K1 (dead; policy words as above)   2..4: K2   5..7: K3   8..10: K4   11..13: K5
+ *     14..16: F0   17..19: K6   20..22: F1   (23 unused)
+ *   so that calls 0..4 are needed eagerly, the pair (K6x, K6y) and call 5 (F1) almost never.
+ *   Reset constructors: sequential in RESET_CTOR(0) for both laws. */
 #define NOM_POS_K6 12
 #define NOM_POS_F0 10
 #define NOM_POS_F1 14
+#define MIS_POS_K2 2
+#define MIS_POS_F0 14
+#define MIS_POS_K6 17
+#define MIS_POS_F1 20
 
 static void rk45_construct(const OrcParams* p, int mismatched, OrcEnv* e, const double act[2], OrcNoise* nz,
                            uint32_t env_id, int stream, uint32_t block, int pos_f0, int pos_f1) {
@@ -354,12 +361,15 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
             double K[7][2];
             K[0][0] = e->f[0]; K[0][1] = e->f[1];
             ns_open(&ns, nz, env_id, STREAM_DYN, attempt);
-            for (int s = 1; s < 6; ++s) simulate(p, mis, e, act, &ns, K[s]);
+            for (int s = 1; s < 6; ++s) {
+                simulate(p, mis, e, act, &ns, K[s]);
+                if (mis && s == 1) ns_seek(&ns, MIS_POS_K2); /* K1 has weight 0 in B and E */
+            }
             double s0 = 0, s1 = 0;
             for (int i = 0; i < 6; ++i) { s0 += K[i][0] * RK_B[i]; s1 += K[i][1] * RK_B[i]; }
             yn0 = y0 + h * s0;
             yn1 = y1 + h * s1;
-            if (!mis) ns_seek(&ns, NOM_POS_K6);
+            ns_seek(&ns, mis ? MIS_POS_K6 : NOM_POS_K6);
             simulate(p, mis, e, act, &ns, fn);
             K[6][0] = fn[0]; K[6][1] = fn[1];
             attempt++; e->n_attempts++;
@@ -386,8 +396,8 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
         if (e->t - t_bound >= 0) break; /* status = 'finished' */
     }
     /* last_state = integrator.y (:45); new RK45 from (t, y) to t + time_span (:46-50) */
-    if (mis) rk45_construct(p, mis, e, act, nz, env_id, STREAM_CTOR, 0, -1, -1);
-    else rk45_construct(p, mis, e, act, nz, env_id, STREAM_DYN, attempt ? attempt - 1 : 0, NOM_POS_F0, NOM_POS_F1);
+    rk45_construct(p, mis, e, act, nz, env_id, STREAM_DYN, attempt ? attempt - 1 : 0,
+                   mis ? MIS_POS_F0 : NOM_POS_F0, mis ? MIS_POS_F1 : NOM_POS_F1);
     return 0;
 }
 

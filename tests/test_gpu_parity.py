@@ -169,12 +169,13 @@ def test_step_vs_oracle_noise_far(mis, math):
     env.check_status()
 
 
-def test_step_vs_oracle_noise_near_origin():
+@pytest.mark.parametrize("mis", [False, True])
+def test_step_vs_oracle_noise_near_origin(mis):
     """sigma > 0 near the origin: the error controller splits steps (tens of rk_step attempts, a
     data-dependent loop).  Accept/reject decisions are discontinuous, so a 1e-16 difference may flip
     one; require >= 99.9 % of envs to agree to POS_TOL and all to stay finite."""
     n, T = 1024, 25
-    torch, env, orc = _mk(n, seed=7, noise_var=0.5, a0=1.0, noise_math="spec")
+    torch, env, orc = _mk(n, seed=7, noise_var=0.5, a0=1.0, noise_math="spec", is_mismatched=mis)
     rng = np.random.default_rng(3)
     init = rng.uniform(-0.5, 0.5, (n, 2))
     env.reset(init=init); orc.reset(0, init_xy=init)
@@ -297,11 +298,14 @@ def test_euler_bit_stability_config2():
     assert np.abs(d).max() < 3e-7 and np.abs(d[1:] - d[:-1]).max() < 1e-12  # offset = the reference's first-step loss
 
 
-def test_rollout_equals_steps():
-    """The fused rollout kernel is bit-identical to T single-step launches (sigma > 0, auto-reset)."""
+@pytest.mark.parametrize("mis", [False, True])
+def test_rollout_equals_steps(mis):
+    """The fused rollout kernel is bit-identical to T single-step launches (sigma > 0, auto-reset).  The
+    rollout does not ask for state_prime, so it takes the lazy K6 / F1 paths that the step path (which
+    always evaluates F1) does not: equal bits prove the laziness changes no outcome, for both noise laws."""
     n, T = 3000, 60
-    torch, e1, _ = _mk(n, seed=9, noise_var=1.0, auto_reset=True)
-    torch, e2, _ = _mk(n, seed=9, noise_var=1.0, auto_reset=True)
+    torch, e1, _ = _mk(n, seed=9, noise_var=1.0, auto_reset=True, is_mismatched=mis)
+    torch, e2, _ = _mk(n, seed=9, noise_var=1.0, auto_reset=True, is_mismatched=mis)
     e1.reset(); e2.reset()
     out = e1.rollout(T, actions=None, want=("traj", "obs", "rew", "done", "actions"))
     for t in range(T):

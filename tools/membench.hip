@@ -18,12 +18,26 @@ __global__ __launch_bounds__(BLOCK) void pattern(long long n, double2* __restric
         double2 p = pos[i]; float4 a = aux[i]; float e = ep[i]; float2 c = act[i];
         p.x += (double)c.x * 1e-3; p.y += (double)c.y * 1e-3;
         a.x = c.x; a.y = c.y; a.w = __int_as_float(__float_as_int(a.w) + 1); e += 10.f;
-        if (VARIANT == 1) {  // nontemporal stores
+        if (VARIANT == 2) {  // everything nontemporal
+            __builtin_nontemporal_store(p.x, &pos[i].x); __builtin_nontemporal_store(p.y, &pos[i].y);
+            __builtin_nontemporal_store(a.x, &aux[i].x); __builtin_nontemporal_store(a.y, &aux[i].y);
+            __builtin_nontemporal_store(a.z, &aux[i].z); __builtin_nontemporal_store(a.w, &aux[i].w);
+            __builtin_nontemporal_store(e, &ep[i]); __builtin_nontemporal_store(10.f, &rew[i]);
+            __builtin_nontemporal_store((unsigned char)(e > 500.f), &done[i]);
+        } else if (VARIANT == 3) {  // agent-scope relaxed atomic stores = write-through (sc1)
+            __hip_atomic_store(&pos[i].x, p.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pos[i].y, p.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<double*>(&aux[i].x), *reinterpret_cast<double*>(&a.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<double*>(&aux[i].z), *reinterpret_cast<double*>(&a.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ep[i], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&rew[i], 10.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            done[i] = (unsigned char)(e > 500.f);
+        } else if (VARIANT == 1) {  // nontemporal stores
             __builtin_nontemporal_store(p.x, &pos[i].x); __builtin_nontemporal_store(p.y, &pos[i].y);
             __builtin_nontemporal_store(a.x, &aux[i].x); __builtin_nontemporal_store(a.y, &aux[i].y);
             __builtin_nontemporal_store(a.z, &aux[i].z); __builtin_nontemporal_store(a.w, &aux[i].w);
         } else { pos[i] = p; aux[i] = a; }
-        ep[i] = e; rew[i] = 10.f; done[i] = (unsigned char)(e > 500.f);
+        if (VARIANT < 2) { ep[i] = e; rew[i] = 10.f; done[i] = (unsigned char)(e > 500.f); }
         s_obs[threadIdx.x * 5 + 0] = (float)p.x; s_obs[threadIdx.x * 5 + 1] = (float)p.y; s_obs[threadIdx.x * 5 + 2] = 0.f;
         s_obs[threadIdx.x * 5 + 3] = 0.f; s_obs[threadIdx.x * 5 + 4] = (float)(p.x + p.y);
     }
@@ -32,7 +46,14 @@ __global__ __launch_bounds__(BLOCK) void pattern(long long n, double2* __restric
     const int nvalid = (int)rows * 5;
     float* dst = obs + base * 5;
     for (int q = threadIdx.x * 4; q < nvalid; q += BLOCK * 4)
-        if (q + 4 <= nvalid) *reinterpret_cast<float4*>(dst + q) = *reinterpret_cast<const float4*>(s_obs + q);
+        if (q + 4 <= nvalid) {
+            const float4 v = *reinterpret_cast<const float4*>(s_obs + q);
+            if (VARIANT == 2) { __builtin_nontemporal_store(v.x, dst + q); __builtin_nontemporal_store(v.y, dst + q + 1);
+                                __builtin_nontemporal_store(v.z, dst + q + 2); __builtin_nontemporal_store(v.w, dst + q + 3); }
+            else if (VARIANT == 3) { __hip_atomic_store(reinterpret_cast<double*>(dst + q), *reinterpret_cast<const double*>(&v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                     __hip_atomic_store(reinterpret_cast<double*>(dst + q + 2), *reinterpret_cast<const double*>(&v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else *reinterpret_cast<float4*>(dst + q) = v;
+        }
 }
 
 // read-only / write-only halves
@@ -69,6 +90,8 @@ int main(int argc, char** argv) {
     run("empty", [&] { hipLaunchKernelGGL(empty_k, dim3(1), dim3(64), 0, 0, n, rew); });
     run("pattern<256>", [&] { hipLaunchKernelGGL((pattern<256, 0>), dim3(g256), dim3(256), 0, 0, n, pos, aux, ep, act, obs, rew, done); });
     run("pattern<256,nt>", [&] { hipLaunchKernelGGL((pattern<256, 1>), dim3(g256), dim3(256), 0, 0, n, pos, aux, ep, act, obs, rew, done); });
+    run("pattern<256,nt-all>", [&] { hipLaunchKernelGGL((pattern<256, 2>), dim3(g256), dim3(256), 0, 0, n, pos, aux, ep, act, obs, rew, done); });
+    run("pattern<256,sc1>", [&] { hipLaunchKernelGGL((pattern<256, 3>), dim3(g256), dim3(256), 0, 0, n, pos, aux, ep, act, obs, rew, done); });
     run("pattern<128>", [&] { hipLaunchKernelGGL((pattern<128, 0>), dim3(g128), dim3(128), 0, 0, n, pos, aux, ep, act, obs, rew, done); });
     run("pattern<512>", [&] { hipLaunchKernelGGL((pattern<512, 0>), dim3(g512), dim3(512), 0, 0, n, pos, aux, ep, act, obs, rew, done); });
     run("pattern<1024>", [&] { hipLaunchKernelGGL((pattern<1024, 0>), dim3(g1024), dim3(1024), 0, 0, n, pos, aux, ep, act, obs, rew, done); });
