@@ -856,13 +856,17 @@ __device__ __forceinline__ void store_env(double* __restrict__ pos, float* __res
 }
 
 // goal of (env, episode step): MR_Env.init_goal = (0,0) (MR_env.py:57) or a trajectory table
-__device__ __forceinline__ void goal_at(const KParams& P, uint32_t fl, const float* __restrict__ goal_table,
-                                        uint32_t env, int32_t counter, double& gx, double& gy) {
-    if (!(fl & kFGoalTable)) { gx = 0.0; gy = 0.0; return; }
+__device__ __forceinline__ float2 goal_fetch(const KParams& P, uint32_t fl, const float* __restrict__ goal_table,
+                                             uint32_t env, int32_t counter) {
+    if (!(fl & kFGoalTable)) return make_float2(0.f, 0.f);
     const int K = P.goal_K > 0 ? P.goal_K : 1, T = P.goal_T > 0 ? P.goal_T : 1;
     const int k = (K == 1) ? 0 : (int)(env % (uint32_t)K);
     const int r = counter < 0 ? 0 : (counter >= T ? T - 1 : counter);
-    const float2 g = reinterpret_cast<const float2*>(goal_table)[(long long)k * T + r];
+    return reinterpret_cast<const float2*>(goal_table)[(long long)k * T + r];
+}
+__device__ __forceinline__ void goal_at(const KParams& P, uint32_t fl, const float* __restrict__ goal_table,
+                                        uint32_t env, int32_t counter, double& gx, double& gy) {
+    const float2 g = goal_fetch(P, fl, goal_table, env, counter);
     gx = (double)g.x; gy = (double)g.y;
 }
 
@@ -957,6 +961,9 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
                                          EnvRegs& e, float act_f, float act_a, const StepWords<RK45, NZ, MIS>& W,
                                          uint32_t fl, StepOut& o, int& fail) {
     e.counter += 1;  // :80
+    // the goal of this step only depends on the counter: fetch it now so that the table read (an L1/L2 hit,
+    // but hundreds of cycles) completes behind the integrator instead of stalling the termination check
+    const float2 goal_f = goal_fetch(P, fl, goal_table, R.env, e.counter);
     const RhsCtx<MIS> C = make_ctx<MIS>(P, (double)act_f, (double)act_a);
     double spx = 0.0, spy = 0.0;
     if constexpr (RK45) {
@@ -967,8 +974,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         fixed_integrate<NZ, MIS>(P, C, R, e.x, e.y, spx, spy);
         e.f0x = spx; e.f0y = spy; e.h_abs = P.dt;
     }
-    double gx, gy;
-    goal_at(P, fl, goal_table, R.env, e.counter, gx, gy);
+    double gx = (double)goal_f.x, gy = (double)goal_f.y;
     const double dx = gx - e.x, dy = gy - e.y;
     const double d2 = __builtin_fma(dx, dx, dy * dy);
     // end (:136-152); Box.contains as a numeric bounds test; distances compared squared
