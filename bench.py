@@ -56,6 +56,7 @@ def parse():
                     help="ddpg = BASELINE config 4 (default); mixed = config 5's trajectory set: goal = reference-"
                          "trajectory table[env_id mod 3] (straight line / figure-eight / random), tracking reward")
     ap.add_argument("--no-step-path", action="store_true", help="skip the extra one-launch-per-step measurement")
+    ap.add_argument("--no-mixed-set", action="store_true", help="skip the extra mixed-trajectory-set measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
@@ -140,6 +141,64 @@ def measure_step_path(cfg, n_local, dev, seed, steps=510, samples=102):
             "roofline_frac": round(ach / HBM_PEAK_GBS, 4)}
 
 
+def mixed_goal_table(cfg, seed):
+    """BASELINE config 5's "mixed trajectory set": env_id mod 3 -> straight line / figure eight / random waypoints,
+    one goal per episode step; switches the env to the goal reward (calculate_reward, MR_env.py:118-134)."""
+    import numpy as np
+    Tg = cfg.max_timesteps + 2
+    k = np.arange(Tg)
+    th = 2 * np.pi * k / Tg
+    tab = np.zeros((3, Tg, 2), dtype=np.float32)
+    tab[0, :, 0] = 110 + 0.3 * k; tab[0, :, 1] = 110 + 0.3 * k                           # straight line
+    tab[1, :, 0] = 110 + 8 * np.sin(th); tab[1, :, 1] = 110 + 8 * np.sin(th) * np.cos(th)  # figure eight
+    tab[2] = np.random.default_rng(seed).uniform(100, 120, (Tg, 2))                        # random waypoints
+    cfg.reward_mode, cfg.min_dist2goal = "goal", 1.0
+    return tab
+
+
+def measure_mixed_set(args, n_local, env_id0, world, dev, seed, barrier, steps=1020):
+    """Secondary figure (every rank takes part, same barrier / max-over-ranks protocol as the headline): the fused
+    rollout on BASELINE config 5's mixed straight-line / figure-eight / random-waypoint trajectory set with the
+    goal reward, returns all-gathered once per episode."""
+    import torch
+    import torch.distributed as dist
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.dist import ReturnGatherer
+    cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math,
+                   seed=seed, is_mismatched=args.mismatched)
+    tab = mixed_goal_table(cfg, seed)
+    env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0, goal_table=tab)
+    env.reset()
+    g = ReturnGatherer(env, world)
+    ep = cfg.max_timesteps + 1
+    bufs = {}
+    want = ("obs", "rew", "done", "actions")
+
+    def run(n_ep):
+        for _ in range(n_ep):
+            env.rollout(ep, actions=None, want=want, out=bufs)
+            g.gather()
+
+    run(2)
+    barrier()
+    t0 = time.perf_counter()
+    run(steps // ep)
+    g.finish()
+    torch.cuda.synchronize(dev)
+    barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    k = (steps // ep) * ep
+    env.check_status()
+    return {"workload": "BASELINE config 5 trajectory set: env_id mod 3 -> straight line / figure eight / random "
+                        "waypoints (goal table), goal reward, same policy / noise / outputs as the headline",
+            "value": n_local * world * k / el, "unit": "env-steps/s", "steps": k, "ms_per_step": el / k * 1e3,
+            "mean_episode_return": g.last_mean()}
+
+
 def trajectory_rmse(dev):
     """Second half of BASELINE's metric: trajectory RMSE vs the CPU reference, on the committed golden trajectories
     the reference itself produced (tests/golden/ref_sim.npz, sigma = 0, 1000-2000 steps each), through the same
@@ -204,16 +263,7 @@ def main():
                    seed=seed, is_mismatched=args.mismatched)
     goal_table = None
     if args.workload == "mixed":
-        import numpy as np
-        Tg = cfg.max_timesteps + 2
-        k = np.arange(Tg)
-        th = 2 * np.pi * k / Tg
-        tab = np.zeros((3, Tg, 2), dtype=np.float32)
-        tab[0, :, 0] = 110 + 0.3 * k; tab[0, :, 1] = 110 + 0.3 * k                           # straight line
-        tab[1, :, 0] = 110 + 8 * np.sin(th); tab[1, :, 1] = 110 + 8 * np.sin(th) * np.cos(th)  # figure eight
-        tab[2] = np.random.default_rng(seed).uniform(100, 120, (Tg, 2))                        # random waypoints
-        goal_table = tab
-        cfg.reward_mode, cfg.min_dist2goal = "goal", 1.0
+        goal_table = mixed_goal_table(cfg, seed)
     env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0, goal_table=goal_table)
     env.reset()
     gatherer = ReturnGatherer(env, world)
@@ -288,6 +338,9 @@ def main():
     el = float(t.item())
     env.check_status()
     mean_ret = gatherer.last_mean()
+    mixed = None
+    if args.mode == "rollout" and args.workload == "ddpg" and not args.no_mixed_set:
+        mixed = measure_mixed_set(args, n_local, env_id0, world, dev, seed, barrier)
 
     # ---- duration of the dominant kernel, HIP events attached to the dispatch (hipExtLaunchKernelGGL)
     # on the stream it runs on; same state regime, right after the timed region.
@@ -345,6 +398,8 @@ def main():
             out["trajectory_rmse_vs_cpu_ref"] = rmse
         if step_path is not None:
             out["step_path"] = step_path
+        if mixed is not None:
+            out["mixed_trajectory_set"] = mixed
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
