@@ -13,7 +13,8 @@ def pytest_configure(config):
     # The in-tree .so files are git-ignored build products: build them if this checkout has none yet
     # (hipcc cross-compiles gfx950 without a GPU).  The package itself never builds or falls back.
     if not (os.path.exists(os.path.join(ROOT, "mr_rl_amd", "libmrsim.so")) and
-            os.path.exists(os.path.join(ROOT, "oracle", "libmrsim_oracle.so"))):
+            os.path.exists(os.path.join(ROOT, "oracle", "libmrsim_oracle.so")) and
+            os.path.exists(os.path.join(ROOT, "examples", "abi_demo"))):
         import __graft_entry__
         __graft_entry__.build()
 

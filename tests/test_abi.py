@@ -71,6 +71,19 @@ def test_no_device_is_an_error_not_a_fallback():
         MRVecEnv(4)
 
 
+def test_c_demo_program_builds_and_refuses_without_a_device():
+    """examples/abi_demo (pure C++ consumer of include/mrsim.h) is built with the library; without a GPU it must stop
+    with an error, not compute anything."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "examples", "abi_demo")
+    assert os.path.exists(exe), "make -C mr_rl_amd/csrc builds it"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present (the GPU suite runs it)")
+    r = subprocess.run([exe, "64"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
 def test_argument_validation():
     from mr_rl_amd import _lib
     L = _lib.lib()

@@ -10,6 +10,8 @@ Stated tolerances (fp64 positions; f0/h_abs are carried between steps in fp32, s
   OBS       float32(oracle obs) within 2 ulp_f32 (+ POS_TOL)
   rew / done / counter: exact
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -17,6 +19,7 @@ from oracle import oracle as O
 from tests.util import actions_figure8, actions_ramp, load_cases, orc_params_from_cfg
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 POS_TOL = 1e-6
 POS_TOL_FAST = 5e-6
 
@@ -606,3 +609,14 @@ def test_nan_action_terminates_and_raises_status():
     pos = env.pos.cpu().numpy()
     assert np.isnan(pos[7]).any() and np.isfinite(np.delete(pos, 7, axis=0)).all()
     assert bool(env.done[7])  # NaN fails the bounds test, as Box.contains would
+
+
+def test_c_abi_demo_program():
+    """The C ABI is usable without Python or torch: examples/abi_demo.cpp (HIP runtime buffers only) runs one episode
+    through mrsim_reset/mrsim_step and through one mrsim_rollout launch and checks episode shape, bitwise agreement
+    of the two paths and the error codes."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "abi_demo")
+    assert os.path.exists(exe), "build it with make -C mr_rl_amd/csrc demo"
+    r = subprocess.run([exe, "5000"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ABI_DEMO_OK" in r.stdout, (r.stdout, r.stderr)
