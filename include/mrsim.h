@@ -175,6 +175,21 @@ int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const
                         const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream,
                         float* kernel_ms_host);
 
+/* Non-blocking measurement aids: the same launches with two caller-owned HIP events attached to the dispatch
+ * (hipExtLaunchKernelGGL), nothing synchronised.  Lets bench.py read each kernel's duration INSIDE its timed
+ * region, on the stream the kernel runs on, without perturbing it.  Events come from mrsim_event_create (thin
+ * wrappers over hipEventCreate / hipEventElapsedTime / hipEventDestroy so a ctypes caller needs no second HIP
+ * binding); mrsim_event_elapsed_ms synchronises on `stop`. */
+int mrsim_event_create(void** event_out);
+int mrsim_event_destroy(void* event);
+int mrsim_event_elapsed_ms(void* start_event, void* stop_event, float* ms_host);
+int mrsim_rollout_events(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
+                         const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream,
+                         void* start_event, void* stop_event);
+int mrsim_step_events(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
+                      const MrsimStepIO* io, uint64_t seed, uint64_t step_idx, void* stream,
+                      void* start_event, void* stop_event);
+
 /* Velocity post-processing that every consumer of run_sim applies to the recorded positions
  * (Learning_module.py:46-59,72-93; main.py:102-109):
  *     p  = uniform_filter1d(p, N, mode="nearest")           (running mean, window [t - N/2, t + N - N/2 - 1])

@@ -18,6 +18,7 @@ SYMBOLS = (
     "mrsim_abi_version", "mrsim_strerror", "mrsim_default_params", "mrsim_reset", "mrsim_step",
     "mrsim_step_timed", "mrsim_random_policy", "mrsim_rollout", "mrsim_rollout_timed", "mrsim_advance_step_base", "mrsim_velocity", "mrsim_debug_normals",
     "mrsim_device_count", "mrsim_device_name",
+    "mrsim_event_create", "mrsim_event_destroy", "mrsim_event_elapsed_ms", "mrsim_rollout_events", "mrsim_step_events",
 )
 
 
@@ -92,6 +93,14 @@ def lib():
     L.mrsim_velocity.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp]
     L.mrsim_velocity.restype = C.c_int
     L.mrsim_advance_step_base.argtypes = [vp, u64, vp]
+    L.mrsim_event_create.argtypes = [C.POINTER(vp)]
+    L.mrsim_event_destroy.argtypes = [vp]
+    L.mrsim_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.mrsim_rollout_events.argtypes = L.mrsim_rollout.argtypes + [vp, vp]
+    L.mrsim_step_events.argtypes = L.mrsim_step.argtypes + [vp, vp]
+    for name in ("mrsim_event_create", "mrsim_event_destroy", "mrsim_event_elapsed_ms", "mrsim_rollout_events",
+                 "mrsim_step_events"):
+        getattr(L, name).restype = C.c_int
     L.mrsim_advance_step_base.restype = C.c_int
     L.mrsim_debug_normals.argtypes = [i64, u32, u64, u64, u32, i32, vp, vp]
     L.mrsim_device_count.restype = C.c_int
@@ -113,6 +122,27 @@ def strerror(code):
 def check(code, what):
     if code != OK:
         raise MrsimError(code, what)
+
+
+class EventPair:
+    """Two HIP events attached to one dispatch by mrsim_rollout_events / mrsim_step_events (measurement aid):
+    elapsed_ms() waits for the stop event and returns that kernel's duration."""
+
+    def __init__(self):
+        self.start, self.stop = C.c_void_p(), C.c_void_p()
+        check(lib().mrsim_event_create(C.byref(self.start)), "mrsim_event_create")
+        check(lib().mrsim_event_create(C.byref(self.stop)), "mrsim_event_create")
+
+    def elapsed_ms(self):
+        ms = C.c_float(0.0)
+        check(lib().mrsim_event_elapsed_ms(self.start, self.stop, C.byref(ms)), "mrsim_event_elapsed_ms")
+        return ms.value
+
+    def close(self):
+        for e in (self.start, self.stop):
+            if e:
+                lib().mrsim_event_destroy(e)
+        self.start, self.stop = C.c_void_p(), C.c_void_p()
 
 
 def default_params():

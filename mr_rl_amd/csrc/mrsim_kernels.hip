@@ -414,8 +414,11 @@ static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams&
     });
 }
 
+// kernel_ms != nullptr: own events, synchronise, report the duration.  ev_start/ev_stop != nullptr: caller's events,
+// attached to the dispatch, nothing synchronised.
 static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, const MrsimStepIO* io,
-                     uint64_t seed, uint64_t step_idx, void* stream, float* kernel_ms) {
+                     uint64_t seed, uint64_t step_idx, void* stream, float* kernel_ms, void* ev_start = nullptr,
+                     void* ev_stop = nullptr) {
     KParams K;
     int rc = make_kparams(p, n, env_id0, seed, step_idx, K);
     if (rc) return rc;
@@ -431,7 +434,7 @@ static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
                (io->actions_out ? kFOutActions : 0u) | (io->state_prime ? kFOutStatePrime : 0u) |
                (io->final_obs ? kFOutFinalObs : 0u) | (io->final_ret ? kFOutFinalRet : 0u) |
                (io->final_len ? kFOutFinalLen : 0u) | (io->status ? kFOutStatus : 0u);
-    LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    LaunchCfg lc{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
     if (kernel_ms == nullptr) return launch_step(lc, p, K, S, IO);
     // timed variant: events attached to this one dispatch (hipExtLaunchKernelGGL)
     if (hipEventCreate(&lc.start) != hipSuccess || hipEventCreate(&lc.stop) != hipSuccess) return MRSIM_ELAUNCH;
@@ -538,7 +541,8 @@ int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float
 }
 
 static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
-                        const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream, float* kernel_ms) {
+                        const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream, float* kernel_ms,
+                        void* ev_start = nullptr, void* ev_stop = nullptr) {
     KParams K;
     int rc = make_kparams(p, n, env_id0, seed, step_idx0, K);
     if (rc) return rc;
@@ -560,7 +564,7 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     const RolloutArgs ra{io->T, io->shared_actions, p->obs_layout, 0, io->actions, io->goal_table, io->traj_xy,
                          io->state_prime_T, io->obs_T, io->rew_T, io->done_T, io->actions_out_T, io->final_ret,
                          io->final_len, io->status};
-    LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    LaunchCfg lc{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
     if (kernel_ms != nullptr && (hipEventCreate(&lc.start) != hipSuccess || hipEventCreate(&lc.stop) != hipSuccess))
         return MRSIM_ELAUNCH;
     rc = dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
@@ -586,6 +590,42 @@ int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const
                         float* kernel_ms_host) {
     if (kernel_ms_host == nullptr) return MRSIM_EINVAL;
     return rollout_impl(p, n, env_id0, st, io, seed, step_idx0, stream, kernel_ms_host);
+}
+
+int mrsim_event_create(void** event_out) {
+    if (event_out == nullptr) return MRSIM_EINVAL;
+    int rc = check_device();
+    if (rc) return rc;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return MRSIM_ELAUNCH;
+    *event_out = e;
+    return MRSIM_OK;
+}
+
+int mrsim_event_destroy(void* event) {
+    if (event == nullptr) return MRSIM_EINVAL;
+    return hipEventDestroy(static_cast<hipEvent_t>(event)) == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+}
+
+int mrsim_event_elapsed_ms(void* start_event, void* stop_event, float* ms_host) {
+    if (start_event == nullptr || stop_event == nullptr || ms_host == nullptr) return MRSIM_EINVAL;
+    if (hipEventSynchronize(static_cast<hipEvent_t>(stop_event)) != hipSuccess ||
+        hipEventElapsedTime(ms_host, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event)) != hipSuccess)
+        return MRSIM_ELAUNCH;
+    return MRSIM_OK;
+}
+
+int mrsim_rollout_events(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
+                         const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream, void* start_event,
+                         void* stop_event) {
+    if (start_event == nullptr || stop_event == nullptr) return MRSIM_EINVAL;
+    return rollout_impl(p, n, env_id0, st, io, seed, step_idx0, stream, nullptr, start_event, stop_event);
+}
+
+int mrsim_step_events(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, const MrsimStepIO* io,
+                      uint64_t seed, uint64_t step_idx, void* stream, void* start_event, void* stop_event) {
+    if (start_event == nullptr || stop_event == nullptr) return MRSIM_EINVAL;
+    return step_impl(p, n, env_id0, st, io, seed, step_idx, stream, nullptr, start_event, stop_event);
 }
 
 int mrsim_velocity(int64_t n, int32_t T, int32_t n_filter, const double* traj_xy, const double* time, double* v_xy,

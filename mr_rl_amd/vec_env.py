@@ -255,11 +255,13 @@ class MRVecEnv:
         _lib.check(rc, "mrsim_random_policy")
         return out
 
-    def rollout(self, T, actions=None, shared_actions=False, want=("traj",), out=None, timed=False):
+    def rollout(self, T, actions=None, shared_actions=False, want=("traj",), out=None, timed=False, events=None):
         """T fused steps in one launch (batched utils.run_sim / DDPG rollout).  actions: [T,N,2], or [T,2]
         with shared_actions=True, or None for the on-device random policy.  want: any of "traj" (fp64
         positions [T,N,2]), "state_prime", "obs", "rew", "done", "actions".  `out` lets a caller reuse the
-        [T,...] buffers of a previous call (the returned dict).  Returns a dict of [T,...] tensors."""
+        [T,...] buffers of a previous call (the returned dict).  Returns a dict of [T,...] tensors.
+        Measurement aids: timed=True synchronises and returns "kernel_ms"; events=_lib.EventPair() attaches the
+        pair to the dispatch without synchronising (read it later with .elapsed_ms())."""
         torch = _torch()
         n, dev = self.num_envs, self.device
         act_t = None
@@ -292,6 +294,8 @@ class MRVecEnv:
             ms = C.c_float(0.0)
             _lib.check(self._L.mrsim_rollout_timed(*args, C.byref(ms)), "mrsim_rollout_timed")
             buf["kernel_ms"] = ms.value
+        elif events is not None:
+            _lib.check(self._L.mrsim_rollout_events(*args, events.start, events.stop), "mrsim_rollout_events")
         else:
             _lib.check(self._L.mrsim_rollout(*args), "mrsim_rollout")
         self.step_idx += int(T)

@@ -620,3 +620,19 @@ def test_c_abi_demo_program():
     assert os.path.exists(exe), "build it with make -C mr_rl_amd/csrc demo"
     r = subprocess.run([exe, "5000"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ABI_DEMO_OK" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_event_attached_launch_times_the_kernel_without_blocking():
+    """mrsim_rollout_events: caller-owned HIP events attached to the dispatch give the same kind of figure as the
+    blocking mrsim_rollout_timed, and the launch produces the same results as a plain one."""
+    from mr_rl_amd._lib import EventPair
+    torch, e1, _ = _mk(8192, seed=5, noise_var=1.0, auto_reset=True)
+    torch, e2, _ = _mk(8192, seed=5, noise_var=1.0, auto_reset=True)
+    e1.reset(); e2.reset()
+    ev = EventPair()
+    o1 = e1.rollout(51, actions=None, want=("obs",), events=ev)
+    o2 = e2.rollout(51, actions=None, want=("obs",), timed=True)
+    ms = ev.elapsed_ms()
+    ev.close()
+    assert 0.0 < ms < 50.0 and 0.0 < o2["kernel_ms"] < 50.0
+    np.testing.assert_array_equal(o1["obs"].cpu().numpy().view(np.uint32), o2["obs"].cpu().numpy().view(np.uint32))
