@@ -180,7 +180,10 @@ struct RolloutArgs {
     int32_t* status;
 };
 
-template <bool RK45, int NZ, bool MIS>
+// FL != 0: the launch's flags word is known at compile time (the host picks such an instantiation when K.flags
+// matches one of the common configurations): every optional path below folds away, which frees the scalar
+// registers their pointers and constants would occupy.  FL == 0: generic kernel, flags read from P.
+template <bool RK45, int NZ, bool MIS, uint32_t FL = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void mr_rollout_kernel(const KParams P, const StateArgs st, const RolloutArgs ra) {
     // All per-step stores use a wave-uniform base (block start of row t, kept in SGPRs) plus a 32-bit
     // per-lane offset, so no 64-bit address arithmetic runs on the vector unit inside the time loop.
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     load_env(st.pos, st.aux, st.ep_ret, i, P, e);
     int fail = 0;
     for (int t = 0; t < ra.T; ++t) {
-        const uint32_t fl = live_flags(P.flags);  // one SGPR; every uniform yes/no below is a bit test
+        const uint32_t fl = FL != 0 ? FL : live_flags(P.flags);  // one SGPR; every uniform yes/no below is a bit test
         const Rng R = make_rng(P, i, (unsigned long long)t);
         const long long row = (long long)t * P.n + blk0;  // uniform
         float af = 0.f, aa = 0.f;
@@ -414,6 +417,29 @@ static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams&
     });
 }
 
+// Flags words with a compile-time-specialised rollout kernel (mr_rollout_kernel<.., FL>): the DDPG rollout workload
+// (in-kernel policy, obs / rew / done / actions + episode return and length, status word, constant reward, goal
+// (0,0), symmetric bounds, auto-reset, [N][5] observations) and the same on a goal table with the goal reward
+// (the mixed trajectory set).  Same code as the generic kernel with every `fl &` test folded; anything else runs
+// the generic kernel.
+constexpr uint32_t kFlDdpg = kFAutoReset | kFSymBounds | kFObsAos | kFOutObs | kFOutRew | kFOutDone | kFOutActions |
+                             kFOutFinalRet | kFOutFinalLen | kFOutStatus;
+constexpr uint32_t kFlMixed = kFlDdpg | kFGoalTable | kFRewardGoal;
+
+template <uint32_t FL>
+static int launch_rollout_fl(const LaunchCfg& lc, int nz, bool mis, const KParams& K, const StateArgs& S,
+                             const RolloutArgs& ra, bool& handled) {
+    handled = true;
+    if (nz == kNoiseFast)
+        return mis ? launch(lc, mr_rollout_kernel<true, kNoiseFast, true, FL>, K.n, K, S, ra)
+                   : launch(lc, mr_rollout_kernel<true, kNoiseFast, false, FL>, K.n, K, S, ra);
+    if (nz == kNoiseSpec)
+        return mis ? launch(lc, mr_rollout_kernel<true, kNoiseSpec, true, FL>, K.n, K, S, ra)
+                   : launch(lc, mr_rollout_kernel<true, kNoiseSpec, false, FL>, K.n, K, S, ra);
+    handled = false;  // sigma == 0: generic kernel
+    return MRSIM_OK;
+}
+
 // kernel_ms != nullptr: own events, synchronise, report the duration.  ev_start/ev_stop != nullptr: caller's events,
 // attached to the dispatch, nothing synchronised.
 static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st, const MrsimStepIO* io,
@@ -567,9 +593,17 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     LaunchCfg lc{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
     if (kernel_ms != nullptr && (hipEventCreate(&lc.start) != hipSuccess || hipEventCreate(&lc.stop) != hipSuccess))
         return MRSIM_ELAUNCH;
-    rc = dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
-        return launch(lc, mr_rollout_kernel<decltype(RK)::value, decltype(NZ)::value, decltype(MIS)::value>, K.n, K, S, ra);
-    });
+    bool handled = false;
+    if (p->integrator == MRSIM_INT_RK45) {
+        const int nz = noise_variant(p);
+        const bool mis = p->mismatched != 0;
+        if (K.flags == kFlDdpg) rc = launch_rollout_fl<kFlDdpg>(lc, nz, mis, K, S, ra, handled);
+        else if (K.flags == kFlMixed) rc = launch_rollout_fl<kFlMixed>(lc, nz, mis, K, S, ra, handled);
+    }
+    if (!handled)
+        rc = dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
+            return launch(lc, mr_rollout_kernel<decltype(RK)::value, decltype(NZ)::value, decltype(MIS)::value>, K.n, K, S, ra);
+        });
     if (kernel_ms != nullptr) {
         if (rc == MRSIM_OK && (hipEventSynchronize(lc.stop) != hipSuccess ||
                                hipEventElapsedTime(kernel_ms, lc.start, lc.stop) != hipSuccess))

@@ -636,3 +636,34 @@ def test_event_attached_launch_times_the_kernel_without_blocking():
     ev.close()
     assert 0.0 < ms < 50.0 and 0.0 < o2["kernel_ms"] < 50.0
     np.testing.assert_array_equal(o1["obs"].cpu().numpy().view(np.uint32), o2["obs"].cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("math", ["fast", "spec"])
+@pytest.mark.parametrize("mis", [False, True])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_flag_specialised_rollout_kernels_equal_the_step_path(mixed, mis, math):
+    """When a launch's flags word is the DDPG-rollout pattern (or the same on a goal table with the goal reward) the
+    host picks a compile-time-specialised mr_rollout_kernel<.., FL>.  Same source, `fl &` tests folded: it has to give
+    the bits of the generic step kernel.  want=(obs, rew, done, actions) is exactly that pattern."""
+    n, T = 2500, 60
+    kw = dict(seed=21, noise_var=1.0, auto_reset=True, is_mismatched=mis, noise_math=math)
+    tab = None
+    if mixed:
+        rng = np.random.default_rng(4)
+        tab = rng.uniform(100, 120, (3, 52, 2)).astype(np.float32)
+        kw.update(reward_mode="goal", min_dist2goal=1.0)
+    torch, e1, _ = _mk(n, goal_table=tab, **kw)
+    torch, e2, _ = _mk(n, goal_table=tab, **kw)
+    e1.reset(); e2.reset()
+    out = e1.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
+    for t in range(T):
+        obs, rew, done, info = e2.step(None)
+        np.testing.assert_array_equal(out["obs"][t].cpu().numpy().view(np.uint32), obs.cpu().numpy().view(np.uint32))
+        np.testing.assert_array_equal(out["rew"][t].cpu().numpy(), rew.cpu().numpy())
+        np.testing.assert_array_equal(out["done"][t].cpu().numpy(), done.cpu().numpy())
+        np.testing.assert_array_equal(out["actions"][t].cpu().numpy(), e2.last_action.cpu().numpy())
+    np.testing.assert_array_equal(e1.pos.cpu().numpy().view(np.uint64), e2.pos.cpu().numpy().view(np.uint64))
+    np.testing.assert_array_equal(e1.aux.cpu().numpy().view(np.uint32), e2.aux.cpu().numpy().view(np.uint32))
+    np.testing.assert_array_equal(e1.final_ret.cpu().numpy(), e2.final_ret.cpu().numpy())
+    np.testing.assert_array_equal(e1.final_len.cpu().numpy(), e2.final_len.cpu().numpy())
+    e1.check_status()
