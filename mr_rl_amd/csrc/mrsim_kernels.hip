@@ -44,14 +44,16 @@ struct IOArgs {
 // ---------------------------------------------------------------------------
 // step
 // ---------------------------------------------------------------------------
-template <bool RK45, int NZ, bool MIS, bool AOS>
+// FL != 0: flags word known at compile time (see mr_rollout_kernel); kFStepBase is not part of it (step_words reads it
+// from P).
+template <bool RK45, int NZ, bool MIS, bool AOS, uint32_t FL = 0>
 __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const StateArgs st, const IOArgs io) {
     __shared__ __attribute__((aligned(16))) float s_obs[AOS ? kBlock * 5 : 4];
     const long long base = (long long)blockIdx.x * kBlock;
     const long long i = base + threadIdx.x;
     const bool active = i < P.n;
     StepOut o;
-    const uint32_t fl = P.flags;
+    const uint32_t fl = FL != 0 ? FL : P.flags;
     if (active) {
         EnvRegs e;
         load_env(st.pos, st.aux, st.ep_ret, i, P, e);
@@ -407,8 +409,15 @@ static int dispatch(bool rk45, int nz, bool mis, F&& f) {
     return rk45 ? with_nz(std::true_type{}) : with_nz(std::false_type{});
 }
 
+// the gym loop's launch pattern: actions from a policy, [N][5] observations, auto-reset with terminal outputs
+constexpr uint32_t kFlGym = kFAutoReset | kFSymBounds | kFObsAos | kFActions | kFOutFinalObs | kFOutFinalRet |
+                            kFOutFinalLen | kFOutStatus;
+
 static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams& K, const StateArgs& S, const IOArgs& IO) {
     const bool aos = p->obs_layout == MRSIM_OBS_AOS;
+    if ((K.flags & ~kFStepBase) == kFlGym && p->integrator == MRSIM_INT_RK45 && noise_variant(p) == kNoiseFast)
+        return p->mismatched ? launch(lc, mr_step_kernel<true, kNoiseFast, true, true, kFlGym>, K.n, K, S, IO)
+                             : launch(lc, mr_step_kernel<true, kNoiseFast, false, true, kFlGym>, K.n, K, S, IO);
     return dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
         constexpr bool rk = decltype(RK)::value, mis = decltype(MIS)::value;
         constexpr int nz = decltype(NZ)::value;

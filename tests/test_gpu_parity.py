@@ -667,3 +667,28 @@ def test_flag_specialised_rollout_kernels_equal_the_step_path(mixed, mis, math):
     np.testing.assert_array_equal(e1.final_ret.cpu().numpy(), e2.final_ret.cpu().numpy())
     np.testing.assert_array_equal(e1.final_len.cpu().numpy(), e2.final_len.cpu().numpy())
     e1.check_status()
+
+
+@pytest.mark.parametrize("mis", [False, True])
+def test_flag_specialised_step_kernel_equals_the_generic_one(mis):
+    """The gym loop's launch pattern (actions from a policy, no state_prime / actions_out tracking) selects
+    mr_step_kernel<.., FL>; a tracking env takes the generic instantiation.  Same bits, also across auto-resets."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    n, T = 3000, 60
+    mk = lambda **kw: MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True, is_mismatched=mis), seed=33, **kw)  # noqa: E731
+    e1, e2 = mk(), mk(track_state_prime=True, track_actions=True)
+    e1.reset(); e2.reset()
+    for t in range(T):
+        a = e1.random_policy()
+        o1, r1, d1, i1 = e1.step(a)
+        o2, r2, d2, i2 = e2.step(a.clone())
+        np.testing.assert_array_equal(o1.cpu().numpy().view(np.uint32), o2.cpu().numpy().view(np.uint32))
+        np.testing.assert_array_equal(d1.cpu().numpy(), d2.cpu().numpy())
+        np.testing.assert_array_equal(i1["final_obs"].cpu().numpy().view(np.uint32),
+                                      i2["final_obs"].cpu().numpy().view(np.uint32))
+    np.testing.assert_array_equal(e1.pos.cpu().numpy().view(np.uint64), e2.pos.cpu().numpy().view(np.uint64))
+    np.testing.assert_array_equal(e1.aux.cpu().numpy().view(np.uint32), e2.aux.cpu().numpy().view(np.uint32))
+    np.testing.assert_array_equal(e1.final_ret.cpu().numpy(), e2.final_ret.cpu().numpy())
+    assert (e1.final_len == 51).all()
+    e1.check_status()
