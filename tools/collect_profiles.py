@@ -54,8 +54,8 @@ for label, d, n in (("membench pattern<256> n=16777216", "cal", 16777216), ("mem
     out["calibration"][label] = {"known_read_KiB": n * 44 / 1024, "FETCH_SIZE_raw_KiB": fr, "FETCH_SIZE_x2_KiB": 2 * fr,
                                  "known_write_KiB": n * 61 / 1024, "WRITE_SIZE_KiB": wr}
 N = 262144
-for label, pre, sub, units in (("mr_rollout_kernel<RK45,fast,nominal> T=51 N=262144", "pmc", "mr_rollout_kernel<true, 2, false>", N * 51),
-                               ("mr_step_kernel<RK45,fast,nominal,aos> N=262144", "pmc_step", "mr_step_kernel<true, 2, false, true>", N)):
+for label, pre, sub, units in (("mr_rollout_kernel<RK45,fast,nominal> T=51 N=262144", "pmc", "mr_rollout_kernel<true, 2, false", N * 51),
+                               ("mr_step_kernel<RK45,fast,nominal,aos> N=262144", "pmc_step", "mr_step_kernel<true, 2, false, true", N)):
     fr, nf = counter_avg(f"{pre}_FETCH_SIZE", "FETCH_SIZE", sub)
     wr, nw = counter_avg(f"{pre}_WRITE_SIZE", "WRITE_SIZE", sub)
     if fr is None or wr is None:
