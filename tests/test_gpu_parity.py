@@ -692,3 +692,60 @@ def test_flag_specialised_step_kernel_equals_the_generic_one(mis):
     np.testing.assert_array_equal(e1.final_ret.cpu().numpy(), e2.final_ret.cpu().numpy())
     assert (e1.final_len == 51).all()
     e1.check_status()
+
+
+@pytest.mark.parametrize("mis", [False, True])
+def test_full_size_properties_config5_mixed_set(mis):
+    """BASELINE config 5's per-GPU shard (N = 262 144, mixed trajectory set, goal reward) through the fused rollout,
+    checked by properties that do not need the oracle at this size: the recorded rewards add up to the episode
+    returns the kernel reports, observations are consistent (obs[4] = |goal - pos|, goal = table[env mod 3][counter]),
+    rewards take only calculate_reward's values, done <=> (timeout or goal reached or out of bounds), and a shard of
+    the same run reproduces its rows (sharding invariance)."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    n, T = 262144, 51
+    rng = np.random.default_rng(11)
+    k = np.arange(52)
+    tab = np.zeros((3, 52, 2), dtype=np.float32)
+    tab[0, :, 0] = 110 + 0.3 * k; tab[0, :, 1] = 110 + 0.3 * k
+    th = 2 * np.pi * k / 52
+    tab[1, :, 0] = 110 + 8 * np.sin(th); tab[1, :, 1] = 110 + 8 * np.sin(th) * np.cos(th)
+    tab[2] = rng.uniform(100, 120, (52, 2))
+    cfg = lambda: MRConfig(noise_var=1.0, auto_reset=True, reward_mode="goal", min_dist2goal=1.0, is_mismatched=mis)  # noqa: E731
+    env = MRVecEnv(n, cfg=cfg(), seed=7, goal_table=tab)
+    env.reset()
+    out = env.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
+    obs, rew, done = out["obs"], out["rew"], out["done"]
+    env.check_status()
+    assert torch.isfinite(obs).all()
+    # rewards: only calculate_reward's three values (MR_env.py:118-134)
+    vals = torch.unique(rew)
+    assert set(vals.cpu().tolist()) <= {100.0, -100.0, np.float32(-0.1).item()}
+    # obs[4] is the distance between obs[0:2] and obs[2:4] wherever the env did not auto-reset in that step
+    nd = ~done
+    d = torch.sqrt((obs[..., 2] - obs[..., 0]) ** 2 + (obs[..., 3] - obs[..., 1]) ** 2)
+    assert torch.allclose(d[nd], obs[..., 4][nd], rtol=2e-6, atol=1e-5)
+    # goal of step t (counter t+1 for envs that have not reset yet) = table[env mod 3][counter]
+    alive = torch.cumsum(done.int(), 0) == 0  # no reset so far, this step included
+    tabd = torch.as_tensor(tab, device="cuda")
+    ids = torch.arange(n, device="cuda") % 3
+    for t in (0, 7, 30, 49):
+        g = tabd[ids, t + 1]
+        m = alive[t]
+        assert torch.equal(obs[t, :, 2:4][m], g[m])
+    # done <=> terminal reward; the last step of the launch is the timeout for every env that never reset before it
+    assert torch.equal(done, (rew == 100.0) | (rew == -100.0))
+    first = alive[T - 2]  # alive through step 50 -> times out at step 51
+    assert done[T - 1][first].all() and (rew[T - 1][first] == -100.0).sum() >= (first.sum() * 0.9)
+    # returns: for envs whose only episode end is the final step, final_ret = sum of the recorded rewards
+    only_last = first & (done.int().sum(0) == 1)
+    tot = rew.double().sum(0)
+    assert torch.allclose(env.final_ret[only_last].double(), tot[only_last], rtol=0, atol=1e-3)
+    assert (env.final_len[only_last] == 51).all()
+    # sharding invariance at full size: rows [k0, k0+m) from an independent shard env are the same bits
+    k0, m = 200003, 4099
+    sh = MRVecEnv(m, cfg=cfg(), seed=7, env_id0=k0, goal_table=tab)
+    sh.reset()
+    o2 = sh.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
+    assert torch.equal(o2["obs"], obs[:, k0:k0 + m]) and torch.equal(o2["rew"], rew[:, k0:k0 + m])
+    assert torch.equal(o2["actions"], out["actions"][:, k0:k0 + m])
