@@ -434,6 +434,7 @@ static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams&
 constexpr uint32_t kFlDdpg = kFAutoReset | kFSymBounds | kFObsAos | kFOutObs | kFOutRew | kFOutDone | kFOutActions |
                              kFOutFinalRet | kFOutFinalLen | kFOutStatus;
 constexpr uint32_t kFlMixed = kFlDdpg | kFGoalTable | kFRewardGoal;
+constexpr uint32_t kFlDdpgSoa = kFlDdpg & ~kFObsAos;  // the same with [T][5][N] observations
 
 template <uint32_t FL>
 static int launch_rollout_fl(const LaunchCfg& lc, int nz, bool mis, const KParams& K, const StateArgs& S,
@@ -608,6 +609,7 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
         const bool mis = p->mismatched != 0;
         if (K.flags == kFlDdpg) rc = launch_rollout_fl<kFlDdpg>(lc, nz, mis, K, S, ra, handled);
         else if (K.flags == kFlMixed) rc = launch_rollout_fl<kFlMixed>(lc, nz, mis, K, S, ra, handled);
+        else if (K.flags == kFlDdpgSoa) rc = launch_rollout_fl<kFlDdpgSoa>(lc, nz, mis, K, S, ra, handled);
     }
     if (!handled)
         rc = dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {

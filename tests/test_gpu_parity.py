@@ -640,7 +640,7 @@ def test_event_attached_launch_times_the_kernel_without_blocking():
 
 @pytest.mark.parametrize("math", ["fast", "spec"])
 @pytest.mark.parametrize("mis", [False, True])
-@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("mixed", [False, True, "soa"])
 def test_flag_specialised_rollout_kernels_equal_the_step_path(mixed, mis, math):
     """When a launch's flags word is the DDPG-rollout pattern (or the same on a goal table with the goal reward) the
     host picks a compile-time-specialised mr_rollout_kernel<.., FL>.  Same source, `fl &` tests folded: it has to give
@@ -648,7 +648,9 @@ def test_flag_specialised_rollout_kernels_equal_the_step_path(mixed, mis, math):
     n, T = 2500, 60
     kw = dict(seed=21, noise_var=1.0, auto_reset=True, is_mismatched=mis, noise_math=math)
     tab = None
-    if mixed:
+    if mixed == "soa":
+        kw.update(obs_layout="soa")
+    elif mixed:
         rng = np.random.default_rng(4)
         tab = rng.uniform(100, 120, (3, 52, 2)).astype(np.float32)
         kw.update(reward_mode="goal", min_dist2goal=1.0)
