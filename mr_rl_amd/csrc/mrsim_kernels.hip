@@ -214,21 +214,34 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         StepOut o;
         env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, af, aa, W, fl, o, fail);
         quantise_env(P, e);
-        if (fl & kFOutTraj) (reinterpret_cast<double2*>(ra.traj_xy) + row)[tid] = make_double2(o.px, o.py);
-        if (fl & kFOutStatePrime) (reinterpret_cast<float2*>(ra.state_prime_T) + row)[tid] = make_float2(o.spx0, o.spy0);
+        // The [T][N] outputs are write-once streams the kernel never reads back: non-temporal stores (+1 %)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        if (fl & kFOutTraj) {
+            const f64x2 v = {o.px, o.py};
+            __builtin_nontemporal_store(v, &(reinterpret_cast<f64x2*>(ra.traj_xy) + row)[tid]);
+        }
+        if (fl & kFOutStatePrime) {
+            const f32x2 v = {o.spx0, o.spy0};
+            __builtin_nontemporal_store(v, &(reinterpret_cast<f32x2*>(ra.state_prime_T) + row)[tid]);
+        }
         if (fl & kFOutObs) {
             if (fl & kFObsAos) {
                 float* __restrict__ b = ra.obs_T + row * 5;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) b[tid * 5u + j] = o.obs[j];
+                for (int j = 0; j < 5; ++j) __builtin_nontemporal_store(o.obs[j], &b[tid * 5u + j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 5; ++j) (ra.obs_T + ((long long)t * 5 + j) * P.n + blk0)[tid] = o.obs[j];
+                for (int j = 0; j < 5; ++j)
+                    __builtin_nontemporal_store(o.obs[j], &(ra.obs_T + ((long long)t * 5 + j) * P.n + blk0)[tid]);
             }
         }
-        if (fl & kFOutRew) (ra.rew_T + row)[tid] = o.rew;
-        if (fl & kFOutDone) (ra.done_T + row)[tid] = o.done;
-        if (fl & kFOutActions) (reinterpret_cast<float2*>(ra.actions_out_T) + row)[tid] = make_float2(af, aa);
+        if (fl & kFOutRew) __builtin_nontemporal_store(o.rew, &(ra.rew_T + row)[tid]);
+        if (fl & kFOutDone) __builtin_nontemporal_store(o.done, &(ra.done_T + row)[tid]);
+        if (fl & kFOutActions) {
+            const f32x2 v = {af, aa};
+            __builtin_nontemporal_store(v, &(reinterpret_cast<f32x2*>(ra.actions_out_T) + row)[tid]);
+        }
         if (o.has_final) {  // return / length of the episode that just ended (latest one wins)
             if (fl & kFOutFinalRet) ra.final_ret[i] = o.fret;
             if (fl & kFOutFinalLen) ra.final_len[i] = o.flen;
