@@ -38,7 +38,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=51000)   # 1000 episodes
-    ap.add_argument("--warmup", type=int, default=5100)
+    ap.add_argument("--warmup", type=int, default=10200)   # 200 episodes = 35 ms: the GPU clocks have settled (tools/clock_ramp_probe.py)
     ap.add_argument("--envs-per-gpu", type=int, default=262144)
     ap.add_argument("--mode", choices=["rollout", "step"], default="rollout")
     ap.add_argument("--rollout-len", type=int, default=51)
