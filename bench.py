@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--workload", choices=["ddpg", "mixed"], default="ddpg",
                     help="ddpg = BASELINE config 4 (default); mixed = config 5's trajectory set: goal = reference-"
                          "trajectory table[env_id mod 3] (straight line / figure-eight / random), tracking reward")
+    ap.add_argument("--settle-episodes", type=int, default=400,
+                    help="untimed episodes before the W warm-up steps so that the GPU clocks have settled whatever W "
+                         "is (a fixed count, not a time: every rank must issue the same collectives)")
     ap.add_argument("--no-step-path", action="store_true", help="skip the extra one-launch-per-step measurement")
     ap.add_argument("--no-mixed-set", action="store_true", help="skip the extra mixed-trajectory-set measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
@@ -334,6 +337,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # clock settle (tools/clock_ramp_probe.py: ~35 ms of load after idle), independent of the W the caller asks for
+    run(args.settle_episodes * ep)
     run(W)
     barrier()
     if args.mode == "rollout":
