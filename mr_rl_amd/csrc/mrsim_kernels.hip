@@ -182,6 +182,26 @@ struct RolloutArgs {
     int32_t* status;
 };
 
+// Issue priority of this wave for time step t of a multi-step kernel.  The four waves that share a SIMD otherwise
+// run strictly oldest-first: measured per-wave durations of one 51-step launch at N = 262 144 (one resident round,
+// tools/wave_time_probe.py history in DESIGN.md section 7) were 72 / 96 / 126 / 155 us for wave slots 0..3, i.e. the
+// SIMD spends the last third of the kernel with one or two waves.  Rotating s_setprio by (t + hardware wave slot)
+// keeps the slots' priorities distinct at any time and gives each of them every level once per four steps: the
+// waves finish within 108..137 us and the kernel in 147 instead of 157 us (+6 %).  (Exactly equal progress, enforced
+// through an LDS progress board in 1024-thread blocks, was NOT faster, 153 us: lockstep waves contend for the same
+// quarter-rate unit -- multiplier, fp64, transcendental -- at the same time.)
+__device__ __forceinline__ unsigned hw_wave_slot() {
+    return __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((4 - 1) << 11));  // WAVE_ID = bits 3:0
+}
+__device__ __forceinline__ void rotate_wave_priority(unsigned t, unsigned slot) {
+    switch ((t + slot) & 3u) {  // s_setprio takes an immediate
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 // FL != 0: the launch's flags word is known at compile time (the host picks such an instantiation when K.flags
 // matches one of the common configurations): every optional path below folds away, which frees the scalar
 // registers their pointers and constants would occupy.  FL == 0: generic kernel, flags read from P.
@@ -194,9 +214,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     const long long i = blk0 + tid;
     if (i >= P.n) return;
     EnvRegs e;
+#ifdef MRSIM_WAVE_PROBE
+    const unsigned long long clk0 = wall_clock64();
+#endif
     load_env(st.pos, st.aux, st.ep_ret, i, P, e);
     int fail = 0;
+    const unsigned slot = hw_wave_slot();
     for (int t = 0; t < ra.T; ++t) {
+        rotate_wave_priority((unsigned)t, slot);
         const uint32_t fl = FL != 0 ? FL : live_flags(P.flags);  // one SGPR; every uniform yes/no below is a bit test
         const Rng R = make_rng(P, i, (unsigned long long)t);
         const long long row = (long long)t * P.n + blk0;  // uniform
@@ -249,6 +274,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     }
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
     if (fail && (P.flags & kFOutStatus)) atomicOr(ra.status, fail);
+#ifdef MRSIM_WAVE_PROBE
+    // measurement build only (make CXXFLAGS+=-DMRSIM_WAVE_PROBE, tools/wave_time_probe.py): lane 0 of every wave
+    // overwrites four final_len entries with its duration (100 MHz ticks), XCC id, HW_ID and start time
+    if (ra.final_len != nullptr && (tid & 63u) == 0) {
+        const unsigned long long clk1 = wall_clock64();
+        ra.final_len[i + 0] = (int)(clk1 - clk0);
+        ra.final_len[i + 1] = (int)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | ((32 - 1) << 11));
+        ra.final_len[i + 2] = (int)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | ((32 - 1) << 11));
+        ra.final_len[i + 3] = (int)(clk0 & 0x7fffffff);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
