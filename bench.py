@@ -419,7 +419,8 @@ def main():
                   "noise_math": args.noise_math, "sigma": args.sigma, "seed": seed,
                   "is_mismatched": bool(args.mismatched),
                   "mean_episode_return": mean_ret,
-                  "returns_allgather": "rccl every 51 steps" if world > 1 else "local"}
+                  "returns_allgather": ("%s all_gather_into_tensor (%s) every 51 steps"
+                                        % (args.dist_backend, gatherer.mode)) if world > 1 else "local"}
         config.update(launch_desc)
         out = {"metric": "env-steps/sec at N parallel envs; trajectory RMSE vs CPU ref", "value": value, "unit": "env-steps/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3,

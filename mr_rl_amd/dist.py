@@ -84,6 +84,7 @@ class ReturnGatherer:
         self._all = [torch.zeros(self.world * n, dtype=torch.float32, device=env.device) for _ in range(2)]
         self._pending = [None, None]
         self.n_gathers = 0
+        self.mode = "async"  # "async" -> "sync" if the backend rejects async_op (decided once, at the first gather)
 
     def _distributed(self):
         import torch.distributed as dist
@@ -101,9 +102,19 @@ class ReturnGatherer:
         self._stage[k].copy_(self.env.final_ret)
         if dist.get_backend(self.group) == "gloo" and self._stage[k].is_cuda:
             gather_returns(self._stage[k], out=self._all[k], group=self.group)  # rehearsal path, synchronous
+        elif self.mode == "async":
+            try:
+                self._pending[k] = dist.all_gather_into_tensor(self._all[k], self._stage[k], group=self.group,
+                                                               async_op=True)
+            except (RuntimeError, TypeError, NotImplementedError) as exc:
+                # Every rank runs the same backend, so every rank takes this branch at the same (first) gather.
+                import sys
+                print(f"[mr_rl_amd.dist] async all_gather_into_tensor unavailable ({exc}); using the blocking form",
+                      file=sys.stderr, flush=True)
+                self.mode = "sync"
+                dist.all_gather_into_tensor(self._all[k], self._stage[k], group=self.group)
         else:
-            self._pending[k] = dist.all_gather_into_tensor(self._all[k], self._stage[k], group=self.group,
-                                                           async_op=True)
+            dist.all_gather_into_tensor(self._all[k], self._stage[k], group=self.group)
         self.n_gathers += 1
 
     def latest(self):
