@@ -270,7 +270,7 @@ def main():
     env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0, goal_table=goal_table)
     env.reset()
     gatherer = ReturnGatherer(env, world)
-    K, W = args.steps, args.warmup
+    K, W = max(args.steps, 1), max(args.warmup, 0)
     ep = cfg.max_timesteps + 1
     done_steps = [0]
     WANT = ("obs", "rew", "done", "actions")
@@ -411,7 +411,7 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
-        value = total * K / el
+        value = total * K / max(el, 1e-12)
         config = {"workload": "BASELINE config 4: DDPG rollout, uniform random policy in the actor range drawn on "
                               "device, sigma=%g, integrator=reference(RK45), reward+done on device, auto-reset, all "
                               "transitions written to HBM" % args.sigma,
@@ -423,7 +423,7 @@ def main():
                                         % (args.dist_backend, gatherer.mode)) if world > 1 else "local"}
         config.update(launch_desc)
         out = {"metric": "env-steps/sec at N parallel envs; trajectory RMSE vs CPU ref", "value": value, "unit": "env-steps/s",
-               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / K * 1e3,
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / max(K, 1) * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic", "config": config, "roofline": roof, "cpu_baseline": cpu}
         if rmse is not None:
