@@ -218,6 +218,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     const unsigned long long clk0 = wall_clock64();
 #endif
     load_env(st.pos, st.aux, st.ep_ret, i, P, e);
+    // Consume the loaded state HERE.  Otherwise its first uses sit inside the time loop and so does their
+    // s_waitcnt vmcnt(0) -- which, executed every iteration, also waits for the previous step's stores (on gfx9
+    // stores count in vmcnt): each wave stalled for a store round trip per step (SQ_WAIT_ANY 16 % of wave time).
+    asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.f0x), "+v"(e.f0y), "+v"(e.h_abs), "+v"(e.counter), "+v"(e.ep_ret));
     int fail = 0;
     const unsigned slot = hw_wave_slot();
     for (int t = 0; t < ra.T; ++t) {
