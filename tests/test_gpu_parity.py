@@ -751,3 +751,34 @@ def test_full_size_properties_config5_mixed_set(mis):
     o2 = sh.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
     assert torch.equal(o2["obs"], obs[:, k0:k0 + m]) and torch.equal(o2["rew"], rew[:, k0:k0 + m])
     assert torch.equal(o2["actions"], out["actions"][:, k0:k0 + m])
+
+
+@pytest.mark.parametrize("math,mis", [("fast", False), ("spec", False), ("fast", True)])
+def test_full_size_rollout_vs_oracle_config4(math, mis):
+    """BASELINE config 4 at its FULL size against the oracle itself (the GPU box's host cores make that a matter of
+    seconds): 262 144 envs, sigma = 1, random policy drawn on device, one whole episode + the auto-reset step through
+    the fused (flag-specialised) rollout kernel; the oracle steps the same envs with the same Philox policy.
+    Every action bit-equal, every observation / reward / done of all 52 steps compared, final state to POS_TOL."""
+    n, T = 262144, 52
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    tol = POS_TOL if math == "spec" else POS_TOL_FAST
+    torch, env, _ = _mk(n, seed=7, noise_var=1.0, auto_reset=True, noise_math=math, is_mismatched=mis)
+    orc = O.VecOracle(n, orc_params_from_cfg(env.cfg), seed=7, threads=threads)
+    og = env.reset(); oo = orc.reset(0)
+    _f32_close(og.cpu().numpy(), oo, extra=0)
+    out = env.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
+    obs, rew, done, act = (out[k].cpu().numpy() for k in ("obs", "rew", "done", "actions"))
+    for t in range(T):
+        a = orc.random_policy(t + 1, env.cfg.policy_low, env.cfg.policy_high)
+        np.testing.assert_array_equal(act[t], a)
+        orc.step(a, step_idx=t + 1)
+        np.testing.assert_array_equal(done[t].astype(np.uint8), orc.done)
+        np.testing.assert_array_equal(rew[t], orc.rew.astype(np.float32))
+        _f32_close(obs[t], orc.obs, extra=tol)
+    assert done[50].all() and not done[:50].any() and not done[51].any()   # every episode is 51 steps (SURVEY 3.6)
+    np.testing.assert_allclose(env.pos.cpu().numpy(), orc.envs["y"], rtol=0, atol=tol)
+    np.testing.assert_array_equal(env.counter.cpu().numpy(), orc.envs["counter"])
+    np.testing.assert_array_equal(env.final_len.cpu().numpy(), orc.final_len)
+    np.testing.assert_allclose(env.final_ret.cpu().numpy(), orc.final_ret, rtol=1e-6)
+    assert (orc.envs["n_attempts"] == 1).mean() > 0.999
+    env.check_status()
