@@ -782,3 +782,37 @@ def test_full_size_rollout_vs_oracle_config4(math, mis):
     np.testing.assert_allclose(env.final_ret.cpu().numpy(), orc.final_ret, rtol=1e-6)
     assert (orc.envs["n_attempts"] == 1).mean() > 0.999
     env.check_status()
+
+
+def test_full_size_rollout_vs_oracle_config5_shard():
+    """One rank's shard of BASELINE config 5 (262 144 envs of the mixed trajectory set, goal reward, global env ids
+    offset as on rank 3 of 8) element-wise against the oracle over one episode + the auto-reset step."""
+    n, T, id0 = 262144, 52, 3 * 262144
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    k = np.arange(52)
+    tab = np.zeros((3, 52, 2), dtype=np.float32)
+    tab[0, :, 0] = 110 + 0.3 * k; tab[0, :, 1] = 110 + 0.3 * k
+    th = 2 * np.pi * k / 52
+    tab[1, :, 0] = 110 + 8 * np.sin(th); tab[1, :, 1] = 110 + 8 * np.sin(th) * np.cos(th)
+    tab[2] = np.random.default_rng(7).uniform(100, 120, (52, 2))
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    cfg = MRConfig(noise_var=1.0, auto_reset=True, reward_mode="goal", min_dist2goal=1.0)
+    env = MRVecEnv(n, cfg=cfg, seed=7, env_id0=id0, goal_table=tab)
+    orc = O.VecOracle(n, orc_params_from_cfg(cfg, 3, 52), seed=7, env_id0=id0, goal_table=tab, threads=threads)
+    og = env.reset(); oo = orc.reset(0)
+    _f32_close(og.cpu().numpy(), oo, extra=0)
+    out = env.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
+    obs, rew, done, act = (out[q].cpu().numpy() for q in ("obs", "rew", "done", "actions"))
+    for t in range(T):
+        a = orc.random_policy(t + 1, cfg.policy_low, cfg.policy_high)
+        np.testing.assert_array_equal(act[t], a)
+        orc.step(a, step_idx=t + 1)
+        np.testing.assert_array_equal(done[t].astype(np.uint8), orc.done)
+        np.testing.assert_array_equal(rew[t], orc.rew.astype(np.float32))
+        _f32_close(obs[t], orc.obs, extra=POS_TOL_FAST)
+    np.testing.assert_allclose(env.pos.cpu().numpy(), orc.envs["y"], rtol=0, atol=POS_TOL_FAST)
+    np.testing.assert_array_equal(env.final_len.cpu().numpy(), orc.final_len)
+    np.testing.assert_allclose(env.final_ret.cpu().numpy(), orc.final_ret, rtol=1e-5, atol=1e-3)
+    assert set(np.unique(rew).tolist()) <= {100.0, -100.0, float(np.float32(-0.1))}
+    env.check_status()
