@@ -816,3 +816,45 @@ def test_full_size_rollout_vs_oracle_config5_shard():
     np.testing.assert_allclose(env.final_ret.cpu().numpy(), orc.final_ret, rtol=1e-5, atol=1e-3)
     assert set(np.unique(rew).tolist()) <= {100.0, -100.0, float(np.float32(-0.1))}
     env.check_status()
+
+
+def test_full_size_configs_2_and_3_vs_oracle():
+    """BASELINE configs 2 and 3 at their full sizes, every step of every env against the oracle.
+    Config 2: 4096 envs, Euler 30 x 1e-3, sigma = 0, alpha-ramp actions, T = 1000 (fp64 state: <= 1e-10).
+    Config 3: 65 536 envs, RK4 x 4 sub-steps, sigma = 0.5, figure-eight action table, tracking goal table, T = 1000."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.rollout import actions_figure8 as af8, goal_table_from_actions
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    T = 1000
+    # ---- config 2
+    n = 4096
+    cfg = MRConfig(noise_var=0.0, integrator="euler", substeps=30)
+    env = MRVecEnv(n, cfg=cfg, seed=1234)
+    orc = O.VecOracle(n, orc_params_from_cfg(cfg), seed=1234, threads=threads)
+    env.reset(); orc.reset(0)
+    acts = actions_ramp(T)
+    traj = env.rollout(T, actions=acts, shared_actions=True, want=("traj",))["traj"].cpu().numpy()
+    for t in range(T):
+        orc.step(np.tile(acts[t][None, :], (n, 1)), step_idx=t + 1)
+        assert np.abs(traj[t] - orc.envs["y"]).max() <= 1e-10
+    # ---- config 3
+    n = 65536
+    acts = af8(T)[:, :2].astype(np.float32)
+    goal = goal_table_from_actions(acts, init=(0.0, 0.0), a0=1.0)
+    cfg = MRConfig(noise_var=0.5, integrator="rk4", substeps=4, reward_mode="goal", min_dist2goal=1.0)
+    env = MRVecEnv(n, cfg=cfg, seed=2024, goal_table=goal)
+    gK, gT = env._gK, env._gT
+    orc = O.VecOracle(n, orc_params_from_cfg(cfg, gK, gT), seed=2024, goal_table=goal, threads=threads)
+    init = np.zeros((n, 2))
+    env.reset(init=init); orc.reset(0, init_xy=init)
+    out = env.rollout(T, actions=acts, shared_actions=True, want=("traj", "rew", "done"))
+    traj, rew, done = out["traj"].cpu().numpy(), out["rew"].cpu().numpy(), out["done"].cpu().numpy()
+    worst = 0.0
+    for t in range(T):
+        orc.step(np.tile(acts[t][None, :], (n, 1)), step_idx=t + 1)
+        worst = max(worst, float(np.abs(traj[t] - orc.envs["y"]).max()))
+        np.testing.assert_array_equal(done[t].astype(np.uint8), orc.done)
+        np.testing.assert_array_equal(rew[t], orc.rew.astype(np.float32))
+    assert worst <= POS_TOL_FAST, worst
+    env.check_status()
