@@ -13,16 +13,27 @@ seed 7.  One "step" = one MR_Env.step() of all N envs.
 --mode step: one launch per env.step() (the drop-in gym loop): [policy kernel -> actions in HBM] +
     [step kernel], captured as a hipGraph of --graph-len steps.
 
-With --gpus N>1 every rank owns a contiguous shard of N x 262144 envs (weak scaling), there is no
-data-path collective, and episode returns are all-gathered over RCCL at episode boundaries (every
-51 steps) inside the timed region.
+--gpus N > 1: this process starts N rank processes itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in their environment, rendezvous on 127.0.0.1) BEFORE anything touches the GPU, relays rank 0's
+JSON line and exits non-zero if any rank does.  Under a launcher that already set WORLD_SIZE (the driver's
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) it is a rank.  Every rank owns
+a contiguous shard of N x 262144 envs (weak scaling), there is no data-path collective, and episode
+returns are all-gathered over RCCL at episode boundaries (every 51 steps) inside the timed region.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel of the chosen mode) and
-`cpu_baseline` objects.
+Prints ONE JSON line on rank 0.  Besides the contract's fields:
+  roofline      the dominant kernel against the resource that binds it.  Rollout mode: bound = "valu" (vector-issue
+                floor of the kernel's measured instruction mix, profiles/rNN/pmc_valu.json) with the HBM fraction of
+                the bytes it really moves (`hbm_frac`, traffic from profiles/rNN/pmc_traffic.json) beside it; SURVEY
+                8(d)'s algorithmic 97 B/env-step figure is kept as the labelled `algorithmic_equiv`, never as `frac`.
+  sustained     the same workload over its own >= 10 200-step region, whatever --steps was (a 20-step timed region is
+                ONE launch and is launch-latency-bound); kernel durations come from HIP events attached to that
+                region's dispatches.
+  cpu_baseline  the oracle (C restatement) on this box's host cores.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,9 +43,25 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_PER_ENV_STEP = 97   # fp64 positions -> reads 40 + writes 57 per env-step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS = 1024                   # 256 CUs x 4 SIMDs
+
+_T0 = time.perf_counter()
 
 
-def parse():
+def trace(msg):
+    """phase markers on stderr (MRSIM_BENCH_TRACE=1): where a profiled run is when something goes wrong"""
+    if os.environ.get("MRSIM_BENCH_TRACE"):
+        print("[bench +%.3fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def under_pmc():
+    """rocprofv3 --pmc exports ROCPROF_COUNTER_COLLECTION to the profiled process.  hipGraph capture / replay under
+    counter collection crashes the profiler (ROCm 7.2: SIGSEGV in its collection thread -- the root cause of round 1's
+    stale pmc_traffic.json, found with tools/pmc_bisect.sh), so graph legs are skipped there and the JSON says so."""
+    return bool(os.environ.get("ROCPROF_COUNTER_COLLECTION"))
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=51000)   # 1000 episodes
@@ -42,6 +69,10 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=262144)
     ap.add_argument("--mode", choices=["rollout", "step"], default="rollout")
     ap.add_argument("--rollout-len", type=int, default=51)
+    ap.add_argument("--carry", choices=["f32", "f64"], default="f64",
+                    help="rollout mode, carried RK45 state (integrator.f, h_abs) inside a launch: f64 registers (default; "
+                         "what the reference carries) or rounded to its fp32 HBM format every step (bit-identical to "
+                         "the step path)")
     ap.add_argument("--policy", choices=["kernel", "fused"], default="kernel", help="step mode only")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph", help="step mode only")
     ap.add_argument("--graph-len", type=int, default=51)
@@ -58,13 +89,93 @@ def parse():
     ap.add_argument("--settle-episodes", type=int, default=400,
                     help="untimed episodes before the W warm-up steps so that the GPU clocks have settled whatever W "
                          "is (a fixed count, not a time: every rank must issue the same collectives)")
+    ap.add_argument("--sustained-steps", type=int, default=10200, help="length of the `sustained` leg (0 = skip)")
     ap.add_argument("--no-step-path", action="store_true", help="skip the extra one-launch-per-step measurement")
     ap.add_argument("--no-mixed-set", action="store_true", help="skip the extra mixed-trajectory-set measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="--gpus N launcher: rendezvous port (0 = pick a free one)")
+    return ap.parse_args(argv)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# --gpus N launcher (no GPU / torch.cuda call on this path: a process that has touched the GPU must never be re-executed)
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rank_commands(n_ranks, argv, port, python=None, script=None, base_env=None):
+    """argv / environment of the N rank processes `bench.py --gpus N` starts: [(cmd, env), ...] -- rank r gets
+    RANK = LOCAL_RANK = r, WORLD_SIZE = LOCAL_WORLD_SIZE = N and a rendezvous on 127.0.0.1:port."""
+    cmd = [python or sys.executable, script or os.path.abspath(__file__)] + list(argv)
+    out = []
+    for r in range(n_ranks):
+        env = dict(os.environ if base_env is None else base_env)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                    "MRSIM_BENCH_LAUNCHER": "bench.py"})
+        out.append((cmd, env))
+    return out
+
+
+def launch_ranks(args, argv):
+    """Parent of `bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment): start the N ranks as fresh child
+    processes, relay rank 0's stdout (the JSON line), wait for all, return the first non-zero exit code."""
+    import tempfile
+    ensure_built()
+    port = args.master_port or _free_port()
+    procs = []
+    out0 = tempfile.TemporaryFile()
+    for r, (cmd, env) in enumerate(rank_commands(args.gpus, argv, port)):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(len(procs)))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print("[bench launcher] rank %d exited with code %d; stopping the other ranks" % (r, code),
+                          file=sys.stderr, flush=True)
+                    for q in pending:
+                        procs[q].terminate()  # exactly the children started above
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+def ensure_built():
+    lib_so = os.path.join(ROOT, "mr_rl_amd", "libmrsim.so")
+    if os.path.exists(lib_so):
+        return
+    # git-ignored build product missing in this checkout: build it (no fallback path)
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        import __graft_entry__
+        __graft_entry__.build()
+    else:
+        t_wait = time.time()
+        while not os.path.exists(lib_so) and time.time() - t_wait < 600:
+            time.sleep(1.0)
+        time.sleep(2.0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(cfg, seed, target_seconds):
     """The oracle (C restatement, kind "port") timed on this box's host cores on a bounded sample of
     the same workload: n_cpu envs, same config, random policy, auto-reset."""
@@ -93,26 +204,54 @@ def cpu_baseline(cfg, seed, target_seconds):
                       f"with OpenMP over {threads} host threads"}
 
 
+def newest_profile(name):
+    import glob
+    f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)), reverse=True)
+    return f[0] if f else None
+
+
+def profiled_config_matches(args, n_local):
+    """PMC counters cannot be read from inside the timed process: the committed passes describe ONE configuration
+    (the default one); any other run gets null instead of somebody else's counters."""
+    return (args.sigma == 1.0 and args.noise_math == "fast" and n_local == 262144 and args.obs_layout == "aos"
+            and args.workload == "ddpg" and not args.mismatched and (args.mode == "step" or args.rollout_len == 51))
+
+
 def committed_traffic(args, n_local):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes
     (profiles/rNN/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
-    same command and corrected as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from
-    inside the timed process, so this is null unless the run matches the profiled configuration."""
-    import glob
-    if not (args.sigma == 1.0 and args.noise_math == "fast" and n_local == 262144 and args.obs_layout == "aos"
-            and args.workload == "ddpg"):
+    same command and corrected as MI355X_MICROARCH.md prescribes)."""
+    f = newest_profile("pmc_traffic.json")
+    if f is None or not profiled_config_matches(args, n_local):
         return None, None
     key = "mr_rollout_kernel" if args.mode == "rollout" else "mr_step_kernel"
-    if args.mode == "rollout" and args.rollout_len != 51:
-        return None, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
-        try:
-            for name, k in json.load(open(f))["kernels"].items():
-                if name.startswith(key):
-                    return int(k["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
-        except Exception:
-            continue
+    try:
+        for name, k in json.load(open(f))["kernels"].items():
+            if name.startswith(key) and (args.mode == "step" or k.get("carry", "f32") == args.carry):
+                return int(k["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+    except Exception:
+        pass
     return None, None
+
+
+def committed_valu_floor(args, n_local, T):
+    """Vector-issue floor of one launch, from the committed instruction mix of the rollout kernel (rocprofv3 --pmc
+    SQ_INSTS_VALU_* per wave-step, profiles/rNN/pmc_valu.json) priced with the per-instruction issue costs measured by
+    tools/instbench at the occupancy the launch runs at: floor = sum_class n_class x cost_class x waves per SIMD x T."""
+    f = newest_profile("pmc_valu.json")
+    if f is None or args.mode != "rollout" or not profiled_config_matches(args, n_local):
+        return None
+    try:
+        d = json.load(open(f))
+        k = d["kernels"]["rollout_" + args.carry]
+        waves_per_simd = n_local / 64.0 / SIMDS
+        floor_us = k["issue_floor_ns_per_wave_step"] * waves_per_simd * T * 1e-3
+        return {"floor_us_per_launch": round(floor_us, 3), "insts_valu_per_wave_step": k["insts_valu_per_wave_step"],
+                "issue_floor_ns_per_wave_step": k["issue_floor_ns_per_wave_step"],
+                "waves_per_simd": waves_per_simd, "costs": d["issue_costs"]["source"],
+                "source": os.path.relpath(f, ROOT)}
+    except Exception:
+        return None
 
 
 def measure_step_path(cfg, n_local, dev, seed, steps=10200, samples=204):
@@ -159,12 +298,65 @@ def mixed_goal_table(cfg, seed):
     return tab
 
 
-def measure_mixed_set(args, n_local, env_id0, world, dev, seed, barrier, steps=10200):
+class RolloutRegion:
+    """Timed regions of the fused-rollout workload: `steps` env steps in launches of <= T cut at episode boundaries,
+    returns all-gathered at every episode boundary, barrier + synchronize on both sides, max over ranks.  Rank 0 can
+    attach a HIP event pair to every full-length dispatch (non-blocking, hipExtLaunchKernelGGL on the launch stream)."""
+
+    def __init__(self, env, gatherer, T, ep, want, world, dev, dist_backend, carry):
+        self.env, self.g, self.T, self.ep, self.want = env, gatherer, T, ep, want
+        self.world, self.dev, self.backend, self.carry = world, dev, dist_backend, carry
+        self.bufs = {}
+        self.done_steps = 0
+        self.launches = 0
+
+    def run(self, nsteps, pool=None, used=None):
+        env, T, ep = self.env, self.T, self.ep
+        left = nsteps
+        while left > 0:
+            chunk = min(left, T, ep - (self.done_steps % ep))
+            ev = None
+            if pool is not None and chunk == T and len(used) < len(pool):
+                ev = pool[len(used)]
+                used.append(ev)
+            env.rollout(chunk, actions=None, want=self.want, out=self.bufs if chunk == T else None, events=ev,
+                        carry=self.carry)
+            self.launches += 1
+            self.done_steps += chunk
+            left -= chunk
+            if self.done_steps % ep == 0:
+                self.g.gather()  # RCCL all-gather of this episode's returns
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(self.dev)
+
+    def timed(self, nsteps, pool=None, used=None):
+        """-> (seconds: max over ranks, launches in the region)"""
+        import torch
+        import torch.distributed as dist
+        self.barrier()
+        l0 = self.launches
+        t0 = time.perf_counter()
+        self.run(nsteps, pool, used)
+        self.g.finish()  # outstanding async all-gathers belong to the timed region
+        torch.cuda.synchronize(self.dev)
+        self.barrier()
+        el = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, self.launches - l0
+
+
+def measure_mixed_set(args, n_local, env_id0, world, dev, seed, steps=10200):
     """Secondary figure (every rank takes part, same barrier / max-over-ranks protocol as the headline): the fused
     rollout on BASELINE config 5's mixed straight-line / figure-eight / random-waypoint trajectory set with the
     goal reward, returns all-gathered once per episode."""
-    import torch
-    import torch.distributed as dist
     from mr_rl_amd import MRConfig, MRVecEnv
     from mr_rl_amd.dist import ReturnGatherer
     cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math,
@@ -174,68 +366,59 @@ def measure_mixed_set(args, n_local, env_id0, world, dev, seed, barrier, steps=1
     env.reset()
     g = ReturnGatherer(env, world)
     ep = cfg.max_timesteps + 1
-    bufs = {}
-    want = ("obs", "rew", "done", "actions")
-
-    def run(n_ep):
-        for _ in range(n_ep):
-            env.rollout(ep, actions=None, want=want, out=bufs)
-            g.gather()
-
-    run(20)
-    barrier()
-    t0 = time.perf_counter()
-    run(steps // ep)
-    g.finish()
-    torch.cuda.synchronize(dev)
-    barrier()
-    el = time.perf_counter() - t0
-    t = torch.tensor([el], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
+    reg = RolloutRegion(env, g, ep, ep, ("obs", "rew", "done", "actions"), world, dev, args.dist_backend, args.carry)
+    reg.run(20 * ep)
     k = (steps // ep) * ep
+    el, launches = reg.timed(k)
     env.check_status()
     return {"workload": "BASELINE config 5 trajectory set: env_id mod 3 -> straight line / figure eight / random "
                         "waypoints (goal table), goal reward, same policy / noise / outputs as the headline",
-            "value": n_local * world * k / el, "unit": "env-steps/s", "steps": k, "ms_per_step": el / k * 1e3,
-            "mean_episode_return": g.last_mean()}
+            "value": n_local * world * k / el, "unit": "env-steps/s", "steps": k, "launches": launches,
+            "ms_per_step": el / k * 1e3, "mean_episode_return": g.last_mean()}
 
 
-def trajectory_rmse(dev):
+def trajectory_rmse(dev, carry):
     """Second half of BASELINE's metric: trajectory RMSE vs the CPU reference, on the committed golden trajectories
     the reference itself produced (tests/golden/ref_sim.npz, sigma = 0, 1000-2000 steps each), through the same
-    fused kernel the timed region runs."""
+    fused kernel the timed region runs.  `value` feeds the reference float32-rounded action tables (what the golden
+    files recorded the reference with); `f64_tables` feeds the reference's own float64 tables (ref_sim_f64.npz, the
+    main.py:14-50 profiles unrounded) through the fp64 action-table input of the rollout."""
     import numpy as np
     from mr_rl_amd import MRConfig, MRVecEnv
-    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_sim.npz"))
-    names = sorted({k.split("/")[0] for k in g.files})
-    worst, per = 0.0, {}
-    for name in names:
-        G = {k.split("/")[1]: g[k] for k in g.files if k.startswith(name + "/")}
-        env = MRVecEnv(64, cfg=MRConfig(noise_var=0.0, a0=float(G["a0"]), is_mismatched=bool(G["mismatched"])), device=dev)
-        env._prev_mismatched = bool(G["mismatch_at_reset"])
-        env.reset(init=np.tile(G["init"][None, :], (64, 1)), is_mismatched=bool(G["mismatched"]))
-        traj = env.rollout(len(G["actions"]), actions=G["actions"].astype(np.float32), shared_actions=True,
-                           want=("traj",))["traj"][:, 0, :].cpu().numpy()
-        per[name] = float(np.sqrt(np.mean(np.sum((traj - G["pos"]) ** 2, axis=1))))
-        worst = max(worst, per[name])
-    return {"value": worst, "unit": "position units (max over %d golden trajectories)" % len(names), "target": 1e-5,
-            "fixtures": "tests/golden/ref_sim.npz"}
+
+    def run(fname, f64):
+        g = np.load(os.path.join(ROOT, "tests", "golden", fname))
+        names = sorted({k.split("/")[0] for k in g.files})
+        worst = 0.0
+        for name in names:
+            G = {k.split("/")[1]: g[k] for k in g.files if k.startswith(name + "/")}
+            env = MRVecEnv(64, cfg=MRConfig(noise_var=0.0, a0=float(G["a0"]), is_mismatched=bool(G["mismatched"])), device=dev)
+            env._prev_mismatched = bool(G["mismatch_at_reset"])
+            env.reset(init=np.tile(G["init"][None, :], (64, 1)), is_mismatched=bool(G["mismatched"]))
+            acts = G["actions"].astype(np.float64 if f64 else np.float32)
+            traj = env.rollout(len(acts), actions=acts, shared_actions=True, want=("traj",), carry=carry)["traj"][:, 0, :].cpu().numpy()
+            worst = max(worst, float(np.sqrt(np.mean(np.sum((traj - G["pos"]) ** 2, axis=1)))))
+        return worst, len(names)
+
+    worst, n = run("ref_sim.npz", False)
+    out = {"value": worst, "unit": "position units (max over %d golden trajectories)" % n, "target": 1e-5,
+           "fixtures": "tests/golden/ref_sim.npz", "carry": carry}
+    if os.path.exists(os.path.join(ROOT, "tests", "golden", "ref_sim_f64.npz")):
+        w64, n64 = run("ref_sim_f64.npz", True)
+        out["f64_tables"] = {"value": w64, "trajectories": n64, "fixtures": "tests/golden/ref_sim_f64.npz"}
+    return out
+
+
+def stats_us(ms):
+    ms = sorted(ms)
+    return sum(ms) / len(ms) * 1e3, ms[len(ms) // 2] * 1e3
 
 
 def main():
     args = parse()
-    lib_so = os.path.join(ROOT, "mr_rl_amd", "libmrsim.so")
-    if not os.path.exists(lib_so):  # git-ignored build product missing in this checkout: build it (no fallback path)
-        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-            import __graft_entry__
-            __graft_entry__.build()
-        else:
-            t_wait = time.time()
-            while not os.path.exists(lib_so) and time.time() - t_wait < 600:
-                time.sleep(1.0)
-            time.sleep(2.0)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    ensure_built()
     import torch
     import torch.distributed as dist
     from mr_rl_amd import MRConfig, MRVecEnv
@@ -249,6 +432,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.share_gpu:
             local_rank = 0
+        elif torch.cuda.device_count() <= local_rank:
+            raise SystemExit("bench.py: rank %d needs cuda:%d but only %d device(s) are visible (--share-gpu only "
+                             "for rehearsals)" % (rank, local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -257,6 +443,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    pmc = under_pmc()
 
     n_local = args.envs_per_gpu
     total = n_local * world
@@ -272,37 +459,22 @@ def main():
     gatherer = ReturnGatherer(env, world)
     K, W = max(args.steps, 1), max(args.warmup, 0)
     ep = cfg.max_timesteps + 1
-    done_steps = [0]
     WANT = ("obs", "rew", "done", "actions")
+    from mr_rl_amd._lib import EventPair
+    launch = args.launch
+    if pmc and launch == "graph":
+        launch = "eager"
 
     if args.mode == "rollout":
         T = args.rollout_len
-        bufs = {}
-        # rank 0 attaches a pair of HIP events to every full-length dispatch of the TIMED region (non-blocking,
-        # hipExtLaunchKernelGGL on the launch stream); they are read after the region for roofline.achieved
-        from mr_rl_amd._lib import EventPair
-        ev_pool = [EventPair() for _ in range(min(K // T + 1, 4096))] if rank == 0 else []
-        ev_used = []
-        ev_on = [False]
-
-        def run(nsteps):
-            """exactly nsteps env steps in launches of <= T, cut at episode boundaries"""
-            left = nsteps
-            while left > 0:
-                chunk = min(left, T, ep - (done_steps[0] % ep))
-                ev = None
-                if ev_on[0] and chunk == T and len(ev_used) < len(ev_pool):
-                    ev = ev_pool[len(ev_used)]
-                    ev_used.append(ev)
-                env.rollout(chunk, actions=None, want=WANT, out=bufs if chunk == T else None, events=ev)
-                done_steps[0] += chunk
-                left -= chunk
-                if done_steps[0] % ep == 0:
-                    gatherer.gather()  # RCCL all-gather of this episode's returns
-        launch_desc = {"rollout_len": T, "transition_bytes_per_env_step": 33}
+        reg = RolloutRegion(env, gatherer, T, ep, WANT, world, dev, args.dist_backend, args.carry)
+        run = reg.run
+        launch_desc = {"rollout_len": T, "transition_bytes_per_env_step": 33, "carry": args.carry}
     else:
         G = args.graph_len
         act = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
+        done_steps = [0]
+        n_launches = [0]
 
         def eager_step():
             if args.policy == "kernel":
@@ -310,19 +482,21 @@ def main():
             else:
                 env.step(None)
 
-        graph = env.capture_steps(G, policy=args.policy) if args.launch == "graph" else None
+        graph = env.capture_steps(G, policy=args.policy) if launch == "graph" else None
 
-        def run(nsteps):
+        def run(nsteps, pool=None, used=None):
             left = nsteps
             while left > 0:
                 chunk = min(left, ep - (done_steps[0] % ep))
                 if graph is not None and chunk == G:
                     graph.replay()
+                    n_launches[0] += 1
                 else:
                     if graph is not None:
                         env.step_idx = 0
                     for _ in range(chunk):
                         eager_step()
+                    n_launches[0] += chunk * (2 if args.policy == "kernel" else 1)
                     if graph is not None:
                         env.advance_step_base(chunk)
                         env.step_idx = 0
@@ -330,7 +504,7 @@ def main():
                 left -= chunk
                 if done_steps[0] % ep == 0:
                     gatherer.gather()
-        launch_desc = {"policy": args.policy, "launch": args.launch, "graph_len": G if graph is not None else 0}
+        launch_desc = {"policy": args.policy, "launch": launch, "graph_len": G if graph is not None else 0}
 
     def barrier():
         if world > 1:
@@ -338,75 +512,135 @@ def main():
         torch.cuda.synchronize(dev)
 
     # clock settle (tools/clock_ramp_probe.py: ~35 ms of load after idle), independent of the W the caller asks for
+    trace("env ready; settle phase: %d episodes" % args.settle_episodes)
     run(args.settle_episodes * ep)
+    trace("settle issued; warm-up %d steps" % W)
     run(W)
     barrier()
+    trace("warm-up done; timed region")
+    # ---- the contract's timed region: EXACTLY K steps between barrier + synchronize, max over ranks
+    ev_pool = [EventPair() for _ in range(min(K // ep + 1, 4096))] if (rank == 0 and args.mode == "rollout") else None
+    ev_used = []
     if args.mode == "rollout":
-        ev_on[0] = True
-    t0 = time.perf_counter()
-    run(K)
-    gatherer.finish()  # outstanding async all-gathers belong to the timed region
-    torch.cuda.synchronize(dev)
-    barrier()
-    el = time.perf_counter() - t0
-    t = torch.tensor([el], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
+        el, launches = reg.timed(K, ev_pool, ev_used)
+    else:
+        l0 = n_launches[0]
+        t0 = time.perf_counter()
+        run(K)
+        gatherer.finish()
+        torch.cuda.synchronize(dev)
+        barrier()
+        el = time.perf_counter() - t0
+        launches = n_launches[0] - l0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+    trace("timed region done")
     env.check_status()
     mean_ret = gatherer.last_mean()
+    region_ms = [e.elapsed_ms() for e in ev_used]
+
+    # ---- sustained leg: the same workload over its own >= 10 200-step region (every rank takes part)
+    sustained = None
+    sus_ms = []
+    if args.mode == "rollout" and args.sustained_steps > 0:
+        ks = max(args.sustained_steps // ep, 1) * ep
+        pool2 = None
+        if rank == 0:
+            pool2 = ev_pool if len(ev_pool) >= ks // reg.T + 1 else [EventPair() for _ in range(ks // reg.T + 1)]
+        used2 = []
+        els, ls = reg.timed(ks, pool2, used2)
+        sus_ms = [e.elapsed_ms() for e in used2]
+        sustained = {"what": "the headline workload over its own region after the settle phase, independent of --steps",
+                     "value": total * ks / els, "unit": "env-steps/s", "steps": ks, "launches": ls,
+                     "ms_per_step": els / ks * 1e3}
+        if sus_ms:
+            avg_us, med_us = stats_us(sus_ms)
+            sustained.update({"avg_kernel_us": round(avg_us, 3), "median_kernel_us": round(med_us, 3),
+                              "kernel_time_over_wall": round(sum(sus_ms) * 1e-3 / els, 4),
+                              "in_kernel_value": n_local * reg.T / (avg_us * 1e-6)})
+        if pool2 is not None and pool2 is not ev_pool:
+            for e in pool2:
+                e.close()
+        trace("sustained leg done")
+    if ev_pool is not None:
+        for e in ev_pool:
+            e.close()
+
     mixed = None
     if args.mode == "rollout" and args.workload == "ddpg" and not args.no_mixed_set:
-        mixed = measure_mixed_set(args, n_local, env_id0, world, dev, seed, barrier)
+        mixed = measure_mixed_set(args, n_local, env_id0, world, dev, seed)
+        trace("mixed set done")
 
-    # ---- duration of the dominant kernel, HIP events attached to the dispatch (hipExtLaunchKernelGGL) on the
-    # stream it runs on.  Rollout mode: the dispatches OF the timed region.  Step mode (the timed region replays
-    # hipGraphs, which cannot carry per-dispatch events): separate timed launches right after it, same state regime.
+    # ---- roofline of the dominant kernel (rank 0): durations from HIP events attached to the dispatches
+    # (hipExtLaunchKernelGGL) on the stream they run on.  Rollout mode: the dispatches of the sustained region (or of the
+    # timed region when that leg is off).  Step mode (graph replays cannot carry per-dispatch events): separate timed
+    # launches right after the region, same state regime.
     roof = None
     if rank == 0:
+        law = "mismatched" if args.mismatched else "nominal"
+        nz = "nonoise" if args.sigma == 0 else args.noise_math
         if args.mode == "rollout":
             T = args.rollout_len
-            ev_on[0] = False
-            ms = sorted(e.elapsed_ms() for e in ev_used)
-            timed_where = "the %d full-length dispatches of the timed region" % len(ms)
-            if not ms:  # fewer than T steps were timed: sample afterwards instead
+            ms, timed_where = (sus_ms, "the %d dispatches of the sustained region" % len(sus_ms)) if sus_ms else \
+                (region_ms, "the %d full-length dispatches of the timed region" % len(region_ms))
+            if not ms:  # fewer than T steps were timed and no sustained leg: sample afterwards instead
                 ns = args.kernel_samples or 10
-                ms = sorted(env.rollout(T, actions=None, want=WANT, out=bufs, timed=True)["kernel_ms"] for _ in range(ns))
+                ms = [env.rollout(T, actions=None, want=WANT, out=reg.bufs, timed=True, carry=args.carry)["kernel_ms"]
+                      for _ in range(ns)]
                 timed_where = "%d launches right after the timed region" % len(ms)
-            for e in ev_pool:
-                e.close()
+            avg_us, med_us = stats_us(ms)
             units = n_local * T
-            law = "mismatched" if args.mismatched else "nominal"
-            kname = "mr_rollout_kernel<RK45,%s,%s>" % ("nonoise" if args.sigma == 0 else args.noise_math, law)
+            traffic, traffic_src = committed_traffic(args, n_local)
+            valu = committed_valu_floor(args, n_local, T)
+            ach = units / (avg_us * 1e-6) / 1e9
+            roof = {"bound": "valu", "achieved": round(ach, 2),
+                    "peak": round(units / (valu["floor_us_per_launch"] * 1e-6) / 1e9, 2) if valu else None,
+                    "unit": "G env-steps/s in-kernel (peak = the kernel's measured VALU instruction mix issued at the "
+                            "per-instruction rates tools/instbench measures at this launch's occupancy)",
+                    "frac": round(valu["floor_us_per_launch"] / avg_us, 4) if valu else None,
+                    "valu": valu,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "hbm_achieved_GBs": round(traffic / (avg_us * 1e-6) / 1e9, 1) if traffic else None,
+                    "hbm_peak_GBs": HBM_PEAK_GBS,
+                    "hbm_frac": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "algorithmic_equiv": {
+                        "what": "SURVEY 8(d)'s algorithmic bytes (state round-trips HBM every step) / kernel time; the "
+                                "fused kernel keeps the state in registers and does NOT move these bytes: an "
+                                "equivalence figure, not a fraction of any peak",
+                        "bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                        "GBs": round(units * ALGO_BYTES_PER_ENV_STEP / (avg_us * 1e-6) / 1e9, 1)},
+                    "kernel": "mr_rollout_kernel<RK45,%s,%s,carry=%s>" % (nz, law, args.carry),
+                    "kernel_timed_over": timed_where, "avg_kernel_us": round(avg_us, 3),
+                    "median_kernel_us": round(med_us, 3), "env_steps_per_launch": units}
         else:
             ns = args.kernel_samples or 102
-            ms = sorted(env.step_timed(env.random_policy(out=act) if args.policy == "kernel" else None)
-                        for _ in range(ns))
+            ms = [env.step_timed(env.random_policy(out=act) if args.policy == "kernel" else None) for _ in range(ns)]
+            avg_us, med_us = stats_us(ms)
             units = n_local
-            timed_where = "%d launches right after the timed region (graph replays cannot carry events)" % len(ms)
-            law = "mismatched" if args.mismatched else "nominal"
-            kname = "mr_step_kernel<RK45,%s,%s,%s>" % ("nonoise" if args.sigma == 0 else args.noise_math, law,
-                                                            args.obs_layout)
-        avg_ms = sum(ms) / len(ms)
-        ach = units * ALGO_BYTES_PER_ENV_STEP / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = committed_traffic(args, n_local)
-        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": kname, "kernel_timed_over": timed_where,
-                "avg_kernel_us": round(avg_ms * 1e3, 3), "median_kernel_us": round(ms[len(ms) // 2] * 1e3, 3),
-                "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "env_steps_per_launch": units}
-        if args.mode == "rollout":
-            roof["note"] = ("achieved counts SURVEY 8(d)'s ALGORITHMIC 97 B per env-step, which assume the env state "
-                            "round-trips HBM every step; the fused rollout keeps it in registers and moves only "
-                            "`traffic` bytes (about 0.36 x algorithmic), so achieved can exceed the HBM peak: the "
-                            "kernel is VALU-bound (DESIGN.md section 7)")
+            traffic, traffic_src = committed_traffic(args, n_local)
+            ach = units * ALGO_BYTES_PER_ENV_STEP / (avg_us * 1e-6) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "hbm_frac": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "kernel": "mr_step_kernel<RK45,%s,%s,%s>" % (nz, law, args.obs_layout),
+                    "kernel_timed_over": "%d launches right after the timed region (graph replays cannot carry events)" % len(ms),
+                    "avg_kernel_us": round(avg_us, 3), "median_kernel_us": round(med_us, 3),
+                    "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "env_steps_per_launch": units}
+    trace("roofline events read")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, seed, args.cpu_seconds)
-    rmse = trajectory_rmse(dev) if rank == 0 and world == 1 else None
+    rmse = trajectory_rmse(dev, args.carry) if rank == 0 and world == 1 else None
+    trace("trajectory rmse done")
     step_path = None
     if rank == 0 and world == 1 and args.mode == "rollout" and not args.no_step_path and args.workload == "ddpg":
-        step_path = measure_step_path(cfg, n_local, dev, seed)
+        if pmc:
+            step_path = {"skipped": "hipGraph capture under rocprofv3 --pmc crashes the profiler (ROCm 7.2)"}
+        else:
+            step_path = measure_step_path(cfg, n_local, dev, seed)
+        trace("step path done")
 
     if world > 1:
         dist.barrier()
@@ -419,19 +653,29 @@ def main():
                   "noise_math": args.noise_math, "sigma": args.sigma, "seed": seed,
                   "is_mismatched": bool(args.mismatched),
                   "mean_episode_return": mean_ret,
+                  "ranks": dist.get_world_size() if world > 1 else 1,
+                  "rank_launcher": os.environ.get("MRSIM_BENCH_LAUNCHER", "external (torchrun)" if world > 1 else "none"),
                   "returns_allgather": ("%s all_gather_into_tensor (%s) every 51 steps"
                                         % (args.dist_backend, gatherer.mode)) if world > 1 else "local"}
         config.update(launch_desc)
+        if args.mode == "rollout" and args.carry == "f64":
+            dtype = "f64 positions and carried RK45 state; f32 Box-Muller normals and stage-noise sums"
+        else:
+            dtype = "f64 positions; f32 Box-Muller normals, stage-noise sums and carried K0 / h_abs"
         out = {"metric": "env-steps/sec at N parallel envs; trajectory RMSE vs CPU ref", "value": value, "unit": "env-steps/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / max(K, 1) * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-               "data": "synthetic", "config": config, "roofline": roof, "cpu_baseline": cpu}
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+               "data": "synthetic", "launches": launches, "config": config, "roofline": roof, "cpu_baseline": cpu}
+        if sustained is not None:
+            out["sustained"] = sustained
         if rmse is not None:
             out["trajectory_rmse_vs_cpu_ref"] = rmse
         if step_path is not None:
             out["step_path"] = step_path
         if mixed is not None:
             out["mixed_trajectory_set"] = mixed
+        if pmc:
+            out["note"] = "run under rocprofv3 counter collection: kernels are serialised, timings are not representative"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

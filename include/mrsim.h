@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRSIM_ABI_VERSION 1
+#define MRSIM_ABI_VERSION 2
 
 enum {
     MRSIM_OK = 0,
@@ -149,7 +149,8 @@ int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float
 typedef struct MrsimRolloutIO {
     int32_t T;               /* steps in this launch; step_idx0 .. step_idx0+T-1 are consumed          */
     int32_t shared_actions;  /* non-zero: actions is [T][2], one table for all envs (utils.run_sim)    */
-    const float* actions;    /* [T][n][2] per-env, [T][2] shared, or NULL = in-kernel random policy    */
+    const void* actions;     /* [T][n][2] per-env, [T][2] shared (fp32, or fp64 when actions_f64), or NULL =   */
+                             /*   in-kernel random policy                                                      */
     const float* goal_table; /* optional [K][T'][2]                                                    */
     double* traj_xy;         /* optional [T][n][2] fp64: position after each step, before any auto-    */
                              /*   reset == what utils.run_sim records from env.last_pos (utils.py:53)  */
@@ -161,11 +162,21 @@ typedef struct MrsimRolloutIO {
     float* final_ret;        /* optional [n]: return of the latest episode that ended in the launch    */
     int32_t* final_len;      /* optional [n]: its length                                               */
     int32_t* status;         /* optional [1], as MrsimStepIO.status                                    */
+    int64_t row_stride;      /* envs per row of every [T][.] buffer above; 0 = n.  A value > n lets several     */
+                             /*   launches (sub-shards of one env set, e.g. on different streams) write their  */
+                             /*   columns of the same [T][row_stride][.] buffers: pass each launch the buffer  */
+                             /*   pointers advanced to its first env.  final_ret / final_len stay [n].         */
+    int32_t carry_f64;       /* 0 (default): the RK45 object's carried state (integrator.f, h_abs) is rounded  */
+                             /*   to its fp32 HBM format after every step, so the launch is bit-identical to T */
+                             /*   calls of mrsim_step.  1: it stays in fp64 registers until the launch ends    */
+                             /*   (closer to the reference, which carries fp64; not bit-identical to steps).   */
+    int32_t actions_f64;     /* non-zero: `actions` holds fp64 values ([T][2] or [T][n][2] doubles) -- the     */
+                             /*   reference's action tables (main.py:14-50) are float64 linspace tables        */
 } MrsimRolloutIO;
 
 /* Fused open-loop rollout, the batched utils.run_sim (utils.py:43-61) and the DDPG rollout workload:
  * T steps of all n envs in one launch, env state kept in registers, every requested per-step output
- * written to [T][n][...] buffers.  Honors auto_reset.  Bit-identical to T calls of mrsim_step. */
+ * written to [T][n][...] buffers.  Honors auto_reset.  Bit-identical to T calls of mrsim_step (carry_f64 = 0). */
 int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
                   const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream);
 

@@ -11,7 +11,7 @@ INT_RK45, INT_EULER, INT_RK4 = 0, 1, 2
 REW_CONSTANT10, REW_GOAL = 0, 1
 OBS_AOS, OBS_SOA = 0, 1
 NOISE_FAST, NOISE_SPEC = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/mrsim.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
@@ -55,6 +55,7 @@ class MrsimRolloutIO(C.Structure):
         ("traj_xy", C.c_void_p), ("state_prime_T", C.c_void_p), ("obs_T", C.c_void_p), ("rew_T", C.c_void_p),
         ("done_T", C.c_void_p), ("actions_out_T", C.c_void_p), ("final_ret", C.c_void_p),
         ("final_len", C.c_void_p), ("status", C.c_void_p),
+        ("row_stride", C.c_int64), ("carry_f64", C.c_int32), ("actions_f64", C.c_int32),
     ]
 
 
@@ -67,16 +68,13 @@ class MrsimError(RuntimeError):
 _lib = None
 
 
-def lib():
-    """Load libmrsim.so (built by `make -C mr_rl_amd/csrc` / __graft_entry__.build())."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path):
+    """Bind one libmrsim build (the default in-tree one, or an A/B variant for tools/ab_rollout.py)."""
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` or `make -C mr_rl_amd/csrc`. mr_rl_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i64, u32, u64, i32 = C.c_void_p, C.c_int64, C.c_uint32, C.c_uint64, C.c_int32
     PP, PS, PIO = C.POINTER(MrsimParams), C.POINTER(MrsimState), C.POINTER(MrsimStepIO)
     L.mrsim_abi_version.restype = C.c_int
@@ -89,30 +87,32 @@ def lib():
     L.mrsim_random_policy.argtypes = [PP, i64, u32, vp, u64, u64, vp]
     L.mrsim_rollout.argtypes = [PP, i64, u32, PS, C.POINTER(MrsimRolloutIO), u64, u64, vp]
     L.mrsim_rollout_timed.argtypes = L.mrsim_rollout.argtypes + [C.POINTER(C.c_float)]
-    L.mrsim_rollout_timed.restype = C.c_int
     L.mrsim_velocity.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp]
-    L.mrsim_velocity.restype = C.c_int
     L.mrsim_advance_step_base.argtypes = [vp, u64, vp]
     L.mrsim_event_create.argtypes = [C.POINTER(vp)]
     L.mrsim_event_destroy.argtypes = [vp]
     L.mrsim_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.mrsim_rollout_events.argtypes = L.mrsim_rollout.argtypes + [vp, vp]
     L.mrsim_step_events.argtypes = L.mrsim_step.argtypes + [vp, vp]
-    for name in ("mrsim_event_create", "mrsim_event_destroy", "mrsim_event_elapsed_ms", "mrsim_rollout_events",
-                 "mrsim_step_events"):
-        getattr(L, name).restype = C.c_int
-    L.mrsim_advance_step_base.restype = C.c_int
     L.mrsim_debug_normals.argtypes = [i64, u32, u64, u64, u32, i32, vp, vp]
     L.mrsim_device_count.restype = C.c_int
     L.mrsim_device_name.argtypes = [C.c_int, C.c_char_p, i32]
-    for name in ("mrsim_default_params", "mrsim_reset", "mrsim_step", "mrsim_step_timed", "mrsim_random_policy",
-                 "mrsim_rollout", "mrsim_debug_normals", "mrsim_device_name"):
-        getattr(L, name).restype = C.c_int
+    for name in SYMBOLS:
+        if name != "mrsim_strerror":
+            getattr(L, name).restype = C.c_int
     if L.mrsim_abi_version() != ABI_VERSION:
-        raise ImportError(f"libmrsim.so ABI {L.mrsim_abi_version()} != binding ABI {ABI_VERSION}")
+        raise ImportError(f"{path}: ABI {L.mrsim_abi_version()} != binding ABI {ABI_VERSION}")
     assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 10 + 8
-    _lib = L
+    assert C.sizeof(MrsimRolloutIO) == 8 + 8 * 11 + 8 + 4 + 4
     return L
+
+
+def lib():
+    """Load libmrsim.so (built by `make -C mr_rl_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        _lib = load(LIB_PATH)
+    return _lib
 
 
 def strerror(code):

@@ -40,6 +40,8 @@ class MRConfig:
     auto_reset: bool = False
     obs_layout: str = "aos"               # storage of obs: [N,5] rows or [5,N] planes (returned view is [N,5])
     noise_math: str = "fast"              # Box-Muller on hardware transcendentals | "spec": bit-identical to the oracle
+    rollout_carry: str = "f32"            # fused rollout: "f32" = carried RK45 state rounded per step (bit-identical to
+                                          # step()); "f64" = kept in fp64 registers for the whole launch
     seed: int = 0
 
     def to_params(self, goal_K=1, goal_T=1):

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
         }
         step_prologue<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa);
         int fail = 0;
-        env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, af, aa, W, fl, o, fail);
+        env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, (double)af, (double)aa, W, fl, o, fail,
+                                MRSIM_ROLLOUT_TABLE ? kSinCosTab : nullptr);  // same arithmetic as the rollout: equal bits
         store_env(st.pos, st.aux, st.ep_ret, i, P, e);
         io.rew[i] = o.rew;
         io.done[i] = o.done;
@@ -169,7 +170,8 @@ struct RolloutArgs {
     int32_t shared_actions;
     int32_t obs_layout;
     int32_t pad;
-    const float* actions;
+    long long row_stride;  // envs per row of the [T][row_stride][...] buffers (>= n: a sub-shard of a wider rollout)
+    const void* actions;
     const float* goal_table;
     double* traj_xy;
     float* state_prime_T;
@@ -212,6 +214,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     const long long blk0 = (long long)blockIdx.x * kBlock;
     const unsigned tid = threadIdx.x;
     const long long i = blk0 + tid;
+#if MRSIM_ROLLOUT_TABLE == 1
+    // sin/cos table of the action heading (mrsim_device.h: sincos_tab): 16 KiB per block, read once from L2 per launch
+    __shared__ __attribute__((aligned(16))) double2 s_sincos[MRSIM_SINCOS_N];
+    for (unsigned k = tid; k < MRSIM_SINCOS_N; k += kBlock) s_sincos[k] = kSinCosTab[k];
+    __syncthreads();
+    const double2* __restrict__ sincos_lds = s_sincos;
+#elif MRSIM_ROLLOUT_TABLE == 2
+    const double2* __restrict__ sincos_lds = kSinCosTab;  // straight from L1 / L2 (16 KiB, shared by every wave)
+#else
+    const double2* __restrict__ sincos_lds = nullptr;
+#endif
     if (i >= P.n) return;
     EnvRegs e;
 #ifdef MRSIM_WAVE_PROBE
@@ -228,10 +241,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         rotate_wave_priority((unsigned)t, slot);
         const uint32_t fl = FL != 0 ? FL : live_flags(P.flags);  // one SGPR; every uniform yes/no below is a bit test
         const Rng R = make_rng(P, i, (unsigned long long)t);
-        const long long row = (long long)t * P.n + blk0;  // uniform
+        const long long row = (long long)t * ra.row_stride + blk0;  // uniform
         float af = 0.f, aa = 0.f;
+        double adf = 0.0, ada = 0.0;  // fp64 action tables (kFActions64): the reference's main.py tables are float64
         StepWords<RK45, NZ, MIS> W;
         if (!(fl & kFActions)) {
+        } else if (fl & kFActions64) {
+            const double2 a = (fl & kFSharedActions) ? reinterpret_cast<const double2*>(ra.actions)[t]
+                                                     : (reinterpret_cast<const double2*>(ra.actions) + row)[tid];
+            adf = a.x; ada = a.y;
+            af = (float)adf; aa = (float)ada;  // what actions_out_T reports
         } else if (fl & kFSharedActions) {
             const float2 a = reinterpret_cast<const float2*>(ra.actions)[t];
             af = a.x; aa = a.y;
@@ -240,9 +259,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
             af = a.x; aa = a.y;
         }
         step_prologue<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa);
+        if (!(fl & kFActions64)) { adf = (double)af; ada = (double)aa; }
         StepOut o;
-        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, af, aa, W, fl, o, fail);
-        quantise_env(P, e);
+        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds);
+        // default: carry K0 / h_abs exactly as a step-by-step run stores them in HBM (fp32), so that a rollout and T
+        // single steps give identical bits; kFCarry64 keeps them in fp64 registers until the launch ends
+        if (!(fl & kFCarry64)) quantise_env(P, e);
         // The [T][N] outputs are write-once streams the kernel never reads back: non-temporal stores (+1 %)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -262,7 +284,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
             } else {
 #pragma unroll
                 for (int j = 0; j < 5; ++j)
-                    __builtin_nontemporal_store(o.obs[j], &(ra.obs_T + ((long long)t * 5 + j) * P.n + blk0)[tid]);
+                    __builtin_nontemporal_store(o.obs[j], &(ra.obs_T + ((long long)t * 5 + j) * ra.row_stride + blk0)[tid]);
             }
         }
         if (fl & kFOutRew) __builtin_nontemporal_store(o.rew, &(ra.rew_T + row)[tid]);
@@ -369,6 +391,7 @@ __global__ __launch_bounds__(kBlock) void mr_debug_normals_kernel(const KParams 
 // host side
 // ---------------------------------------------------------------------------
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
 static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx,
                         KParams& K) {
@@ -400,6 +423,11 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
         K.act_lo_f[j] = (float)p->act_low[j]; K.act_span_f[j] = (float)(p->act_high[j] - p->act_low[j]);
     }
     K.h1_thresh = 0.01 / std::pow(p->time_span, 5.0);
+    K.h1_thresh_m = K.h1_thresh / 1.05;
+    K.k_h0 = 105.0 * p->time_span;
+    K.gmax_dt = 2.0 * 6.78 * p->sigma / p->time_span;
+    K.zmax2_dt = 2.0 * 6.78 / p->time_span;
+    K.zmax_e6_sigma = kZmaxE6 * p->sigma;
     K.h1_thresh2_f = (float)(K.h1_thresh * K.h1_thresh);
     K.dt2_f = (float)(p->time_span * p->time_span);
     K.substeps = p->substeps; K.reward_mode = p->reward_mode; K.max_timesteps = p->max_timesteps;
@@ -496,10 +524,7 @@ static int launch_rollout_fl(const LaunchCfg& lc, int nz, bool mis, const KParam
     if (nz == kNoiseFast)
         return mis ? launch(lc, mr_rollout_kernel<true, kNoiseFast, true, FL>, K.n, K, S, ra)
                    : launch(lc, mr_rollout_kernel<true, kNoiseFast, false, FL>, K.n, K, S, ra);
-    if (nz == kNoiseSpec)
-        return mis ? launch(lc, mr_rollout_kernel<true, kNoiseSpec, true, FL>, K.n, K, S, ra)
-                   : launch(lc, mr_rollout_kernel<true, kNoiseSpec, false, FL>, K.n, K, S, ra);
-    handled = false;  // sigma == 0: generic kernel
+    handled = false;  // sigma == 0 / noise_math = spec: generic kernel
     return MRSIM_OK;
 }
 
@@ -637,9 +662,13 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     if (rc) return rc;
     if ((rc = check_state(st))) return rc;
     if (io == nullptr || io->T < 0) return MRSIM_EINVAL;
+    if (io->row_stride != 0 && io->row_stride < n) return MRSIM_EINVAL;
     if (io->T == 0) return MRSIM_OK;
-    if ((io->actions && !aligned16(io->actions)) || (io->traj_xy && !aligned16(io->traj_xy)) ||
-        (io->actions_out_T && !aligned16(io->actions_out_T)) || (io->state_prime_T && !aligned16(io->state_prime_T)))
+    // per-env {x, y} fp64 records move as one 16-byte access, {f, alpha} / state_prime fp32 pairs as one 8-byte access
+    // (a sub-shard that starts at an odd env of a shared [T][N][2] fp32 buffer is 8-byte aligned only)
+    if ((io->actions && !(io->actions_f64 ? aligned16(io->actions) : aligned8(io->actions))) ||
+        (io->traj_xy && !aligned16(io->traj_xy)) || (io->actions_out_T && !aligned8(io->actions_out_T)) ||
+        (io->state_prime_T && !aligned8(io->state_prime_T)))
         return MRSIM_EALIGN;
     if (io->goal_table != nullptr && (p->goal_K < 1 || p->goal_T < 1)) return MRSIM_EINVAL;
     if ((rc = check_device())) return rc;
@@ -649,8 +678,10 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
                (io->state_prime_T ? kFOutStatePrime : 0u) | (io->obs_T ? kFOutObs : 0u) | (io->rew_T ? kFOutRew : 0u) |
                (io->done_T ? kFOutDone : 0u) | (io->actions_out_T ? kFOutActions : 0u) |
                (io->final_ret ? kFOutFinalRet : 0u) | (io->final_len ? kFOutFinalLen : 0u) |
-               (io->status ? kFOutStatus : 0u);
-    const RolloutArgs ra{io->T, io->shared_actions, p->obs_layout, 0, io->actions, io->goal_table, io->traj_xy,
+               (io->status ? kFOutStatus : 0u) | (io->carry_f64 ? kFCarry64 : 0u) |
+               ((io->actions && io->actions_f64) ? kFActions64 : 0u);
+    const long long row_stride = io->row_stride > 0 ? (long long)io->row_stride : (long long)n;
+    const RolloutArgs ra{io->T, io->shared_actions, p->obs_layout, 0, row_stride, io->actions, io->goal_table, io->traj_xy,
                          io->state_prime_T, io->obs_T, io->rew_T, io->done_T, io->actions_out_T, io->final_ret,
                          io->final_len, io->status};
     LaunchCfg lc{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
@@ -660,9 +691,15 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     if (p->integrator == MRSIM_INT_RK45) {
         const int nz = noise_variant(p);
         const bool mis = p->mismatched != 0;
-        if (K.flags == kFlDdpg) rc = launch_rollout_fl<kFlDdpg>(lc, nz, mis, K, S, ra, handled);
-        else if (K.flags == kFlMixed) rc = launch_rollout_fl<kFlMixed>(lc, nz, mis, K, S, ra, handled);
-        else if (K.flags == kFlDdpgSoa) rc = launch_rollout_fl<kFlDdpgSoa>(lc, nz, mis, K, S, ra, handled);
+        switch (K.flags) {
+            case kFlDdpg: rc = launch_rollout_fl<kFlDdpg>(lc, nz, mis, K, S, ra, handled); break;
+            case kFlMixed: rc = launch_rollout_fl<kFlMixed>(lc, nz, mis, K, S, ra, handled); break;
+            case kFlDdpgSoa: rc = launch_rollout_fl<kFlDdpgSoa>(lc, nz, mis, K, S, ra, handled); break;
+            case kFlDdpg | kFCarry64: rc = launch_rollout_fl<kFlDdpg | kFCarry64>(lc, nz, mis, K, S, ra, handled); break;
+            case kFlMixed | kFCarry64: rc = launch_rollout_fl<kFlMixed | kFCarry64>(lc, nz, mis, K, S, ra, handled); break;
+            case kFlDdpgSoa | kFCarry64: rc = launch_rollout_fl<kFlDdpgSoa | kFCarry64>(lc, nz, mis, K, S, ra, handled); break;
+            default: break;
+        }
     }
     if (!handled)
         rc = dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {

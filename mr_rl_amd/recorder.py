@@ -7,30 +7,51 @@ episodes once, on the host, and written in the same dictionary layout, so the re
 settling-time helpers read new runs unchanged:
 
   iterations            index of the last episode (starts at -1)                        MR_data.py:15
-  states[it]            [steps+1, 2]  row 0 = the reset state                           :39,54
-  observations[it]      [steps+1, 5]  row 0 = the reset observation                     :40,55
-  actions[it]           [steps+1, 2]  row 0 = zeros  (MR_env.py:196)                    :41,56
-  rewards[it]           [steps+1, 1]  row 0 = [0]    (MR_env.py:197)                    :42,57
+  states[it]            [steps+1, 2]  float64, row 0 = the reset state                  :39,54
+  observations[it]      [steps+1, 5]  float64, row 0 = the reset observation            :40,55
+  actions[it]           [steps+1, 2]  float64, row 0 = zeros  (MR_env.py:196)           :41,56
+  rewards[it]           [steps+1, 1]  row 0 = [0]  (MR_env.py:197); int64 under the     :42,57
+                        reference's constant reward (`rew = 10`, MR_env.py:89), float64 under calculate_reward
   steps[it]             number of transitions                                            :38,53
   info, viewer, scream, obs_states_str, time_step                                        :20-24
+
+Pinned against the reference's own recorder by tests/golden/ref_experiment.npz (tests/test_gpu_parity.py).
 """
 import pickle
 
 import numpy as np
 
 
-def episodes_from_rollout(obs0, traj, obs, actions, rew, done):
+def _empty():
+    return dict(iterations=-1, states={}, observations={}, actions={}, rewards={}, steps={}, info=None, viewer=None,
+                scream=None, obs_states_str={}, time_step=10)
+
+
+def _rewards_column(rew, integer):
+    r = np.asarray(rew, np.float64)
+    col = np.vstack([np.array([0.0]), r[:, None]]) if len(r) else np.array([[0.0]])
+    return col.astype(np.int64) if integer else col
+
+
+def episodes_from_rollout(obs0, traj, obs, actions, rew, done, goals=None, integer_rewards=None, auto_reset=None):
     """Cut ONE env's rollout into MRExperiment episodes.
 
     obs0 [5]: observation returned by reset() before the rollout; traj [T,2] fp64 positions after each
     step (before any auto-reset); obs [T,5] returned observations (the reset observation on a done step
     when auto_reset is on); actions [T,2]; rew [T]; done [T].
+    goals: optional [T,2] goal of every step (an env with a goal table: the goal varies along the episode);
+    default = the goal the reset observation shows (MR_Env.init_goal).  Only used to rebuild the terminal
+    observation that an auto-reset step replaces by the next episode's reset observation.
+    integer_rewards: None = int64 column when every reward is an integer (the reference's `rew = 10`).
+    auto_reset: whether the rollout ran with same-step auto-reset (then the returned observation of a done step is the
+    NEXT episode's reset observation and the terminal one is rebuilt); None = tell from the data.
     """
     traj, obs, actions = np.asarray(traj, np.float64), np.asarray(obs, np.float64), np.asarray(actions, np.float64)
     rew, done = np.asarray(rew, np.float64), np.asarray(done, bool)
     T = len(rew)
-    d = dict(iterations=-1, states={}, observations={}, actions={}, rewards={}, steps={}, info=None, viewer=None,
-             scream=None, obs_states_str={}, time_step=10)
+    if integer_rewards is None:
+        integer_rewards = bool(np.all(rew == np.round(rew)))
+    d = _empty()
     start, reset_obs = 0, np.asarray(obs0, np.float64)
     for t in range(T + 1):
         if t == T or done[t]:
@@ -40,16 +61,20 @@ def episodes_from_rollout(obs0, traj, obs, actions, rew, done):
             it = d["iterations"] = d["iterations"] + 1
             n = end - start
             step_obs = obs[start:end].copy()
-            goal = reset_obs[2:4]
             if t < T and done[t]:
-                # the returned obs of the done step is the NEXT episode's reset obs (auto-reset): rebuild the
-                # terminal observation from the recorded position
                 p = traj[t]
-                step_obs[-1] = [p[0], p[1], goal[0], goal[1], np.hypot(goal[0] - p[0], goal[1] - p[1])]
+                replaced = auto_reset
+                if replaced is None:
+                    replaced = not (step_obs[-1, 0] == np.float32(p[0]) and step_obs[-1, 1] == np.float32(p[1]))
+                if replaced:
+                    # the returned obs of the done step is the NEXT episode's reset obs (auto-reset): rebuild the
+                    # terminal observation from the recorded position and the goal of THAT step
+                    goal = reset_obs[2:4] if goals is None else np.asarray(goals[t], np.float64)
+                    step_obs[-1] = [p[0], p[1], goal[0], goal[1], np.hypot(goal[0] - p[0], goal[1] - p[1])]
             d["states"][it] = np.vstack([reset_obs[:2], traj[start:end]])
             d["observations"][it] = np.vstack([reset_obs, step_obs])
             d["actions"][it] = np.vstack([np.zeros(2), actions[start:end]])
-            d["rewards"][it] = np.vstack([np.array([0.0]), rew[start:end, None]])
+            d["rewards"][it] = _rewards_column(rew[start:end], integer_rewards)
             d["steps"][it] = n
             if t < T:
                 reset_obs = obs[t]
@@ -57,13 +82,54 @@ def episodes_from_rollout(obs0, traj, obs, actions, rew, done):
     return d
 
 
+def _goals_of(env, T, env_index, counter0):
+    """[T,2] goal of each step of env `env_index` when the env has a goal table ([K][Tg][2], row = counter after the
+    step, clamped), else None.  Valid for one episode (no reset inside the T steps)."""
+    if env.goal_table is None:
+        return None
+    tab = env.goal_table.cpu().numpy()
+    K, Tg = tab.shape[0], tab.shape[1]
+    k = (env.env_id0 + env_index) % K if K > 1 else 0
+    rows = np.clip(counter0 + 1 + np.arange(T), 0, Tg - 1)
+    return tab[k, rows]
+
+
 def record_rollout(env, T, env_index=0, actions=None, shared_actions=False):
     """Run a fused T-step rollout on `env` and return the MRExperiment-layout dict of one env."""
     obs0 = env.obs[env_index].double().cpu().numpy()
+    p0 = env.pos[env_index].cpu().numpy()  # the reset state in fp64 (the observation is float32)
+    if obs0[0] == np.float32(p0[0]) and obs0[1] == np.float32(p0[1]):
+        obs0[:2] = p0
+        obs0[4] = np.hypot(obs0[2] - p0[0], obs0[3] - p0[1])
+    counter0 = int(env.counter[env_index].item())
     out = env.rollout(T, actions=actions, shared_actions=shared_actions,
                       want=("traj", "obs", "rew", "done", "actions"))
     g = lambda k: out[k][:, env_index].cpu().numpy()  # noqa: E731
-    return episodes_from_rollout(obs0, g("traj"), g("obs"), g("actions"), g("rew"), g("done"))
+    goals = None
+    if env.goal_table is not None and not env.cfg.auto_reset:
+        goals = _goals_of(env, T, env_index, counter0)
+    return episodes_from_rollout(obs0, g("traj"), g("obs"), g("actions"), g("rew"), g("done"), goals=goals,
+                                 auto_reset=bool(env.cfg.auto_reset))
+
+
+def record_episodes(env, inits, action_tables, env_index=0, **reset_kwargs):
+    """The reference's recorded loop (`env.set_save_experice(name)`; per episode `env.reset(init)` then `env.step(a)`
+    until done -- MR_env.py:94-95,190-198) for explicit start positions: episode k resets every env of `env` to
+    inits[k], plays action_tables[k] ([T_k, 2], shared by all envs) as ONE fused launch and keeps the transitions up to
+    and including the first done of env `env_index`.  Returns one MRExperiment-layout dict holding all episodes."""
+    if env.cfg.auto_reset:
+        raise ValueError("record_episodes drives explicit resets: construct the env with auto_reset=False")
+    d = _empty()
+    for init, table in zip(inits, action_tables):
+        table = np.asarray(table)
+        T = len(table)
+        init = np.asarray(init, dtype=np.float64)
+        env.reset(init=np.tile(init[None, :], (env.num_envs, 1)), **reset_kwargs)
+        one = record_rollout(env, T, env_index=env_index, actions=table[:, :2], shared_actions=True)
+        it = d["iterations"] = d["iterations"] + 1
+        for key in ("states", "observations", "actions", "rewards", "steps"):
+            d[key][it] = one[key][0]  # the first episode of the launch: everything after its done is dropped
+    return d
 
 
 def save_experiment(d, path):

@@ -83,7 +83,8 @@ def run_sim(actions, init_pos=None, noise_var=1, a0=1, is_mismatched=False, num_
     if actions.ndim != 2 or actions.shape[1] < 2:
         raise IndexError("actions must be [T, >=2] {freq, alpha}")
     T = len(actions)
-    c = cfg if cfg is not None else MRConfig()
+    import dataclasses
+    c = dataclasses.replace(cfg) if cfg is not None else MRConfig()  # the caller's cfg is not modified
     c.auto_reset = False
     env = MRVecEnv(num_envs, cfg=c, device=device, seed=seed)
     init = None
@@ -92,7 +93,8 @@ def run_sim(actions, init_pos=None, noise_var=1, a0=1, is_mismatched=False, num_
         init = np.tile(init[None, :], (num_envs, 1)) if init.ndim == 1 else init
     env.reset(init=init, noise_var=noise_var, a0=a0, is_mismatched=is_mismatched)
     want = ("traj", "state_prime") if return_state_prime else ("traj",)
-    out = env.rollout(T, actions=torch.as_tensor(actions[:, :2].astype(np.float32)), shared_actions=True, want=want)
+    # the table goes in as float64 (the reference's main.py tables are float64 linspace tables): no float32 rounding
+    out = env.rollout(T, actions=torch.as_tensor(np.ascontiguousarray(actions[:, :2])), shared_actions=True, want=want)
     env.check_status()
     traj = out["traj"].cpu().numpy()
     X, Y = traj[:, :, 0], traj[:, :, 1]

@@ -255,19 +255,29 @@ class MRVecEnv:
         _lib.check(rc, "mrsim_random_policy")
         return out
 
-    def rollout(self, T, actions=None, shared_actions=False, want=("traj",), out=None, timed=False, events=None):
+    def rollout(self, T, actions=None, shared_actions=False, want=("traj",), out=None, timed=False, events=None,
+                carry=None):
         """T fused steps in one launch (batched utils.run_sim / DDPG rollout).  actions: [T,N,2], or [T,2]
-        with shared_actions=True, or None for the on-device random policy.  want: any of "traj" (fp64
-        positions [T,N,2]), "state_prime", "obs", "rew", "done", "actions".  `out` lets a caller reuse the
-        [T,...] buffers of a previous call (the returned dict).  Returns a dict of [T,...] tensors.
+        with shared_actions=True, or None for the on-device random policy; a float64 array / tensor is
+        passed on as fp64 (the reference's action tables are float64, main.py:14-50), anything else as fp32.
+        want: any of "traj" (fp64 positions [T,N,2]), "state_prime", "obs", "rew", "done", "actions".
+        `out` lets a caller reuse the [T,...] buffers of a previous call (the returned dict).
+        carry: "f32" (default, cfg.rollout_carry) rounds the carried RK45 state to its HBM format after every
+        step -- bit-identical to T calls of step(); "f64" keeps it in fp64 registers for the whole launch.
+        Returns a dict of [T,...] tensors.
         Measurement aids: timed=True synchronises and returns "kernel_ms"; events=_lib.EventPair() attaches the
         pair to the dispatch without synchronising (read it later with .elapsed_ms())."""
         torch = _torch()
         n, dev = self.num_envs, self.device
-        act_t = None
+        act_t, act64 = None, False
         if actions is not None:
-            act_t = torch.as_tensor(actions, dtype=torch.float32, device=dev).contiguous()
+            act64 = (torch.is_tensor(actions) and actions.dtype == torch.float64) or \
+                    (isinstance(actions, np.ndarray) and actions.dtype == np.float64)
+            act_t = torch.as_tensor(actions, dtype=torch.float64 if act64 else torch.float32, device=dev).contiguous()
             assert act_t.shape == ((T, 2) if shared_actions else (T, n, 2))
+        carry = self.cfg.rollout_carry if carry is None else carry
+        if carry not in ("f32", "f64"):
+            raise ValueError("carry must be 'f32' or 'f64'")
         buf = out if out is not None else {}
 
         def get(key, shape, dtype):
@@ -287,7 +297,7 @@ class MRVecEnv:
         P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         io = _lib.MrsimRolloutIO(int(T), int(bool(shared_actions)), P(act_t), P(self.goal_table), P(traj), P(sp_T),
                                  P(obs_T), P(rew_T), P(done_T), P(acts_T), P(self.final_ret), P(self.final_len),
-                                 P(self.status))
+                                 P(self.status), 0, int(carry == "f64"), int(act64))
         args = [C.byref(self._params), n, self.env_id0, C.byref(self._st), C.byref(io), self.seed_value,
                 self.step_idx, self._stream()]
         if timed:
@@ -369,12 +379,34 @@ class MRVecEnv:
         return self.init_goal
 
     # ------------------------------------------------------------------ checkpoint
+    _CFG_STATE = ("noise_var", "a0", "is_mismatched", "init_low", "init_high")  # what reset() / set_init_space change
+
     def state_dict(self):
+        """Everything a resumed env needs to continue bit for bit: the per-env state, the RNG position -- host
+        step_idx plus, once capture_steps() / enable_device_step_base() moved the counter into HBM, the device word
+        it lives in -- and the cfg fields reset() kwargs and set_init_space() may have changed."""
+        sb = getattr(self, "_step_base", None)
         return {"pos": self.pos.clone(), "aux": self.aux.clone(), "ep_ret": self.ep_ret.clone(),
-                "step_idx": self.step_idx, "seed": self.seed_value, "env_id0": self.env_id0,
-                "prev_mismatched": self._prev_mismatched}
+                "final_ret": self.final_ret.clone(), "final_len": self.final_len.clone(),
+                "step_idx": self.step_idx, "step_base": None if sb is None else int(sb.item()),
+                "seed": self.seed_value, "env_id0": self.env_id0, "prev_mismatched": self._prev_mismatched,
+                "cfg": {k: getattr(self.cfg, k) for k in self._CFG_STATE}}
 
     def load_state_dict(self, sd):
         self.pos.copy_(sd["pos"]); self.aux.copy_(sd["aux"]); self.ep_ret.copy_(sd["ep_ret"])
-        self.step_idx, self.seed_value, self.env_id0 = int(sd["step_idx"]), int(sd["seed"]), int(sd["env_id0"])
+        if "final_ret" in sd:
+            self.final_ret.copy_(sd["final_ret"]); self.final_len.copy_(sd["final_len"])
+        self.seed_value, self.env_id0 = int(sd["seed"]), int(sd["env_id0"])
         self._prev_mismatched = bool(sd["prev_mismatched"])
+        for k, v in sd.get("cfg", {}).items():
+            setattr(self.cfg, k, v)
+        self.init_space = make_box(self.cfg.init_low, self.cfg.init_high)
+        # RNG position = step_base (device word, if this env keeps one) + step_idx; restore it in whichever form THIS
+        # env uses, so a checkpoint taken behind a captured graph resumes on an eager env and vice versa
+        total = int(sd["step_idx"]) + int(sd.get("step_base") or 0)
+        if getattr(self, "_step_base", None) is not None:
+            self._step_base.fill_(total)
+            self.step_idx = 0
+        else:
+            self.step_idx = total
+        self._refresh_params()

@@ -306,6 +306,7 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
     const double act[2] = {f_t, alpha_t}; /* :41 */
     const int mis = p->mismatched;
     e->n_rhs = 0; e->n_attempts = 0;
+    e->err_margin = INFINITY;
     NStream ns;
 
     if (p->integrator != ORC_INT_RK45) {
@@ -379,6 +380,7 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
             double e0 = 0, e1 = 0;
             for (int i = 0; i < 7; ++i) { e0 += K[i][0] * RK_E[i]; e1 += K[i][1] * RK_E[i]; }
             const double error_norm = rms2(e0 * h / sc0, e1 * h / sc1);
+            if (fabs(error_norm - 1.0) < e->err_margin) e->err_margin = fabs(error_norm - 1.0);
             if (error_norm < 1) {
                 double factor = (error_norm == 0) ? RK_MAX_FACTOR
                                                   : fmin(RK_MAX_FACTOR, RK_SAFETY * pow(error_norm, RK_ERR_EXP));

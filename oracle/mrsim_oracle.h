@@ -65,6 +65,9 @@ typedef struct {
     double h_abs;          /* integrator.h_abs                                          */
     double state_prime[2]; /* Simulator.state_prime = last RHS value (MR_simulator.py:87) */
     double ep_ret;         /* sum of rewards this episode (build extension)             */
+    double err_margin;     /* diagnostic: min over the last step's rk_step attempts of |error_norm - 1|, the   */
+                           /*   distance of the accept / reject decision from its discontinuity (tests use it  */
+                           /*   to tell a genuine decision flip from a kernel bug)                             */
     int32_t counter;       /* MR_Env.counter                                            */
     int32_t n_rhs;         /* RHS evaluations in the last step (diagnostic)             */
     int32_t n_attempts;    /* rk_step attempts in the last step (diagnostic)            */

@@ -33,14 +33,14 @@ class OrcParams(C.Structure):
 class OrcEnv(C.Structure):
     _fields_ = [
         ("y", C.c_double * 2), ("t", C.c_double), ("f", C.c_double * 2), ("h_abs", C.c_double),
-        ("state_prime", C.c_double * 2), ("ep_ret", C.c_double),
+        ("state_prime", C.c_double * 2), ("ep_ret", C.c_double), ("err_margin", C.c_double),
         ("counter", C.c_int32), ("n_rhs", C.c_int32), ("n_attempts", C.c_int32), ("status", C.c_int32),
     ]
 
 
 ENV_DTYPE = np.dtype([
     ("y", "<f8", 2), ("t", "<f8"), ("f", "<f8", 2), ("h_abs", "<f8"), ("state_prime", "<f8", 2),
-    ("ep_ret", "<f8"), ("counter", "<i4"), ("n_rhs", "<i4"), ("n_attempts", "<i4"), ("status", "<i4"),
+    ("ep_ret", "<f8"), ("err_margin", "<f8"), ("counter", "<i4"), ("n_rhs", "<i4"), ("n_attempts", "<i4"), ("status", "<i4"),
 ])
 
 

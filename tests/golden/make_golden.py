@@ -21,6 +21,9 @@ them is copied.  What is committed is data: inputs and the reference's outputs.
                 out-of-bounds termination is therefore documented as
                 "parity unpinned (gym absent)" in DESIGN.md.     (G6, G7)
 
+  ref_sim_f64.npz  the ref_sim scenarios with the reference's own float64 action tables (not rounded to float32).
+  ref_experiment.npz  MR_data.MRExperiment's dictionaries after three recorded MR_Env episodes (8f-3).
+
 Usage:  python tests/golden/make_golden.py   (writes next to this file)
 """
 import os
@@ -117,12 +120,14 @@ def run_simulator(actions, init, a0, noise_var, mismatched, mismatch_at_reset=Fa
     return out
 
 
-def gen_sim():
+def gen_sim(round_f32=True):
+    """round_f32=False: the reference's own float64 action tables (main.py:14-50 builds float64 linspace tables),
+    written to ref_sim_f64.npz -- pins the fp64 action-table input of the rollout (MrsimRolloutIO.actions_f64)."""
     rng = np.random.default_rng(20261004)
     cases = {}
 
     def add(name, actions, init, a0, mismatched=False, mismatch_at_reset=False):
-        actions = f32(actions)
+        actions = f32(actions) if round_f32 else np.asarray(actions, dtype=np.float64)
         r = run_simulator(actions, init, a0, 0.0, mismatched, mismatch_at_reset)
         cases[name] = dict(actions=actions, init=np.asarray(init, float), a0=a0,
                            mismatched=int(mismatched), mismatch_at_reset=int(mismatch_at_reset), **r)
@@ -144,8 +149,9 @@ def gen_sim():
     for name, d in cases.items():
         for k, v in d.items():
             flat[f"{name}/{k}"] = np.asarray(v)
-    np.savez_compressed(os.path.join(HERE, "ref_sim.npz"), **flat)
-    print("ref_sim.npz:", ", ".join(cases))
+    fname = "ref_sim.npz" if round_f32 else "ref_sim_f64.npz"
+    np.savez_compressed(os.path.join(HERE, fname), **flat)
+    print(fname + ":", ", ".join(cases))
 
 
 # --------------------------------------------------------------------------
@@ -293,9 +299,75 @@ def gen_env():
     print("ref_env.npz written")
 
 
+def gen_experiment():
+    """ref_experiment.npz: what the reference's own recorder, MR_data.MRExperiment (MR_data.py:27-57), holds after a
+    DDPG-style loop over the imported MR_Env with set_save_experice (MR_env.py:223-226; hooks :94-95,190-198):
+    three sigma = 0 episodes -- reset(init) then step until done.  The reference pickles itself into
+    ./_experiments/ from the second reset on (MR_env.py:190-192, MR_data.py:67-74), so the loop runs in a scratch
+    directory that has one; that pickle (written by the reference's code here, from our inputs) is read back through
+    the reference's own load_from_experiment as a cross-check and then discarded."""
+    _install_standins()
+    import contextlib
+    import io
+    import tempfile
+    import MR_env   # noqa: E402 (reference, unmodified)
+    import MR_data  # noqa: E402 (reference, unmodified)
+
+    rng = np.random.default_rng(515)
+    episodes = [
+        ([112.5, 103.25], actions_random(60, rng, idle_frac=0.0, wide=True)),  # times out at step 51
+        ([40.0, 0.0], np.tile([[20.0, np.pi]], (25, 1))),                      # reaches the goal at step 17
+        ([108.0, 119.5], actions_random(60, rng, idle_frac=0.1)),              # times out at step 51
+    ]
+    flat = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "_experiments"))
+        os.chdir(tmp)
+        try:
+            env = MR_env.MR_Env()
+            env.set_save_experice("golden")
+            for k, (init, actions) in enumerate(episodes):
+                actions = f32(actions)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    env.reset(init=np.asarray(init, dtype=np.float64), noise_var=0.0, a0=1.0, is_mismatched=False)
+                n = 0
+                for a in actions:
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        _, _, d, _ = env.step(a)
+                    n += 1
+                    if d:
+                        break
+                flat[f"in/{k}/init"] = np.asarray(init, dtype=np.float64)
+                flat[f"in/{k}/actions"] = actions[:n]
+            exp = env.MR_data
+            d = exp.__dict__
+            files = sorted(os.listdir("_experiments"))
+            if files:  # cross-check: the reference's own pickle, read by the reference's own loader
+                chk = MR_data.MRExperiment()
+                chk.load_from_experiment(files[-1])
+                assert chk.iterations >= 1 and np.array_equal(chk.states[0], d["states"][0])
+        finally:
+            os.chdir(cwd)
+    flat["iterations"] = np.asarray(d["iterations"])
+    flat["time_step"] = np.asarray(d["time_step"])
+    for key in ("states", "observations", "actions", "rewards"):
+        for it, v in d[key].items():
+            flat[f"{key}/{it}"] = np.asarray(v)
+    for it, v in d["steps"].items():
+        flat[f"steps/{it}"] = np.asarray(v)
+    flat["keys"] = np.asarray(sorted(d.keys()))
+    np.savez_compressed(os.path.join(HERE, "ref_experiment.npz"), **flat)
+    print("ref_experiment.npz: iterations", d["iterations"], "steps", dict(d["steps"]),
+          "dtypes", {k: str(np.asarray(d[k][0]).dtype) for k in ("states", "observations", "actions", "rewards")},
+          "keys", sorted(d.keys()))
+
+
 if __name__ == "__main__":
     import scipy
     print(f"numpy {np.__version__}, scipy {scipy.__version__}, reference at {REF}")
     gen_sim()
+    gen_sim(round_f32=False)
     gen_noise()
     gen_env()
+    gen_experiment()

@@ -1,0 +1,380 @@
+"""GPU tests added in round 2 (all through the C ABI):
+  * the MRExperiment-compatible recorder against the reference's own recorder (tests/golden/ref_experiment.npz);
+  * canary-poisoned guard regions around every per-env buffer for ragged sizes, both observation layouts;
+  * MR_Env.set_init_space / seed against the oracle;
+  * checkpoint / resume of an env whose RNG counter lives in HBM (captured hipGraph);
+  * the fp64-carry rollout, fp64 action tables (the reference's own float64 tables), sub-shard launches into shared
+    [T][N] buffers (row_stride), the table-driven sin/cos against libm.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import load_cases, orc_params_from_cfg
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POS_TOL = 1e-6
+
+
+def _env(n, seed=0, goal_table=None, env_id0=0, **cfg_kw):
+    from mr_rl_amd import MRConfig, MRVecEnv
+    return MRVecEnv(n, cfg=MRConfig(**cfg_kw), seed=seed, goal_table=goal_table, env_id0=env_id0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 8f-3: recorder vs the reference's MR_data.MRExperiment
+# ----------------------------------------------------------------------------------------------------------------------
+def test_recorder_matches_reference_mrexperiment(tmp_path):
+    """tests/golden/ref_experiment.npz holds MR_data.MRExperiment.__dict__ after the imported reference MR_Env recorded
+    three sigma = 0 episodes (set_save_experice; make_golden.py: gen_experiment).  recorder.record_episodes plays the
+    same inits / action tables through the fused rollout kernel: every key, shape, dtype and value must agree (states to
+    POS_TOL -- fp64 positions; observations to float32 resolution -- the kernel's obs are float32; actions, rewards,
+    steps exactly), the first row of every episode being the reset row with a zero action and reward [0]."""
+    from mr_rl_amd import recorder
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_experiment.npz"))
+    n_ep = int(g["iterations"]) + 1
+    inits = [g[f"in/{k}/init"] for k in range(n_ep)]
+    # the golden stopped each table at `done`; give the launch a few steps more to check that everything after the
+    # first done is dropped
+    tables = [np.vstack([g[f"in/{k}/actions"], np.tile(g[f"in/{k}/actions"][-1:], (3, 1))]) for k in range(n_ep)]
+    env = _env(8, noise_var=0.0)
+    d = recorder.record_episodes(env, inits, tables, env_index=5, noise_var=0.0, a0=1.0, is_mismatched=False)
+    env.check_status()
+    assert sorted(d.keys()) == [str(k) for k in g["keys"]]                      # MR_data.py:15-24
+    assert d["iterations"] == int(g["iterations"]) and d["time_step"] == int(g["time_step"])
+    assert d["info"] is None and d["viewer"] is None and d["scream"] is None and d["obs_states_str"] == {}
+    for it in range(n_ep):
+        steps = int(g[f"steps/{it}"])
+        assert d["steps"][it] == steps
+        for key, width in (("states", 2), ("observations", 5), ("actions", 2), ("rewards", 1)):
+            want, got = g[f"{key}/{it}"], d[key][it]
+            assert got.shape == want.shape == (steps + 1, width), (key, it, got.shape, want.shape)
+            assert got.dtype == want.dtype, (key, it, got.dtype, want.dtype)
+        np.testing.assert_allclose(d["states"][it], g[f"states/{it}"], rtol=0, atol=POS_TOL)
+        np.testing.assert_array_equal(d["states"][it][0], inits[it])                                   # reset row
+        want_obs = g[f"observations/{it}"]
+        tol = 2 * np.spacing(np.abs(want_obs).astype(np.float32)).astype(np.float64) + POS_TOL
+        assert np.all(np.abs(d["observations"][it] - want_obs) <= tol)
+        np.testing.assert_array_equal(d["actions"][it], g[f"actions/{it}"])
+        np.testing.assert_array_equal(d["actions"][it][0], [0.0, 0.0])                                 # MR_env.py:196
+        np.testing.assert_array_equal(d["rewards"][it], g[f"rewards/{it}"])
+        assert d["rewards"][it][0, 0] == 0 and (d["rewards"][it][1:] == 10).all()                    # MR_env.py:197,89
+    assert [int(g[f"steps/{i}"]) for i in range(n_ep)] == [51, 17, 51]
+    # round trip through the load the reference does: pickle.load + __dict__.update (MR_data.py:76-85)
+    path = tmp_path / "exp"
+    recorder.save_experiment(d, path)
+
+    class MRExperimentLike:
+        pass
+    m = MRExperimentLike()
+    m.__dict__.update(recorder.load_experiment(path))
+    assert m.iterations == d["iterations"] and m.steps == d["steps"]
+    for it in range(n_ep):
+        np.testing.assert_array_equal(m.states[it], d["states"][it])
+        np.testing.assert_array_equal(m.rewards[it], d["rewards"][it])
+
+
+def test_recorder_terminal_observation_uses_the_goal_of_the_terminal_step():
+    """With a goal table the goal moves along the episode; under auto-reset the returned observation of the done step
+    is the next episode's reset row, so the recorder rebuilds the terminal one -- from the goal of THAT step (ADVICE r01:
+    it used the reset goal)."""
+    from mr_rl_amd import recorder
+    T = 60
+    tab = np.zeros((1, T, 2), dtype=np.float32)
+    tab[0, :, 0] = 500 + 3.0 * np.arange(T); tab[0, :, 1] = -200 + 1.5 * np.arange(T)
+    env = _env(4, seed=3, goal_table=tab, noise_var=0.0, auto_reset=True)
+    env.reset()
+    out = env.rollout(55, want=("traj", "obs", "rew", "done", "actions"))
+    done = out["done"][:, 2].cpu().numpy()
+    t = int(np.argmax(done))
+    assert t == 50
+    g = lambda k: out[k][:, 2].cpu().numpy()  # noqa: E731
+    d = recorder.episodes_from_rollout(np.zeros(5), g("traj"), g("obs"), g("actions"), g("rew"), g("done"),
+                                       goals=tab[0, np.clip(np.arange(1, 56), 0, T - 1)], auto_reset=True)
+    term = d["observations"][0][-1]
+    np.testing.assert_allclose(term[2:4], tab[0, 51])            # the goal of step 51 (counter = 51), not of the reset
+    np.testing.assert_allclose(term[:2], g("traj")[t])
+    np.testing.assert_allclose(term[4], np.hypot(*(tab[0, 51] - g("traj")[t])), rtol=1e-12)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# canaries: nothing is written outside [n] / [n][5] / [5][n] / [T][n][.] for ragged sizes
+# ----------------------------------------------------------------------------------------------------------------------
+GUARD = 64  # elements on each side (a multiple of 16 bytes for every dtype used)
+
+
+class Guarded:
+    def __init__(self, torch, shape, dtype, fill=None):
+        self.numel = int(np.prod(shape))
+        self.big = torch.empty(self.numel + 2 * GUARD, dtype=dtype, device="cuda")
+        self.poison(torch)
+        self.view = self.big[GUARD:GUARD + self.numel].view(*shape)
+        if fill is not None:
+            self.view.fill_(fill)
+
+    def poison(self, torch):
+        raw = self.big.view(torch.uint8)
+        raw.copy_(torch.arange(raw.numel(), device="cuda").to(torch.uint8) * 37 + 11)
+        self.ref = raw.clone()
+
+    def intact(self, torch):
+        raw = self.big.view(torch.uint8)
+        item = self.big.element_size()
+        lo, hi = GUARD * item, (GUARD + self.numel) * item
+        return bool(torch.equal(raw[:lo], self.ref[:lo]) and torch.equal(raw[hi:], self.ref[hi:]))
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("n", [1, 63, 255, 257, 1023])
+def test_canary_guard_regions(n, layout):
+    """Every per-env buffer the kernels write (state, step outputs, final_*, [T][n][.] rollout outputs) sits between
+    poisoned guard regions; after resets, steps with auto-reset and a fused rollout the guards must be byte-identical
+    (the [n][5] tail store of the step kernel and the strided stores of the rollout are where a one-past write would
+    hide).  The guarded run must also equal a plain run bit for bit (the poison never leaks into a result)."""
+    import torch
+    from mr_rl_amd import _lib
+    T = 7
+    ref = _env(n, seed=13, noise_var=1.0, auto_reset=True, obs_layout=layout, max_timesteps=4)
+    env = _env(n, seed=13, noise_var=1.0, auto_reset=True, obs_layout=layout, max_timesteps=4)
+    oshape = (5, n) if layout == "soa" else (n, 5)
+    G = {}
+    for name, shape, dtype, fill in [("pos", (n, 2), torch.float64, 0.0), ("aux", (n, 4), torch.float32, 0.0),
+                                     ("ep_ret", (n,), torch.float32, 0.0), ("_obs", oshape, torch.float32, 0.0),
+                                     ("_final_obs", oshape, torch.float32, 0.0), ("rew", (n,), torch.float32, 0.0),
+                                     ("_done_u8", (n,), torch.uint8, 0), ("final_ret", (n,), torch.float32, 0.0),
+                                     ("final_len", (n,), torch.int32, 0)]:
+        G[name] = Guarded(torch, shape, dtype, fill)
+        setattr(env, name, G[name].view)
+    env._st = _lib.MrsimState(env.pos.data_ptr(), env.aux.data_ptr(), env.ep_ret.data_ptr())
+    env.reset(); ref.reset()
+    for _ in range(6):  # auto-reset fires at step 5 (max_timesteps = 4): final_* are written
+        a = ref.random_policy()
+        env.step(a.clone()); ref.step(a)
+    assert torch.equal(env.pos, ref.pos) and torch.equal(env._obs, ref._obs) and torch.equal(env.final_len, ref.final_len)
+    assert (env.final_len == 5).all()
+    # fused rollout into guarded [T][n][.] buffers
+    bufs = {}
+    want = ("traj", "state_prime", "obs", "rew", "done", "actions")
+    shapes = {"traj": ((T, n, 2), torch.float64), "state_prime": ((T, n, 2), torch.float32),
+              "obs": ((T, 5, n) if layout == "soa" else (T, n, 5), torch.float32), "rew": ((T, n), torch.float32),
+              "done": ((T, n), torch.uint8), "actions": ((T, n, 2), torch.float32)}
+    for k, (shape, dtype) in shapes.items():
+        G["T_" + k] = Guarded(torch, shape, dtype)
+        bufs["_" + k] = G["T_" + k].view
+    out = env.rollout(T, want=want, out=bufs)
+    outr = ref.rollout(T, want=want)
+    torch.cuda.synchronize()
+    for k in want:
+        assert out[k].data_ptr() == G["T_" + k].view.data_ptr()  # the guarded buffer really was the one written
+        assert torch.equal(out[k], outr[k]), k
+    assert torch.equal(env.pos, ref.pos) and torch.equal(env.aux, ref.aux)
+    bad = [k for k, g in G.items() if not g.intact(torch)]
+    assert not bad, f"guard region overwritten around {bad} (n={n}, layout={layout})"
+    env.check_status()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a12: set_init_space / seed
+# ----------------------------------------------------------------------------------------------------------------------
+def test_set_init_space_changes_what_reset_samples_and_matches_oracle():
+    """MR_env.py:154-155: set_init_space replaces init_space, which reset(init=None) samples (MR_env.py:172-173).
+    Positions must lie in the new box and be bit-equal to the oracle's orc_sample_init with the same bounds
+    (float32-rounded like gym's Box.sample)."""
+    n = 4096
+    env = _env(n, seed=77, noise_var=0.0)
+    obs = env.reset()
+    p0 = env.pos.cpu().numpy()
+    assert (p0 >= 100).all() and (p0 <= 120).all()
+    env.set_init_space([0.0, -3.0], [1.0, -1.0])
+    assert tuple(env.init_space.low) == (0.0, -3.0) and tuple(env.init_space.high) == (1.0, -1.0)
+    step_idx = env.step_idx
+    obs = env.reset()
+    p1 = env.pos.cpu().numpy()
+    assert (p1[:, 0] >= 0).all() and (p1[:, 0] <= 1).all() and (p1[:, 1] >= -3).all() and (p1[:, 1] <= -1).all()
+    orc = O.VecOracle(n, orc_params_from_cfg(env.cfg), seed=77)
+    orc.reset(step_idx)
+    np.testing.assert_array_equal(p1, orc.envs["y"])
+    np.testing.assert_array_equal(p1, p1.astype(np.float32).astype(np.float64))   # float32 samples (MR_env.py:40-42)
+    np.testing.assert_array_equal(obs.cpu().numpy()[:, :2], p1.astype(np.float32))
+    # a masked reset only touches the masked envs and uses the new box for them
+    mask = np.zeros(n, bool); mask[::3] = True
+    env.set_init_space([100.0, 100.0], [120.0, 120.0])
+    env.reset(mask=mask)
+    p2 = env.pos.cpu().numpy()
+    np.testing.assert_array_equal(p2[~mask], p1[~mask])
+    assert (p2[mask] >= 100).all()
+
+
+def test_seed_changes_and_repeats_the_stream():
+    """env.seed(n) (keras-rl era callers, old/MR_dqn_keras_rl.py:19): same seed => same stream, other seed => other."""
+    n = 2048
+
+    def run(seed_call):
+        env = _env(n, seed=1, noise_var=1.0, auto_reset=True)
+        assert env.seed(seed_call) == [seed_call]
+        env.reset()
+        for _ in range(5):
+            env.step(None)
+        return env.pos.cpu().numpy()
+    a, b, c = run(123), run(123), run(124)
+    np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(a, c)
+    env = _env(8, seed=5)
+    assert env.seed() == [5]   # no argument: reports the current seed
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# checkpoint with the RNG counter in HBM
+# ----------------------------------------------------------------------------------------------------------------------
+def test_state_dict_resumes_a_captured_graph_env_bitwise():
+    """After capture_steps() the step counter lives in a device word (step_idx is an offset from it).  state_dict()
+    must carry that word: a restored env -- eager or captured itself -- continues with the noise the original would
+    have drawn next, and the cfg fields reset() kwargs changed come along."""
+    import torch
+    n, G = 1500, 9
+    a = _env(n, seed=9, noise_var=1.0, auto_reset=True)
+    a.reset(noise_var=0.7, a0=1.3)
+    g = a.capture_steps(G, policy="kernel")
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    sd = a.state_dict()
+    assert sd["step_base"] == 1 + 3 * G and sd["step_idx"] == 0
+    assert sd["cfg"]["noise_var"] == 0.7 and sd["cfg"]["a0"] == 1.3
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    # (1) an eager env resumes from the checkpoint
+    b = _env(n, seed=0, noise_var=1.0, auto_reset=True)
+    b.load_state_dict(sd)
+    assert b.cfg.noise_var == 0.7 and b.cfg.a0 == 1.3 and b.step_idx == 1 + 3 * G
+    for _ in range(2 * G):
+        b.step(b.random_policy())
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.aux, b.aux) and torch.equal(a.ep_ret, b.ep_ret)
+    # (2) an env that keeps its own device counter resumes too
+    c = _env(n, seed=0, noise_var=1.0, auto_reset=True)
+    c.reset()
+    c.enable_device_step_base()
+    c.load_state_dict(sd)
+    assert int(c._step_base.item()) == 1 + 3 * G and c.step_idx == 0
+    for _ in range(2 * G):
+        c.step(c.random_policy())
+    assert torch.equal(a.pos, c.pos) and torch.equal(a.aux, c.aux)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fp64 carry, fp64 action tables, sub-shards, sin/cos table
+# ----------------------------------------------------------------------------------------------------------------------
+SIM = load_cases("ref_sim.npz")
+SIM64 = load_cases("ref_sim_f64.npz")
+
+
+def _golden_rollout(G, f64_actions, carry):
+    env = _env(4, noise_var=0.0, a0=float(G["a0"]), is_mismatched=bool(G["mismatched"]))
+    env._prev_mismatched = bool(G["mismatch_at_reset"])
+    env.reset(init=np.tile(G["init"][None, :], (4, 1)), is_mismatched=bool(G["mismatched"]))
+    acts = G["actions"].astype(np.float64 if f64_actions else np.float32)
+    traj = env.rollout(len(acts), actions=acts, shared_actions=True, want=("traj",), carry=carry)["traj"][:, 1, :].cpu().numpy()
+    env.check_status()
+    return traj
+
+
+@pytest.mark.parametrize("name", sorted(SIM))
+def test_golden_sim_fp64_carry(name):
+    """carry='f64': K0 / h_abs stay in fp64 registers for the whole launch, as the reference carries them; the fp32
+    carry was the whole 4e-7 RMSE of round 1.  Against the reference's own trajectories: <= 2e-9 absolute, 1e-9 RMSE."""
+    G = SIM[name]
+    traj = _golden_rollout(G, False, "f64")
+    err = np.abs(traj - G["pos"])
+    assert err.max() <= 2e-9, err.max()
+    assert np.sqrt(np.mean(np.sum((traj - G["pos"]) ** 2, axis=1))) <= 1e-9
+
+
+@pytest.mark.parametrize("name", sorted(SIM64))
+def test_golden_sim_float64_action_tables(name):
+    """The reference's own float64 action tables (not rounded to float32) through MrsimRolloutIO.actions_f64: the
+    float32 quantisation of the action ABI is out of the comparison.  Same bounds as above; the float32
+    path on these tables shows what the quantisation costs (reported, bounded by 1e-5)."""
+    G = SIM64[name]
+    traj = _golden_rollout(G, True, "f64")
+    assert np.abs(traj - G["pos"]).max() <= 2e-9
+    t32 = _golden_rollout(G, False, "f64")   # same tables rounded to float32 at the ABI
+    rmse32 = np.sqrt(np.mean(np.sum((t32 - G["pos"]) ** 2, axis=1)))
+    assert rmse32 <= 1e-5, rmse32            # BASELINE's gate still holds with float32 actions
+
+
+def test_sub_shard_launches_into_shared_buffers_equal_one_launch():
+    """MrsimRolloutIO.row_stride: two launches over env sub-ranges (each with its own state slice, env_id0 offset and
+    buffer pointers advanced to its first env) fill the columns of the same [T][N][.] buffers bit-identically to one
+    launch over all N envs -- also for a ragged split and [T][5][N] observations."""
+    import torch
+    from mr_rl_amd import _lib
+    N, T, cut = 1000, 53, 389
+    for layout in ("aos", "soa"):
+        full = _env(N, seed=4, noise_var=1.0, auto_reset=True, obs_layout=layout)
+        full.reset()
+        want = ("traj", "obs", "rew", "done", "actions")
+        ref = {k: v.clone() for k, v in full.rollout(T, want=want).items() if k in want}
+        env = _env(N, seed=4, noise_var=1.0, auto_reset=True, obs_layout=layout)
+        env.reset()
+        soa = layout == "soa"
+        bufs = {"traj": torch.zeros((T, N, 2), dtype=torch.float64, device="cuda"),
+                "obs": torch.zeros((T, 5, N) if soa else (T, N, 5), dtype=torch.float32, device="cuda"),
+                "rew": torch.zeros((T, N), dtype=torch.float32, device="cuda"),
+                "done": torch.zeros((T, N), dtype=torch.uint8, device="cuda"),
+                "actions": torch.zeros((T, N, 2), dtype=torch.float32, device="cuda")}
+        L = _lib.lib()
+        for first, n in ((0, cut), (cut, N - cut)):
+            st = _lib.MrsimState(env.pos[first:].data_ptr(), env.aux[first:].data_ptr(), env.ep_ret[first:].data_ptr())
+            obs_ptr = bufs["obs"][0, 0, first:].data_ptr() if soa else bufs["obs"][0, first:].data_ptr()
+            io = _lib.MrsimRolloutIO(T, 0, None, None, bufs["traj"][0, first:].data_ptr(), None, obs_ptr,
+                                     bufs["rew"][0, first:].data_ptr(), bufs["done"][0, first:].data_ptr(),
+                                     bufs["actions"][0, first:].data_ptr(), env.final_ret[first:].data_ptr(),
+                                     env.final_len[first:].data_ptr(), env.status.data_ptr(), N, 0, 0)
+            if first % 2 == 1 and False:
+                pass
+            rc = L.mrsim_rollout(C.byref(env._params), n, env.env_id0 + first, C.byref(st), C.byref(io), env.seed_value,
+                                 env.step_idx, env._stream())
+            assert rc == 0, _lib.strerror(rc)
+        torch.cuda.synchronize()
+        obs = bufs["obs"].transpose(1, 2) if soa else bufs["obs"]
+        assert torch.equal(bufs["traj"], ref["traj"]) and torch.equal(obs, ref["obs"])
+        assert torch.equal(bufs["rew"], ref["rew"]) and torch.equal(bufs["done"].bool(), ref["done"])
+        assert torch.equal(bufs["actions"], ref["actions"])
+        assert torch.equal(env.pos, full.pos) and torch.equal(env.final_len, full.final_len)
+    # a stride smaller than n is refused
+    io = _lib.MrsimRolloutIO(T, 0, None, None, None, None, None, None, None, None, None, None, None, N - 1, 0, 0)
+    st = _lib.MrsimState(env.pos.data_ptr(), env.aux.data_ptr(), env.ep_ret.data_ptr())
+    assert L.mrsim_rollout(C.byref(env._params), N, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EINVAL
+
+
+def test_table_sincos_matches_libm():
+    """The kernels take sin/cos of the action heading from a 1024-entry table + degree-5/4 polynomials (mrsim_device.h:
+    sincos_tab).  One sigma = 0 step from a fixed start isolates it: displacement = dt (1 - b1) a0 f (cos, sin) + the
+    same first-step terms the oracle (libm sin/cos) computes.  2e-13 absolute on positions ~100 (a few ulp) over the
+    whole supported range, table-cell edges, quadrant edges, and beyond +-4e6 rad where the polynomial path takes over."""
+    import torch
+    rng = np.random.default_rng(12)
+    k = np.arange(-2048, 2048)
+    al = np.concatenate([rng.uniform(-4 * np.pi, 4 * np.pi, 60000), k * (2 * np.pi / 1024), (k + 0.5) * (2 * np.pi / 1024),
+                         np.nextafter(k * (np.pi / 2), np.inf), rng.uniform(-3.9e6, 3.9e6, 20000),
+                         rng.uniform(-1e7, 1e7, 5000), [0.0, -0.0, 4.0e6, -4.0e6, 3999999.5]]).astype(np.float32)
+    n = len(al)
+    for carry, mis in (("f32", False), ("f64", True)):
+        env = _env(n, noise_var=0.0, a0=1.25, is_mismatched=mis)
+        init = np.tile(np.array([[103.5, -97.25]]), (n, 1))
+        env.reset(init=init, is_mismatched=mis)
+        a = np.stack([np.full(n, 20.0, np.float32), al], 1)
+        out = env.rollout(2, actions=np.stack([a, a]), want=("traj",), carry=carry)["traj"].cpu().numpy()
+        orc = O.VecOracle(n, orc_params_from_cfg(env.cfg), seed=0)
+        orc.reset(0, init_xy=init)
+        for t in range(2):
+            orc.step(a, step_idx=t + 1)
+            np.testing.assert_allclose(out[t], orc.envs["y"], rtol=0, atol=2e-13)
+        # the step kernel uses the same table arithmetic: identical bits
+        env2 = _env(n, noise_var=0.0, a0=1.25, is_mismatched=mis)
+        env2.reset(init=init, is_mismatched=mis)
+        env2.step(a)
+        np.testing.assert_array_equal(env2.pos.cpu().numpy(), out[0])
