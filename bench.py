@@ -73,7 +73,13 @@ def parse(argv=None):
                     help="rollout mode, carried RK45 state (integrator.f, h_abs) inside a launch: f64 registers (default; "
                          "what the reference carries) or rounded to its fp32 HBM format every step (bit-identical to "
                          "the step path)")
-    ap.add_argument("--policy", choices=["kernel", "fused"], default="kernel", help="step mode only")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="rollout mode: the envs of a GPU run as this many sub-shard launches on as many HIP streams "
+                         "(mr_rl_amd.collector; 1 = one launch per episode).  Kernel durations for `roofline` always come "
+                         "from a one-stream region")
+    ap.add_argument("--policy", choices=["kernel", "overlap", "fused"], default="kernel",
+                    help="step mode only: policy kernel -> HBM -> step kernel; the same with step t+1's policy kernel on a "
+                         "second captured stream beside step t; or drawn inside the step kernel")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph", help="step mode only")
     ap.add_argument("--graph-len", type=int, default=51)
     ap.add_argument("--obs-layout", choices=["aos", "soa"], default="aos")
@@ -256,31 +262,41 @@ def committed_valu_floor(args, n_local, T):
 
 def measure_step_path(cfg, n_local, dev, seed, steps=10200, samples=204):
     """Secondary figure reported beside the headline: the same workload driven through the drop-in gym loop,
-    one launch per MR_Env.step() ([policy kernel -> actions in HBM] + [step kernel], hipGraph of 51 steps)."""
+    one launch per MR_Env.step(), hipGraph of 51 steps: [policy kernel -> actions in HBM] + [step kernel] (`value`), and
+    with the exploration policy drawn inside the step kernel (`policy_in_step_kernel`, one kernel per step).  (A third
+    form, step t+1's policy kernel on a second captured stream beside step t -- capture_steps(policy="overlap") -- is
+    slower: graph replay pays ~5 us per cross-stream dependency, 14.7 vs 9.1 us per step; not measured here.)"""
     import torch
     from mr_rl_amd import MRVecEnv
-    env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed)
-    env.reset()
     ep = cfg.max_timesteps + 1
-    graph = env.capture_steps(ep, policy="kernel")
-    for _ in range(40):  # ~20 ms: lets the GPU clocks settle
-        graph.replay()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps // ep):
-        graph.replay()
-    torch.cuda.synchronize(dev)
-    el = time.perf_counter() - t0
     k = (steps // ep) * ep
+
+    def run(policy):
+        env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed)
+        env.reset()
+        graph = env.capture_steps(ep, policy=policy)
+        for _ in range(40):  # ~20 ms: lets the GPU clocks settle
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps // ep):
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        env.check_status()
+        return env, el
+
+    env, el = run("kernel")
     act = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
     ms = sorted(env.step_timed(env.random_policy(out=act)) for _ in range(samples))
     avg_ms = sum(ms) / len(ms)
     ach = n_local * ALGO_BYTES_PER_ENV_STEP / (avg_ms * 1e-3) / 1e9
-    env.check_status()
+    _, el_f = run("fused")
     return {"mode": "step (one launch per env.step, hipGraph of 51 steps, policy kernel + step kernel)",
             "value": n_local * k / el, "unit": "env-steps/s", "steps": k, "ms_per_step": el / k * 1e3,
             "kernel": "mr_step_kernel", "avg_kernel_us": round(avg_ms * 1e3, 3),
-            "roofline_frac": round(ach / HBM_PEAK_GBS, 4)}
+            "roofline_frac": round(ach / HBM_PEAK_GBS, 4),
+            "policy_in_step_kernel": {"value": n_local * k / el_f, "unit": "env-steps/s", "ms_per_step": el_f / k * 1e3}}
 
 
 def mixed_goal_table(cfg, seed):
@@ -299,29 +315,28 @@ def mixed_goal_table(cfg, seed):
 
 
 class RolloutRegion:
-    """Timed regions of the fused-rollout workload: `steps` env steps in launches of <= T cut at episode boundaries,
-    returns all-gathered at every episode boundary, barrier + synchronize on both sides, max over ranks.  Rank 0 can
-    attach a HIP event pair to every full-length dispatch (non-blocking, hipExtLaunchKernelGGL on the launch stream)."""
+    """Timed regions of the fused-rollout workload on a RolloutCollector (S sub-shard launches per episode on S HIP
+    streams): `steps` env steps in launch groups of <= T cut at episode boundaries, returns all-gathered at every episode
+    boundary, barrier + synchronize on both sides, max over ranks.  With S = 1, rank 0 can attach a HIP event pair to
+    every full-length dispatch (non-blocking, hipExtLaunchKernelGGL on the launch stream)."""
 
-    def __init__(self, env, gatherer, T, ep, want, world, dev, dist_backend, carry):
-        self.env, self.g, self.T, self.ep, self.want = env, gatherer, T, ep, want
-        self.world, self.dev, self.backend, self.carry = world, dev, dist_backend, carry
-        self.bufs = {}
+    def __init__(self, col, gatherer, ep, world, dev, dist_backend):
+        self.col, self.g, self.T, self.ep = col, gatherer, col.T, ep
+        self.world, self.dev, self.backend = world, dev, dist_backend
         self.done_steps = 0
         self.launches = 0
 
     def run(self, nsteps, pool=None, used=None):
-        env, T, ep = self.env, self.T, self.ep
+        col, T, ep = self.col, self.T, self.ep
         left = nsteps
         while left > 0:
             chunk = min(left, T, ep - (self.done_steps % ep))
             ev = None
-            if pool is not None and chunk == T and len(used) < len(pool):
-                ev = pool[len(used)]
-                used.append(ev)
-            env.rollout(chunk, actions=None, want=self.want, out=self.bufs if chunk == T else None, events=ev,
-                        carry=self.carry)
-            self.launches += 1
+            if pool is not None and chunk == T and col.S == 1 and len(used) < len(pool):
+                ev = [pool[len(used)]]
+                used.append(ev[0])
+            col.collect(events=ev, steps=chunk)
+            self.launches += len(col.shards)
             self.done_steps += chunk
             left -= chunk
             if self.done_steps % ep == 0:
@@ -332,7 +347,7 @@ class RolloutRegion:
         import torch.distributed as dist
         if self.world > 1:
             dist.barrier()
-        torch.cuda.synchronize(self.dev)
+        torch.cuda.synchronize(self.dev)  # device-wide: the sub-shard streams included
 
     def timed(self, nsteps, pool=None, used=None):
         """-> (seconds: max over ranks, launches in the region)"""
@@ -353,28 +368,35 @@ class RolloutRegion:
         return el, self.launches - l0
 
 
-def measure_mixed_set(args, n_local, env_id0, world, dev, seed, steps=10200):
+def make_region(args, cfg, n_local, env_id0, world, dev, seed, streams, goal_table=None, T=None):
+    from mr_rl_amd.collector import RolloutCollector
+    from mr_rl_amd.dist import ReturnGatherer
+    ep = cfg.max_timesteps + 1
+    col = RolloutCollector(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0, goal_table=goal_table,
+                           streams=streams, T=T if T is not None else ep, carry=args.carry)
+    col.reset()
+    g = ReturnGatherer(col.env, world, source=lambda: col.ready()["final_ret"], release=col.release)
+    return RolloutRegion(col, g, ep, world, dev, args.dist_backend)
+
+
+def measure_mixed_set(args, n_local, env_id0, world, dev, seed, streams, steps=10200):
     """Secondary figure (every rank takes part, same barrier / max-over-ranks protocol as the headline): the fused
     rollout on BASELINE config 5's mixed straight-line / figure-eight / random-waypoint trajectory set with the
     goal reward, returns all-gathered once per episode."""
-    from mr_rl_amd import MRConfig, MRVecEnv
-    from mr_rl_amd.dist import ReturnGatherer
+    from mr_rl_amd import MRConfig
     cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math,
                    seed=seed, is_mismatched=args.mismatched)
     tab = mixed_goal_table(cfg, seed)
-    env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0, goal_table=tab)
-    env.reset()
-    g = ReturnGatherer(env, world)
-    ep = cfg.max_timesteps + 1
-    reg = RolloutRegion(env, g, ep, ep, ("obs", "rew", "done", "actions"), world, dev, args.dist_backend, args.carry)
+    reg = make_region(args, cfg, n_local, env_id0, world, dev, seed, streams, goal_table=tab)
+    ep = reg.ep
     reg.run(20 * ep)
     k = (steps // ep) * ep
     el, launches = reg.timed(k)
-    env.check_status()
+    reg.col.check_status()
     return {"workload": "BASELINE config 5 trajectory set: env_id mod 3 -> straight line / figure eight / random "
                         "waypoints (goal table), goal reward, same policy / noise / outputs as the headline",
             "value": n_local * world * k / el, "unit": "env-steps/s", "steps": k, "launches": launches,
-            "ms_per_step": el / k * 1e3, "mean_episode_return": g.last_mean()}
+            "streams": reg.col.S, "ms_per_step": el / k * 1e3, "mean_episode_return": reg.g.last_mean()}
 
 
 def trajectory_rmse(dev, carry):
@@ -454,30 +476,31 @@ def main():
     goal_table = None
     if args.workload == "mixed":
         goal_table = mixed_goal_table(cfg, seed)
-    env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0, goal_table=goal_table)
-    env.reset()
-    gatherer = ReturnGatherer(env, world)
     K, W = max(args.steps, 1), max(args.warmup, 0)
     ep = cfg.max_timesteps + 1
-    WANT = ("obs", "rew", "done", "actions")
     from mr_rl_amd._lib import EventPair
     launch = args.launch
     if pmc and launch == "graph":
         launch = "eager"
+    streams = 1 if pmc else max(1, args.streams)  # under counter collection dispatches are serialised anyway
 
     if args.mode == "rollout":
         T = args.rollout_len
-        reg = RolloutRegion(env, gatherer, T, ep, WANT, world, dev, args.dist_backend, args.carry)
-        run = reg.run
-        launch_desc = {"rollout_len": T, "transition_bytes_per_env_step": 33, "carry": args.carry}
+        reg = make_region(args, cfg, n_local, env_id0, world, dev, seed, streams, goal_table=goal_table, T=T)
+        run, gatherer = reg.run, reg.g
+        launch_desc = {"rollout_len": T, "transition_bytes_per_env_step": 33, "carry": args.carry, "streams": streams,
+                       "sub_shards": [n for _, n in reg.col.shards]}
     else:
+        env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0, goal_table=goal_table)
+        env.reset()
+        gatherer = ReturnGatherer(env, world)
         G = args.graph_len
         act = torch.empty((n_local, 2), dtype=torch.float32, device=dev)
         done_steps = [0]
         n_launches = [0]
 
         def eager_step():
-            if args.policy == "kernel":
+            if args.policy in ("kernel", "overlap"):
                 env.step(env.random_policy(out=act))
             else:
                 env.step(None)
@@ -496,7 +519,7 @@ def main():
                         env.step_idx = 0
                     for _ in range(chunk):
                         eager_step()
-                    n_launches[0] += chunk * (2 if args.policy == "kernel" else 1)
+                    n_launches[0] += chunk * (1 if args.policy == "fused" else 2)
                     if graph is not None:
                         env.advance_step_base(chunk)
                         env.step_idx = 0
@@ -519,7 +542,8 @@ def main():
     barrier()
     trace("warm-up done; timed region")
     # ---- the contract's timed region: EXACTLY K steps between barrier + synchronize, max over ranks
-    ev_pool = [EventPair() for _ in range(min(K // ep + 1, 4096))] if (rank == 0 and args.mode == "rollout") else None
+    one_stream = args.mode == "rollout" and streams == 1
+    ev_pool = [EventPair() for _ in range(min(K // ep + 1, 4096))] if (rank == 0 and one_stream) else None
     ev_used = []
     if args.mode == "rollout":
         el, launches = reg.timed(K, ev_pool, ev_used)
@@ -537,59 +561,75 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
     trace("timed region done")
-    env.check_status()
+    (reg.col if args.mode == "rollout" else env).check_status()
     mean_ret = gatherer.last_mean()
     region_ms = [e.elapsed_ms() for e in ev_used]
-
-    # ---- sustained leg: the same workload over its own >= 10 200-step region (every rank takes part)
-    sustained = None
-    sus_ms = []
-    if args.mode == "rollout" and args.sustained_steps > 0:
-        ks = max(args.sustained_steps // ep, 1) * ep
-        pool2 = None
-        if rank == 0:
-            pool2 = ev_pool if len(ev_pool) >= ks // reg.T + 1 else [EventPair() for _ in range(ks // reg.T + 1)]
-        used2 = []
-        els, ls = reg.timed(ks, pool2, used2)
-        sus_ms = [e.elapsed_ms() for e in used2]
-        sustained = {"what": "the headline workload over its own region after the settle phase, independent of --steps",
-                     "value": total * ks / els, "unit": "env-steps/s", "steps": ks, "launches": ls,
-                     "ms_per_step": els / ks * 1e3}
-        if sus_ms:
-            avg_us, med_us = stats_us(sus_ms)
-            sustained.update({"avg_kernel_us": round(avg_us, 3), "median_kernel_us": round(med_us, 3),
-                              "kernel_time_over_wall": round(sum(sus_ms) * 1e-3 / els, 4),
-                              "in_kernel_value": n_local * reg.T / (avg_us * 1e-6)})
-        if pool2 is not None and pool2 is not ev_pool:
-            for e in pool2:
-                e.close()
-        trace("sustained leg done")
     if ev_pool is not None:
         for e in ev_pool:
             e.close()
 
+    # ---- sustained legs (every rank takes part): the same workload over its own >= 10 200-step region, (a) as
+    # configured (S streams), (b) one launch per episode on ONE stream with a HIP event pair on every dispatch -- the
+    # kernel durations `roofline` is built from
+    sustained = None
+    sus_ms = []
+    if args.mode == "rollout" and args.sustained_steps > 0:
+        ks = max(args.sustained_steps // ep, 1) * ep
+
+        def leg(region, with_events):
+            pool2 = [EventPair() for _ in range(ks // region.T + 1)] if (with_events and rank == 0) else None
+            used2 = []
+            els, ls = region.timed(ks, pool2, used2)
+            ms = [e.elapsed_ms() for e in used2]
+            if pool2 is not None:
+                for e in pool2:
+                    e.close()
+            d = {"value": total * ks / els, "unit": "env-steps/s", "steps": ks, "launches": ls, "streams": region.col.S,
+                 "ms_per_step": els / ks * 1e3}
+            if ms:
+                avg_us, med_us = stats_us(ms)
+                d.update({"avg_kernel_us": round(avg_us, 3), "median_kernel_us": round(med_us, 3),
+                          "kernel_time_over_wall": round(sum(ms) * 1e-3 / els, 4),
+                          "in_kernel_value": n_local * region.T / (avg_us * 1e-6)})
+            return d, ms
+
+        sustained, sus_ms = leg(reg, one_stream)
+        sustained["what"] = "the headline workload over its own region after the settle phase, independent of --steps"
+        if not one_stream:
+            reg1 = make_region(args, cfg, n_local, env_id0, world, dev, seed, 1, goal_table=goal_table, T=T)
+            reg1.run(40 * ep)  # its own buffers and state; the clocks are settled already
+            one, sus_ms = leg(reg1, True)
+            reg1.col.check_status()
+            one["what"] = "the same on ONE stream, one launch per episode: the per-dispatch kernel durations behind `roofline`"
+            sustained["one_stream"] = one
+            del reg1
+        trace("sustained legs done")
+
     mixed = None
     if args.mode == "rollout" and args.workload == "ddpg" and not args.no_mixed_set:
-        mixed = measure_mixed_set(args, n_local, env_id0, world, dev, seed)
+        mixed = measure_mixed_set(args, n_local, env_id0, world, dev, seed, streams)
         trace("mixed set done")
 
     # ---- roofline of the dominant kernel (rank 0): durations from HIP events attached to the dispatches
-    # (hipExtLaunchKernelGGL) on the stream they run on.  Rollout mode: the dispatches of the sustained region (or of the
-    # timed region when that leg is off).  Step mode (graph replays cannot carry per-dispatch events): separate timed
-    # launches right after the region, same state regime.
+    # (hipExtLaunchKernelGGL) on the stream they run on.  Rollout mode: the dispatches of the one-stream sustained region
+    # (or of the timed region when that leg is off).  Step mode (graph replays cannot carry per-dispatch events): separate
+    # timed launches right after the region, same state regime.
     roof = None
     if rank == 0:
         law = "mismatched" if args.mismatched else "nominal"
         nz = "nonoise" if args.sigma == 0 else args.noise_math
         if args.mode == "rollout":
             T = args.rollout_len
-            ms, timed_where = (sus_ms, "the %d dispatches of the sustained region" % len(sus_ms)) if sus_ms else \
+            ms, timed_where = (sus_ms, "the %d dispatches of the one-stream sustained region" % len(sus_ms)) if sus_ms else \
                 (region_ms, "the %d full-length dispatches of the timed region" % len(region_ms))
-            if not ms:  # fewer than T steps were timed and no sustained leg: sample afterwards instead
+            if not ms:  # no sustained leg and a multi-stream / short timed region: sample afterwards instead
                 ns = args.kernel_samples or 10
-                ms = [env.rollout(T, actions=None, want=WANT, out=reg.bufs, timed=True, carry=args.carry)["kernel_ms"]
-                      for _ in range(ns)]
-                timed_where = "%d launches right after the timed region" % len(ms)
+                env1 = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0, goal_table=goal_table)
+                env1.reset()
+                b1 = {}
+                ms = [env1.rollout(T, actions=None, want=reg.col.want, out=b1, timed=True, carry=args.carry)["kernel_ms"]
+                      for _ in range(ns + 20)][20:]
+                timed_where = "%d launches after the timed region" % len(ms)
             avg_us, med_us = stats_us(ms)
             units = n_local * T
             traffic, traffic_src = committed_traffic(args, n_local)
@@ -616,7 +656,7 @@ def main():
                     "median_kernel_us": round(med_us, 3), "env_steps_per_launch": units}
         else:
             ns = args.kernel_samples or 102
-            ms = [env.step_timed(env.random_policy(out=act) if args.policy == "kernel" else None) for _ in range(ns)]
+            ms = [env.step_timed(env.random_policy(out=act) if args.policy != "fused" else None) for _ in range(ns)]
             avg_us, med_us = stats_us(ms)
             units = n_local
             traffic, traffic_src = committed_traffic(args, n_local)

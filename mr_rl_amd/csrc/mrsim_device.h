@@ -215,15 +215,19 @@ __device__ __forceinline__ float sqrt_rn_small(float w) {
 
 // Box-Muller.  kNoiseSpec: specified operation by operation (oracle/mrsim_oracle.c: orc_box_muller),
 // bit-identical to the oracle.  kNoiseFast: same uniforms, same formula, hardware transcendentals
-// (v_log_f32, v_sqrt_f32, v_sin_f32/v_cos_f32 take the angle in revolutions): within ~1e-6 of the spec.
+// (v_log_f32, v_sqrt_f32, v_sin_f32/v_cos_f32 take the angle in revolutions): within 1e-6 + 7.5e-7 r of the spec.
 template <int NZ>
-__device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float& z0, float& z1) {
+__device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float& z0, float& z1, float* radius = nullptr) {
     const float u = __builtin_fmaf((float)ua, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
     if constexpr (NZ == kNoiseFast) {
         const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // -2 ln2 log2 u
-        const float t = __builtin_fmaf((float)ub, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+        // angle in revolutions for v_sin / v_cos, which are 1-periodic: 1 + (ub >> 9) * 2^-23 in [1, 2), assembled by ONE
+        // v_alignbit_b32 ({0x7F, ub} >> 9 = 0x3F800000 | ub >> 9) instead of v_cvt_f32_u32 + v_fma.  Top 23 bits of ub:
+        // within 2^-23 revolutions of the spec's (ub + 0.5) 2^-32, i.e. a normal within 7.5e-7 r of the spec's.
+        const float t = __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, ub, 9u));
         z0 = r * __builtin_amdgcn_cosf(t);
         z1 = r * __builtin_amdgcn_sinf(t);
+        if (radius != nullptr) *radius = r;
     } else {
         const float r = sqrt_rn_small(-2.0f * spec_logf(u));
         const uint32_t oct = ub >> 29;
@@ -249,6 +253,7 @@ __device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float& z0, 
         if (sneg) ss = -ss;
         z0 = r * cc;
         z1 = r * ss;
+        if (radius != nullptr) *radius = r;
     }
 }
 
@@ -431,6 +436,18 @@ __device__ __forceinline__ void noise_vec(const KParams& P, const RhsCtx<MIS>& C
     }
 }
 
+// K = V + N for one RHS evaluation, one fma per term
+template <bool MIS>
+__device__ __forceinline__ void rhs_value(const KParams& P, const RhsCtx<MIS>& C, float za, float zx, float zy,
+                                          double& kx, double& ky) {
+    kx = __builtin_fma(P.sigma, (double)zx, C.vx);
+    ky = __builtin_fma(P.sigma, (double)zy, C.vy);
+    if constexpr (MIS) {
+        kx = __builtin_fma(C.gx, (double)za, kx);
+        ky = __builtin_fma(C.gy, (double)za, ky);
+    }
+}
+
 // progress of the sub-step loop of one env step (+ what the constructor needs from its last attempt)
 struct SubStep {
     double tau, h_abs;
@@ -483,9 +500,11 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
             float z0, z1;
             box_muller<NZ>(LS->f0a, LS->f0b, z0, z1);
             if constexpr (MIS) {
-                noise_vec<MIS>(P, C, z0, z1, LS->f0y, n0x, n0y);
+                noise_vec<MIS>(P, C, z0, z1, LS->f0y, n0x, n0y);  // n0 itself only feeds the fp32 fallback test
+                rhs_value<MIS>(P, C, z0, z1, LS->f0y, f0x, f0y);
             } else {
                 noise_vec<MIS>(P, C, 0.f, z0, z1, n0x, n0y);
+                rhs_value<MIS>(P, C, 0.f, z0, z1, f0x, f0y);
             }
             have1 = need_f1;
             if (have1) eval_f1();
@@ -497,13 +516,15 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
         block_normals<NZ, NC>(R, c0_of(stream, 0, 0), z);
         if constexpr (MIS) {
             noise_vec<MIS>(P, C, z[0], z[1], z[2], n0x, n0y);
+            rhs_value<MIS>(P, C, z[0], z[1], z[2], f0x, f0y);
             noise_vec<MIS>(P, C, z[3], z[4], z[5], n1x, n1y);
         } else {
             noise_vec<MIS>(P, C, 0.f, z[0], z[1], n0x, n0y);
+            rhs_value<MIS>(P, C, 0.f, z[0], z[1], f0x, f0y);
             noise_vec<MIS>(P, C, 0.f, z[2], z[3], n1x, n1y);
         }
     }
-    f0x = C.vx + n0x; f0y = C.vy + n0y;
+    if constexpr (NZ == kNoNoise) { f0x = C.vx; f0y = C.vy; }
     spx = C.vx + n1x; spy = C.vy + n1y;
 
     const double sc0 = __builtin_fma(__builtin_fabs(x), P.rtol, P.atol);
@@ -600,11 +621,14 @@ constexpr float kB2f = (float)(500.0 / 1113), kB3f = (float)(125.0 / 192), kB4f 
 constexpr float kE2f = (float)(71.0 / 16695), kE3f = (float)(-71.0 / 1920), kE4f = (float)(17253.0 / 339200),
                 kE5f = (float)(-22.0 / 525), kE6f = (float)(1.0 / 40);
 constexpr int kMaxAttempts = 4096;  // every lane leaves the loop: bounded spin
+// |z| of this generator never exceeds sqrt(-2 ln 2^-33) = 6.763 (u >= 2^-33); bound with margin
+constexpr double kZmaxE6 = 6.78 * (1.0 / 40);  // Zmax * E6
 
 // weighted noise sums of one rk_step attempt:  nb = sum_{2..5} B_i N_i,  ne = sum_{2..6} E_i N_i,
 // n6 = N_6 (f_new's noise; only matters when another sub-step follows)
 struct AttemptNoise {
-    double nbx, nby, nex, ney;
+    float bx32, by32, ba32;  // sum_{2..5} B_i z_i per component (z_a: mismatched law only)
+    double nex, ney;
     float z6a, z6x, z6y;  // f_new's normals; only needed when another sub-step follows
     // lazy K6 (nominal law, first attempt): error sums WITHOUT the E6*z6 term and the two Philox words of
     // K6's Box-Muller pair; nex/ney/z6* are filled by finish_k6() only if the bound test cannot decide
@@ -617,6 +641,11 @@ struct AttemptNoise {
     uint32_t k6a, k6b;   // mismatched: the words of the pair (K6x, K6y)
     uint32_t w3[4];      // the block's last call (3 nominal / 5 mismatched), valid when have3
     bool have3;
+    // nominal law: the E-weighted sums (ex32, ey32) are formed lazily (finish_e) from the kept stage normals kz; the
+    // level-0 accept test only needs R32 = Zmax E6 + sum_{2..5} |E_i| r_i >= |sum_{2..6} E_i z_i| (r_i = the Box-Muller
+    // radius of stage i: |z| = r |cos| <= r)
+    float kz[8], R32;
+    bool lazyE;
 };
 
 template <int NZ, bool MIS, bool FIRST>
@@ -624,11 +653,14 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
                                                       uint32_t attempt, const uint32_t* d0) {
     AttemptNoise A;
     if constexpr (NZ == kNoNoise) {
-        A.nbx = A.nby = A.nex = A.ney = 0.0;
+        A.bx32 = A.by32 = A.ba32 = 0.f; A.nex = A.ney = 0.0;
         A.z6a = A.z6x = A.z6y = 0.f;
         A.ex32 = A.ey32 = A.ea32 = 0.f; A.lazy6 = false;
         A.f0a = A.f0b = A.k6a = A.k6b = 0u; A.f0y = 0.f;
         A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u; A.have3 = false;
+        A.R32 = 0.f; A.lazyE = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) A.kz[j] = 0.f;
         return A;
     } else if constexpr (!MIS) {
         // nominal law: call 0 = [K1 (dead) | K2], call 1 = [K3 | K4], call 2 = [K5 | F0], call 3 = [K6 | F1].
@@ -650,21 +682,24 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         }
         A.f0a = w[2][2]; A.f0b = w[2][3];
         A.k6a = A.k6b = 0u; A.f0y = 0.f; A.ea32 = 0.f;
-        float k2x, k2y, k3x, k3y, k4x, k4y, k5x, k5y;
-        box_muller<NZ>(w[0][2], w[0][3], k2x, k2y);
-        box_muller<NZ>(w[1][0], w[1][1], k3x, k3y);
-        box_muller<NZ>(w[1][2], w[1][3], k4x, k4y);
-        box_muller<NZ>(w[2][0], w[2][1], k5x, k5y);
+        float k2x, k2y, k3x, k3y, k4x, k4y, k5x, k5y, r2, r3, r4, r5;
+        box_muller<NZ>(w[0][2], w[0][3], k2x, k2y, &r2);
+        box_muller<NZ>(w[1][0], w[1][1], k3x, k3y, &r3);
+        box_muller<NZ>(w[1][2], w[1][3], k4x, k4y, &r4);
+        box_muller<NZ>(w[2][0], w[2][1], k5x, k5y, &r5);
         float bx = kB2f * k2x, by = kB2f * k2y;
         bx = __builtin_fmaf(kB3f, k3x, bx); by = __builtin_fmaf(kB3f, k3y, by);
         bx = __builtin_fmaf(kB4f, k4x, bx); by = __builtin_fmaf(kB4f, k4y, by);
         bx = __builtin_fmaf(kB5f, k5x, bx); by = __builtin_fmaf(kB5f, k5y, by);
-        float ex = kE2f * k2x, ey = kE2f * k2y;
-        ex = __builtin_fmaf(kE3f, k3x, ex); ey = __builtin_fmaf(kE3f, k3y, ey);
-        ex = __builtin_fmaf(kE4f, k4x, ex); ey = __builtin_fmaf(kE4f, k4y, ey);
-        ex = __builtin_fmaf(kE5f, k5x, ex); ey = __builtin_fmaf(kE5f, k5y, ey);
-        A.nbx = P.sigma * (double)bx; A.nby = P.sigma * (double)by;
-        A.ex32 = ex; A.ey32 = ey;
+        float Rb = __builtin_fmaf(kE2f, r2, (float)kZmaxE6);   // E2, E4, E6 > 0 > E3, E5
+        Rb = __builtin_fmaf(-kE3f, r3, Rb);
+        Rb = __builtin_fmaf(kE4f, r4, Rb);
+        Rb = __builtin_fmaf(-kE5f, r5, Rb);
+        A.R32 = Rb * 1.0001f;  // fp32 rounding of the four terms
+        A.kz[0] = k2x; A.kz[1] = k2y; A.kz[2] = k3x; A.kz[3] = k3y; A.kz[4] = k4x; A.kz[5] = k4y; A.kz[6] = k5x; A.kz[7] = k5y;
+        A.lazyE = true;
+        A.bx32 = bx; A.by32 = by; A.ba32 = 0.f;
+        A.ex32 = A.ey32 = 0.f;
         A.nex = A.ney = 0.0; A.z6a = A.z6x = A.z6y = 0.f;
         A.lazy6 = true;
         return A;
@@ -707,17 +742,28 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         ea = __builtin_fmaf(kE4f, k4[0], ea); ex = __builtin_fmaf(kE4f, k4[1], ex); ey = __builtin_fmaf(kE4f, k4[2], ey);
         ea = __builtin_fmaf(kE5f, k5[0], ea); ex = __builtin_fmaf(kE5f, k5[1], ex); ey = __builtin_fmaf(kE5f, k5[2], ey);
         ea = __builtin_fmaf(kE6f, A.z6a, ea);
-        A.nbx = __builtin_fma(C.gx, (double)ba, P.sigma * (double)bx);
-        A.nby = __builtin_fma(C.gy, (double)ba, P.sigma * (double)by);
+        A.bx32 = bx; A.by32 = by; A.ba32 = ba;
         A.ex32 = ex; A.ey32 = ey; A.ea32 = ea;
         A.nex = A.ney = 0.0; A.z6x = A.z6y = 0.f;
         A.lazy6 = true;
+        A.R32 = 0.f; A.lazyE = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) A.kz[j] = 0.f;
         return A;
     }
 }
 
-// |z| of this generator never exceeds sqrt(-2 ln 2^-33) = 6.763 (u >= 2^-33); bound with margin
-constexpr double kZmaxE6 = 6.78 * (1.0 / 40);  // Zmax * E6
+
+// the E-weighted sums of stages 2..5 from the kept normals (same fp32 chain as the eager form had)
+__device__ __forceinline__ void finish_e(AttemptNoise& A) {
+    if (!A.lazyE) return;
+    float ex = kE2f * A.kz[0], ey = kE2f * A.kz[1];
+    ex = __builtin_fmaf(kE3f, A.kz[2], ex); ey = __builtin_fmaf(kE3f, A.kz[3], ey);
+    ex = __builtin_fmaf(kE4f, A.kz[4], ex); ey = __builtin_fmaf(kE4f, A.kz[5], ey);
+    ex = __builtin_fmaf(kE5f, A.kz[6], ex); ey = __builtin_fmaf(kE5f, A.kz[7], ey);
+    A.ex32 = ex; A.ey32 = ey;
+    A.lazyE = false;
+}
 
 // evaluate K6's Box-Muller pair and complete the error sums (same fp32 chain as the eager form: E6 is its last term)
 template <int NZ, bool MIS>
@@ -751,7 +797,10 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
     S.attempt += 1;
     const double dfx = f0x - C.vx, dfy = f0y - C.vy;
     double sx = __builtin_fma(kB0, dfx, C.vx), sy = __builtin_fma(kB0, dfy, C.vy);
-    if constexpr (NZ != kNoNoise) { sx += A.nbx; sy += A.nby; }
+    if constexpr (NZ != kNoNoise) {  // + sum_{2..5} B_i N_i, one fma per term (N = sigma z [+ g z_a])
+        sx = __builtin_fma(P.sigma, (double)A.bx32, sx); sy = __builtin_fma(P.sigma, (double)A.by32, sy);
+        if constexpr (MIS) { sx = __builtin_fma(C.gx, (double)A.ba32, sx); sy = __builtin_fma(C.gy, (double)A.ba32, sy); }
+    }
     const double xn = __builtin_fma(h, sx, x);
     const double yn = __builtin_fma(h, sy, y);
     const bool last = !(tn < P.dt);
@@ -766,23 +815,26 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
             if (last) {
                 const double l0 = __builtin_fma(__builtin_fabs(x), P.rtol, P.atol);
                 const double l1 = __builtin_fma(__builtin_fabs(y), P.rtol, P.atol);
-                double pex = __builtin_fma(P.sigma, (double)A.ex32, kE0 * dfx);
-                double pey = __builtin_fma(P.sigma, (double)A.ey32, kE0 * dfy);
-                if constexpr (MIS) {  // the g*z_a terms (K6a included) are already exact in ea32
-                    pex = __builtin_fma(C.gx, (double)A.ea32, pex);
-                    pey = __builtin_fma(C.gy, (double)A.ea32, pey);
+                // level 0 (max norm, nominal law): |err| <= h (|E0| max|K0 - V| + sigma (Zmax E6 + sum |E_i| r_i)) per
+                // component; if that is below 0.99 x the smaller scale, each ratio of the rms norm is < 1 =>
+                // error_norm < 1.  A handful of operations, and the E-weighted sums of the stage normals are not even
+                // formed; decides practically every step away from the origin (typical error_norm there is 0.03 .. 0.1).
+                // Not used under the mismatched law: its velocities (a0' = a0 + 0.2 f: up to 100) and the extra g*z_a
+                // noise put error_norm near 0.5, where this test fails for half the waves and only adds work (measured).
+                if constexpr (!MIS && MRSIM_AB_CHEAP) {
+                    const double dmax = fmax(__builtin_fabs(dfx), __builtin_fabs(dfy));
+                    const double eb = __builtin_fma(P.sigma, (double)A.R32, -kE0 * dmax);
+                    if (__builtin_expect(h * eb <= 0.99 * fmin(l0, l1), 1)) { accepted = true; decided = true; }
                 }
-                // level 0 (max norm): both worst-case error components below 0.99 x the smaller scale => each ratio
-                // of the rms norm is < 1 => error_norm < 1.  Five fp64 operations; decides practically every step
-                // away from the origin under the nominal law (typical error_norm there is 0.03 .. 0.1).  Not used
-                // under the mismatched law: its velocities (a0' = a0 + 0.2 f: up to 100) and the extra g*z_a noise
-                // put error_norm near 0.5, where this test fails for half the waves and only adds work (measured).
-                const double emax = fmax(__builtin_fabs(pex), __builtin_fabs(pey));
-                if (MRSIM_AB_CHEAP && !MIS &&
-                    __builtin_expect(__builtin_fma(h, emax, h * P.zmax_e6_sigma) <= 0.99 * fmin(l0, l1), 1)) {
-                    accepted = true; decided = true;
-                } else {
+                if (!decided) {
                     // level 1 (rms norm with the worst-case K6): sqrt(2) less pessimistic
+                    finish_e(A);
+                    double pex = __builtin_fma(P.sigma, (double)A.ex32, kE0 * dfx);
+                    double pey = __builtin_fma(P.sigma, (double)A.ey32, kE0 * dfy);
+                    if constexpr (MIS) {  // the g*z_a terms (K6a included) are already exact in ea32
+                        pex = __builtin_fma(C.gx, (double)A.ea32, pex);
+                        pey = __builtin_fma(C.gy, (double)A.ea32, pey);
+                    }
                     const double b6 = h * P.zmax_e6_sigma;
                     const double l00 = l0 * l0, l11 = l1 * l1;
                     const double axw = __builtin_fabs(h * pex) + b6;
@@ -792,6 +844,7 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
                     }
                 }
             }
+            if (!decided) finish_e(A);
             if (!decided) finish_k6<NZ, MIS>(P, C, R, S.attempt - 1, A);
         }
     }

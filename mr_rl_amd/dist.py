@@ -76,9 +76,15 @@ class ReturnGatherer:
     waited on (stream-side wait, no host block).  latest() / last_mean() wait for the newest gather.
     """
 
-    def __init__(self, env, world_size=1, group=None):
+    def __init__(self, env, world_size=1, group=None, source=None, release=None):
+        """source: optional callable returning the [n_local] returns of the episode that just ended, after making the
+        current stream wait for whatever produces them (mr_rl_amd.collector.RolloutCollector: `lambda:
+        collector.ready()["final_ret"]`); default env.final_ret.  release: optional callable invoked once the returns
+        have been staged (the collector may then overwrite that buffer set)."""
         import torch
         self.env, self.world, self.group = env, int(world_size), group
+        self._source = source if source is not None else (lambda: env.final_ret)
+        self._release = release
         n = env.num_envs
         self._stage = [torch.zeros(n, dtype=torch.float32, device=env.device) for _ in range(2)]
         self._all = [torch.zeros(self.world * n, dtype=torch.float32, device=env.device) for _ in range(2)]
@@ -99,7 +105,9 @@ class ReturnGatherer:
         if self._pending[k] is not None:
             self._pending[k].wait()  # the collective that used these buffers two episodes ago
             self._pending[k] = None
-        self._stage[k].copy_(self.env.final_ret)
+        self._stage[k].copy_(self._source())
+        if self._release is not None:
+            self._release()
         if dist.get_backend(self.group) == "gloo" and self._stage[k].is_cuda:
             gather_returns(self._stage[k], out=self._all[k], group=self.group)  # rehearsal path, synchronous
         elif self.mode == "async":
@@ -122,7 +130,7 @@ class ReturnGatherer:
         if self.n_gathers == 0:
             return None
         if not self._distributed():
-            return self.env.final_ret
+            return self._source()
         k = (self.n_gathers - 1) % 2
         if self._pending[k] is not None:
             self._pending[k].wait()

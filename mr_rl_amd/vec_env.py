@@ -244,14 +244,14 @@ class MRVecEnv:
         self.step_idx += 1
         return ms.value
 
-    def random_policy(self, out=None):
+    def random_policy(self, out=None, lookahead=0):
         """actions[N,2] ~ U[policy_low, policy_high) on device (consumes no step index: it is keyed by the
-        step it feeds)."""
+        step it feeds -- the next step() by default, the one `lookahead` steps later otherwise)."""
         torch = _torch()
         if out is None:
             out = torch.empty((self.num_envs, 2), dtype=torch.float32, device=self.device)
         rc = self._L.mrsim_random_policy(C.byref(self._params), self.num_envs, self.env_id0, self._p(out),
-                                         self.seed_value, self.step_idx, self._stream())
+                                         self.seed_value, self.step_idx + int(lookahead), self._stream())
         _lib.check(rc, "mrsim_random_policy")
         return out
 
@@ -294,20 +294,9 @@ class MRVecEnv:
         rew_T = get("rew", (T, n), torch.float32)
         done_T = get("done", (T, n), torch.uint8)
         acts_T = get("actions", (T, n, 2), torch.float32)
-        P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        io = _lib.MrsimRolloutIO(int(T), int(bool(shared_actions)), P(act_t), P(self.goal_table), P(traj), P(sp_T),
-                                 P(obs_T), P(rew_T), P(done_T), P(acts_T), P(self.final_ret), P(self.final_len),
-                                 P(self.status), 0, int(carry == "f64"), int(act64))
-        args = [C.byref(self._params), n, self.env_id0, C.byref(self._st), C.byref(io), self.seed_value,
-                self.step_idx, self._stream()]
-        if timed:
-            ms = C.c_float(0.0)
-            _lib.check(self._L.mrsim_rollout_timed(*args, C.byref(ms)), "mrsim_rollout_timed")
-            buf["kernel_ms"] = ms.value
-        elif events is not None:
-            _lib.check(self._L.mrsim_rollout_events(*args, events.start, events.stop), "mrsim_rollout_events")
-        else:
-            _lib.check(self._L.mrsim_rollout(*args), "mrsim_rollout")
+        self.launch_rollout(T, 0, n, act_t=act_t, shared_actions=shared_actions, act64=act64, traj=traj, sp_T=sp_T,
+                            obs_T=obs_T, rew_T=rew_T, done_T=done_T, acts_T=acts_T, carry=carry, timed_into=buf if timed else None,
+                            events=events)
         self.step_idx += int(T)
         if traj is not None:
             buf["traj"] = traj
@@ -323,22 +312,82 @@ class MRVecEnv:
             buf["actions"] = acts_T
         return buf
 
+    def launch_rollout(self, T, first, n, act_t=None, shared_actions=False, act64=False, traj=None, sp_T=None, obs_T=None,
+                       rew_T=None, done_T=None, acts_T=None, final_ret=None, final_len=None, carry="f32", step_idx=None,
+                       stream=None, timed_into=None, events=None):
+        """One mrsim_rollout launch over the envs [first, first + n) of this env set (a sub-shard when n < num_envs):
+        state, final_* and every [T, N, ...] buffer are passed advanced to env `first`, the buffers keep their row
+        length N (MrsimRolloutIO.row_stride), the RNG keys stay the GLOBAL env ids.  Does not advance step_idx (the
+        caller launches all sub-shards of a rollout with the same step_idx and advances once).  mr_rl_amd.collector
+        uses it to put sub-shards on different HIP streams."""
+        N = self.num_envs
+        assert 0 <= first and n >= 1 and first + n <= N
+        fr = self.final_ret if final_ret is None else final_ret
+        fl = self.final_len if final_len is None else final_len
+
+        def P(t, per_env_elems=None, soa_obs=False):
+            """device pointer of t advanced to env `first`; t is [T, N, k] / [T, N] (or [T, 5, N] for SoA observations),
+            or [N, ...] when per_env_elems is given"""
+            if t is None:
+                return None
+            if per_env_elems is not None:
+                return t.data_ptr() + first * per_env_elems * t.element_size()
+            if soa_obs:
+                return t.data_ptr() + first * t.element_size()
+            return t.data_ptr() + first * int(np.prod(t.shape[2:], dtype=np.int64)) * t.element_size()
+
+        st = _lib.MrsimState(P(self.pos, 2), P(self.aux, 4), P(self.ep_ret, 1))
+        a_ptr = None
+        if act_t is not None:
+            a_ptr = act_t.data_ptr() if shared_actions else P(act_t)
+        io = _lib.MrsimRolloutIO(int(T), int(bool(shared_actions)), a_ptr, None if self.goal_table is None else
+                                 self.goal_table.data_ptr(), P(traj), P(sp_T), P(obs_T, soa_obs=self._soa), P(rew_T),
+                                 P(done_T), P(acts_T), P(fr, 1), P(fl, 1), self.status.data_ptr(),
+                                 0 if n == N else N, int(carry == "f64"), int(act64))
+        sidx = self.step_idx if step_idx is None else int(step_idx)
+        strm = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        args = [C.byref(self._params), n, self.env_id0 + first, C.byref(st), C.byref(io), self.seed_value, sidx, strm]
+        if timed_into is not None:
+            ms = C.c_float(0.0)
+            _lib.check(self._L.mrsim_rollout_timed(*args, C.byref(ms)), "mrsim_rollout_timed")
+            timed_into["kernel_ms"] = ms.value
+        elif events is not None:
+            _lib.check(self._L.mrsim_rollout_events(*args, events.start, events.stop), "mrsim_rollout_events")
+        else:
+            _lib.check(self._L.mrsim_rollout(*args), "mrsim_rollout")
+
     def capture_steps(self, G, policy="kernel"):
         """Capture G env steps into one hipGraph (torch.cuda.CUDAGraph is only the capture plumbing).
         policy: "kernel" = policy kernel writes actions to HBM, step kernel reads them (the shape of a
-        real actor -> env.step(actions) loop); "fused" = the step kernel draws the policy itself.
+        real actor -> env.step(actions) loop); "overlap" = the same two kernels, but the exploration policy of step
+        t + 1 -- which depends on nothing but (seed, step index, env id) -- runs on a second captured stream while the
+        step kernel of step t runs (two rotating action buffers).  Measured SLOWER on MI355X / ROCm 7.2 (14.7 vs 9.1 us per
+        step at N = 262 144: graph replay pays ~5 us for every cross-stream dependency), kept for the record and tested;
+        "fused" = the step kernel draws the policy itself.
         Each replay advances the device step base by G, so replays draw fresh noise."""
         torch = _torch()
         self.enable_device_step_base()
-        act = torch.empty((self.num_envs, 2), dtype=torch.float32, device=self.device)
+        acts = [torch.empty((self.num_envs, 2), dtype=torch.float32, device=self.device) for _ in range(2)]
+        side2 = torch.cuda.Stream(device=self.device) if policy == "overlap" else None
 
         def body():
             self.step_idx = 0
-            for _ in range(G):
-                if policy == "kernel":
-                    self.step(self.random_policy(out=act))
-                else:
-                    self.step(None)
+            if policy == "overlap":
+                main = torch.cuda.current_stream(self.device)
+                self.random_policy(out=acts[0])
+                for g in range(G):
+                    if g + 1 < G:
+                        side2.wait_stream(main)      # acts[(g+1)%2] was read by step g-1, which is on `main`
+                        with torch.cuda.stream(side2):
+                            self.random_policy(out=acts[(g + 1) % 2], lookahead=1)
+                    self.step(acts[g % 2])
+                    main.wait_stream(side2)          # step g+1 reads what side2 has just been asked to write
+            else:
+                for _ in range(G):
+                    if policy == "kernel":
+                        self.step(self.random_policy(out=acts[0]))
+                    else:
+                        self.step(None)
             self.advance_step_base(G)
             self.step_idx = 0
 
@@ -351,6 +400,7 @@ class MRVecEnv:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             body()
+        self._graph_keepalive = (acts, side2)
         return graph
 
     def check_status(self):

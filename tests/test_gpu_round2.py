@@ -361,13 +361,19 @@ def test_table_sincos_matches_libm():
     al = np.concatenate([rng.uniform(-4 * np.pi, 4 * np.pi, 60000), k * (2 * np.pi / 1024), (k + 0.5) * (2 * np.pi / 1024),
                          np.nextafter(k * (np.pi / 2), np.inf), rng.uniform(-3.9e6, 3.9e6, 20000),
                          rng.uniform(-1e7, 1e7, 5000), [0.0, -0.0, 4.0e6, -4.0e6, 3999999.5]]).astype(np.float32)
-    n = len(al)
-    for carry, mis in (("f32", False), ("f64", True)):
+    for mis in (False, True):
+        if mis:
+            # the reference forms cos(alpha + 0.1) / sin(alpha - 0.15) from the ROUNDED sums (MR_simulator.py:79-80): at
+            # |alpha| ~ 1e6 that rounding alone moves the result by 1e-9, while the kernel's angle addition does not
+            # round the angle.  Compare the mismatched law where the sum is exact to 1e-14 (|alpha| < 64).
+            al = al[np.abs(al) < 64.0]
+        n = len(al)
         env = _env(n, noise_var=0.0, a0=1.25, is_mismatched=mis)
         init = np.tile(np.array([[103.5, -97.25]]), (n, 1))
         env.reset(init=init, is_mismatched=mis)
         a = np.stack([np.full(n, 20.0, np.float32), al], 1)
-        out = env.rollout(2, actions=np.stack([a, a]), want=("traj",), carry=carry)["traj"].cpu().numpy()
+        # carry f64: nothing but the sin/cos (and fma contraction) separates kernel and oracle over these two steps
+        out = env.rollout(2, actions=np.stack([a, a]), want=("traj",), carry="f64")["traj"].cpu().numpy()
         orc = O.VecOracle(n, orc_params_from_cfg(env.cfg), seed=0)
         orc.reset(0, init_xy=init)
         for t in range(2):
@@ -378,3 +384,83 @@ def test_table_sincos_matches_libm():
         env2.reset(init=init, is_mismatched=mis)
         env2.step(a)
         np.testing.assert_array_equal(env2.pos.cpu().numpy(), out[0])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# RolloutCollector: sub-shard launches on several HIP streams
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("streams", [1, 2, 3])
+def test_collector_streams_equal_the_single_launch(streams):
+    """The envs of one GPU as S sub-shard launches on S streams, rotating [T][N][.] buffer sets: every episode's
+    transitions, returns and the final env state are bit-identical to one launch per episode on one stream (same
+    global env ids, same step indices) -- also for a ragged 3-way split, and with the consumer (this test) reading
+    episode k while episode k + 1 is already enqueued."""
+    import torch
+    from mr_rl_amd import MRConfig
+    from mr_rl_amd.collector import RolloutCollector
+    N, E = 70000, 5
+    cfg = dict(noise_var=1.0, auto_reset=True)
+    ref = _env(N, seed=11, env_id0=1000, **cfg)
+    ref.reset()
+    col = RolloutCollector(N, cfg=MRConfig(**cfg), seed=11, env_id0=1000, streams=streams, carry="f32")
+    col.reset()
+    assert sum(n for _, n in col.shards) == N and len(col.shards) == streams
+    want = ("obs", "rew", "done", "actions")
+    col.collect()
+    for k in range(E):
+        if k + 1 < E:
+            col.collect()                 # episode k + 1 is in flight while episode k is read
+        got = col.ready(k)
+        exp = ref.rollout(col.T, want=want)
+        for key in want:
+            assert torch.equal(got[key], exp[key]), (k, key)
+        assert torch.equal(got["final_ret"], ref.final_ret) and torch.equal(got["final_len"], ref.final_len)
+        assert (got["final_len"] == 51).all()
+        col.release(k)
+    col.join()
+    assert torch.equal(col.env.pos, ref.pos) and torch.equal(col.env.aux, ref.aux)
+    assert col.env.step_idx == ref.step_idx
+    col.check_status()
+
+
+def test_collector_feeds_the_return_gatherer():
+    """ReturnGatherer(source = collector.ready, release = collector.release): single process => latest() is the newest
+    episode's returns of ALL envs (the all-gather path itself is covered over gloo in tests/test_dist_cpu.py)."""
+    from mr_rl_amd import MRConfig
+    from mr_rl_amd.collector import RolloutCollector
+    from mr_rl_amd.dist import ReturnGatherer
+    col = RolloutCollector(5000, cfg=MRConfig(noise_var=1.0, auto_reset=True, reward_mode="goal"), seed=2, streams=2)
+    col.reset()
+    g = ReturnGatherer(col.env, 1, source=lambda: col.ready()["final_ret"], release=col.release)
+    for _ in range(3):
+        col.collect()
+        g.gather()
+    r = g.latest()
+    assert r.shape == (5000,) and g.n_gathers == 3
+    assert abs(g.last_mean() - float(col.ready()["final_ret"].mean())) < 1e-6
+    assert (r < 0).all()   # goal reward: 50 x -0.1 - 100 at the timeout, nobody reaches (0,0) from [100,120]^2
+
+
+def test_overlapped_policy_graph_equals_the_sequential_one():
+    """capture_steps(policy="overlap"): step t+1's policy kernel runs on a second captured stream beside step t, with two
+    rotating action buffers.  Same actions, same noise => bit-identical to the sequential capture and to eager steps,
+    replay after replay."""
+    import torch
+    n, G = 5000, 13
+    a = _env(n, seed=5, noise_var=1.0, auto_reset=True); a.reset()
+    b = _env(n, seed=5, noise_var=1.0, auto_reset=True); b.reset()
+    c = _env(n, seed=5, noise_var=1.0, auto_reset=True); c.reset()
+    ga = a.capture_steps(G, policy="overlap")
+    gb = b.capture_steps(G, policy="kernel")
+    for _ in range(G):
+        c.step(c.random_policy())
+    torch.cuda.synchronize()
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.pos, c.pos)
+    for rep in range(5):   # 5 x 13 steps: crosses an auto-reset (step 51)
+        ga.replay(); gb.replay()
+        for _ in range(G):
+            c.step(c.random_policy())
+        torch.cuda.synchronize()
+        assert torch.equal(a.pos, b.pos) and torch.equal(a.obs, b.obs) and torch.equal(a.aux, b.aux), rep
+        assert torch.equal(a.pos, c.pos) and torch.equal(a.final_len, c.final_len), rep
+    a.check_status()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of kernel variants of the fused rollout (cdna_hip_programming.md rule 24: N variants x M rounds
-in ONE process, per-launch HIP events, median and min reported).  Variants are libmrsim builds with different -D
+in ONE process, per-launch HIP events, median and min reported), in blocks of several hundred back-to-back launches
+whose first hundred are discarded: the chip lowers its clock under this load within tens of ms (DVFS), and by a
+different amount for variants that draw different power.  Variants are libmrsim builds with different -D
 switches (make -C mr_rl_amd/csrc variants -> mr_rl_amd/variants/libmrsim_<tag>.so), optionally ":f64" for the fp64 carry.
 Usage (GPU box):  python tools/ab_rollout.py [--rounds 10] [--launches 30] [--workload ddpg|mixed] tag[:f64] ...
 Also prints max |pos difference| of every variant against the first one after the same number of steps."""
@@ -12,8 +14,11 @@ from mr_rl_amd import MRConfig, MRVecEnv, _lib
 
 ap = argparse.ArgumentParser()
 ap.add_argument("variants", nargs="+")
-ap.add_argument("--rounds", type=int, default=10)
-ap.add_argument("--launches", type=int, default=30)
+ap.add_argument("--rounds", type=int, default=4)
+ap.add_argument("--launches", type=int, default=400,
+                help="back-to-back launches per variant and round; long blocks so that each variant runs at the clock the "
+                     "chip holds for IT (short interleaved blocks let a power-hungrier variant ride the previous one's clock)")
+ap.add_argument("--discard", type=int, default=100, help="leading launches of every block left out of the statistics")
 ap.add_argument("--envs", type=int, default=262144)
 ap.add_argument("--workload", default="ddpg")
 ap.add_argument("--mismatched", action="store_true")
@@ -42,9 +47,10 @@ for r in range(a.rounds):
     for v, e, b, ms in order:
         for k in range(a.launches):
             e.rollout(T, want=WANT, out=b, events=pool[k])
-        ms.extend(p.elapsed_ms() for p in pool)
+        ms.extend([p.elapsed_ms() for p in pool][a.discard:])
 ref = envs[0][1].pos.clone()
-print(f"# N={a.envs} T={T} workload={a.workload} mismatched={a.mismatched} rounds={a.rounds} x launches={a.launches} (interleaved, one process)")
+print(f"# N={a.envs} T={T} workload={a.workload} mismatched={a.mismatched} rounds={a.rounds} x launches={a.launches} "
+      f"(first {a.discard} of each block discarded; blocks interleaved in one process)")
 base = statistics.median(envs[0][3])
 for v, e, b, ms in envs:
     e.check_status()

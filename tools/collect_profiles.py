@@ -1,71 +1,163 @@
 #!/usr/bin/env python3
 """Turn the scratch output of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the committed evidence under
-profiles/<tag>/:  kernel_stats_bench_{rollout,step}.csv, bench_under_rocprof_rollout.json and pmc_traffic.json.
+profiles/<tag>/:  kernel_stats_bench_{rollout,step}.csv, bench_under_rocprof_rollout.json, pmc_traffic.json,
+pmc_valu.json, instbench.json.
 
-Usage (in the repo root, after `gpurun -- bash tools/profile_round.sh r01`):  python tools/collect_profiles.py r01
+STRICT (a crashed profiler pass was hidden behind an older CSV): exits non-zero and leaves profiles/<tag>/
+untouched when
+  * status.txt is missing, lists a pass with a non-zero exit code, or lacks an expected pass;
+  * a pass left no CSV, or left more than one run directory (stale output mixed in);
+  * the round was taken with another bench.py / libmrsim.so than the ones in this tree (sha256 in sha.txt).
+Every JSON records the source CSV, its mtime and the sha256 prefixes of bench.py / libmrsim.so it describes.
+
+Usage (repo root, after `gpurun -- bash tools/profile_round.sh r02`):  python tools/collect_profiles.py r02
 """
-import csv, glob, json, os, shutil, sys
+import csv, glob, hashlib, json, os, shutil, sys, time
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = f"gpurun_out/prof_{tag}"
 dst = f"profiles/{tag}"
-os.makedirs(dst, exist_ok=True)
+N, T, ALGO = 262144, 51, 97
+WAVES = N // 64
 
 
-def newest(pattern):
-    f = sorted(glob.glob(pattern), key=os.path.getmtime)
-    return f[-1] if f else None
+def die(msg):
+    print(f"collect_profiles: {msg} -- profiles/{tag}/ left untouched", file=sys.stderr)
+    sys.exit(1)
 
 
-for sub, name in (("kt", "kernel_stats_bench_rollout.csv"), ("kt_step", "kernel_stats_bench_step.csv")):
-    f = newest(f"{src}/{sub}/*/*kernel_stats.csv")
-    if f:
-        shutil.copy(f, f"{dst}/{name}")
-        print("copied", f, "->", name)
-if os.path.exists(f"{src}/kt_bench.json"):
-    line = [l for l in open(f"{src}/kt_bench.json").read().splitlines() if l.startswith("{")]
-    if line:
-        open(f"{dst}/bench_under_rocprof_rollout.json", "w").write(line[-1] + "\n")
+def sha16(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
-def counter_avg(dirname, counter, kernel_sub):
-    """mean Counter_Value over the dispatches of kernels whose name contains kernel_sub"""
-    f = newest(f"{src}/{dirname}/*/*counter_collection.csv")
-    if not f:
-        return None, 0
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-         if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]]
-    return (sum(v) / len(v), len(v)) if v else (None, 0)
+EXPECTED = ["kt", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
+                                             for p in ("pmc_f64", "pmc_f32", "pmc_step", "cal", "cal262k")] + \
+           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")]
+if not os.path.exists(f"{src}/status.txt"):
+    die(f"{src}/status.txt not found (did tools/profile_round.sh {tag} run?)")
+status = dict(l.split() for l in open(f"{src}/status.txt").read().splitlines() if l.strip())
+bad = [k for k in EXPECTED if status.get(k) != "0"]
+if bad:
+    die("passes failed or missing: " + ", ".join(f"{k}={status.get(k, 'absent')}" for k in bad))
+shas = {os.path.basename(l.split()[1]): l.split()[0][:16] for l in open(f"{src}/sha.txt").read().splitlines()}
+here = {"bench.py": sha16("bench.py"), "libmrsim.so": sha16("mr_rl_amd/libmrsim.so")}
+if shas != here:
+    die(f"the round describes bench.py/libmrsim.so {shas}, this tree has {here}")
 
 
-ALGO = 97
-out = {
+def the_csv(dirname, suffix):
+    f = glob.glob(f"{src}/{dirname}/*/*{suffix}")
+    if len(f) != 1:
+        die(f"{src}/{dirname}: expected exactly one *{suffix}, found {len(f)}")
+    return f[0]
+
+
+def counters(dirname, kernel_sub, skip_first=0.5):
+    """{counter: mean value per dispatch} over the later dispatches of kernels whose name contains kernel_sub"""
+    f = the_csv(dirname, "counter_collection.csv")
+    agg, grid = {}, None
+    for r in csv.DictReader(open(f)):
+        if kernel_sub in r["Kernel_Name"]:
+            agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            grid = int(r["Grid_Size"])
+    if not agg:
+        die(f"{f}: no dispatch of a kernel matching {kernel_sub!r}")
+    out = {}
+    for c, v in agg.items():
+        v = v[int(len(v) * skip_first):]
+        out[c] = sum(v) / len(v)
+    return out, len(next(iter(agg.values()))), grid, f
+
+
+prov = lambda f: {"csv": os.path.relpath(f, src), "csv_mtime": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(f)))}  # noqa: E731
+stamp = {"bench_py_sha16": here["bench.py"], "libmrsim_so_sha16": here["libmrsim.so"], "round": tag}
+
+# ---- everything is gathered first; files are only written once nothing can fail any more
+files = {}
+files["kernel_stats_bench_rollout.csv"] = open(the_csv("kt", "kernel_stats.csv")).read()
+files["kernel_stats_bench_step.csv"] = open(the_csv("kt_step", "kernel_stats.csv")).read()
+line = [l for l in open(f"{src}/kt.out").read().splitlines() if l.startswith("{")]
+if not line:
+    die("kt.out holds no bench JSON line")
+files["bench_under_rocprof_rollout.json"] = line[-1] + "\n"
+inst = json.load(open(f"{src}/instbench.out"))
+files["instbench.json"] = json.dumps({"what": "tools/instbench --json: ns per wave-instruction per SIMD, 8 independent chains per wave",
+                                      **stamp, "rows": inst}, indent=1) + "\n"
+
+traffic = {
     "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B, "
-             "MI355X_MICROARCH.md HBM section), WRITE_SIZE is exact",
+             "MI355X_MICROARCH.md HBM section), WRITE_SIZE is exact; both calibrated below on tools/membench whose bytes are known",
     "commands": "tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of `python3 bench.py "
-                "--no-cpu-baseline --steps 102 [--mode step --launch eager]` and of tools/membench); tools/collect_profiles.py",
-    "calibration": {}, "kernels": {},
+                "--no-cpu-baseline --no-step-path --no-mixed-set --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0 "
+                "[--carry f64|f32] [--mode step --launch eager]` and of tools/membench); tools/collect_profiles.py",
+    **stamp, "calibration": {}, "kernels": {},
 }
 for label, d, n in (("membench pattern<256> n=16777216", "cal", 16777216), ("membench pattern<256> n=262144", "cal262k", 262144)):
-    fr, _ = counter_avg(f"{d}_FETCH_SIZE", "FETCH_SIZE", "pattern<256, 0>")
-    wr, _ = counter_avg(f"{d}_WRITE_SIZE", "WRITE_SIZE", "pattern<256, 0>")
-    if fr is None or wr is None:
-        continue
-    out["calibration"][label] = {"known_read_KiB": n * 44 / 1024, "FETCH_SIZE_raw_KiB": fr, "FETCH_SIZE_x2_KiB": 2 * fr,
-                                 "known_write_KiB": n * 61 / 1024, "WRITE_SIZE_KiB": wr}
-N = 262144
-for label, pre, sub, units in (("mr_rollout_kernel<RK45,fast,nominal> T=51 N=262144", "pmc", "mr_rollout_kernel<true, 2, false", N * 51),
-                               ("mr_step_kernel<RK45,fast,nominal,aos> N=262144", "pmc_step", "mr_step_kernel<true, 2, false, true", N)):
-    fr, nf = counter_avg(f"{pre}_FETCH_SIZE", "FETCH_SIZE", sub)
-    wr, nw = counter_avg(f"{pre}_WRITE_SIZE", "WRITE_SIZE", sub)
-    if fr is None or wr is None:
-        continue
-    b = (2 * fr + wr) * 1024
-    out["kernels"][label] = {"FETCH_SIZE_raw_KiB": fr, "WRITE_SIZE_KiB": wr, "dispatches_averaged": [nf, nw],
-                             "hbm_bytes_per_launch": b, "algorithmic_bytes_per_launch": units * ALGO,
-                             "traffic_over_algorithmic": b / (units * ALGO), "bytes_per_env_step": b / units}
-if out["kernels"]:
-    json.dump(out, open(f"{dst}/pmc_traffic.json", "w"), indent=1)
-    print(json.dumps(out["kernels"], indent=1))
-else:
-    print("no PMC output found under", src, "- pmc_traffic.json left untouched")
+    fr, _, _, f1 = counters(f"{d}_FETCH_SIZE", "pattern<256, 0>", 0.0)
+    wr, _, _, f2 = counters(f"{d}_WRITE_SIZE", "pattern<256, 0>", 0.0)
+    traffic["calibration"][label] = {"known_read_KiB": n * 44 / 1024, "FETCH_SIZE_raw_KiB": fr["FETCH_SIZE"],
+                                     "FETCH_SIZE_x2_KiB": 2 * fr["FETCH_SIZE"], "known_write_KiB": n * 61 / 1024,
+                                     "WRITE_SIZE_KiB": wr["WRITE_SIZE"], "source": [prov(f1), prov(f2)]}
+for label, pre, sub, units, carry in (
+        (f"mr_rollout_kernel<RK45,fast,nominal,carry=f64> T={T} N={N}", "pmc_f64", "mr_rollout_kernel<true, 2, false", N * T, "f64"),
+        (f"mr_rollout_kernel<RK45,fast,nominal,carry=f32> T={T} N={N}", "pmc_f32", "mr_rollout_kernel<true, 2, false", N * T, "f32"),
+        (f"mr_step_kernel<RK45,fast,nominal,aos> N={N}", "pmc_step", "mr_step_kernel<true, 2, false, true", N, None)):
+    fr, nf, _, f1 = counters(f"{pre}_FETCH_SIZE", sub)
+    wr, nw, _, f2 = counters(f"{pre}_WRITE_SIZE", sub)
+    b = (2 * fr["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024
+    k = {"FETCH_SIZE_raw_KiB": fr["FETCH_SIZE"], "WRITE_SIZE_KiB": wr["WRITE_SIZE"], "dispatches_seen": [nf, nw],
+         "hbm_bytes_per_launch": b, "algorithmic_bytes_per_launch": units * ALGO,
+         "traffic_over_algorithmic": b / (units * ALGO), "bytes_per_env_step": b / units, "source": [prov(f1), prov(f2)]}
+    if carry:
+        k["carry"] = carry
+    traffic["kernels"][label] = k
+files["pmc_traffic.json"] = json.dumps(traffic, indent=1) + "\n"
+
+# ---- VALU issue floor: instruction mix per wave-step x measured issue cost per class
+cost = {}
+for r in inst:
+    cost.setdefault(r["op"], {})[r["waves_per_simd"]] = r["ns"]
+CLASS_OP = {  # PMC class -> the instbench instruction that prices it
+    "SQ_INSTS_VALU_INT64": "v_mad_u64_u32", "SQ_INSTS_VALU_TRANS_F32": "v_sin_f32", "SQ_INSTS_VALU_FMA_F64": "v_fma_f64",
+    "SQ_INSTS_VALU_MUL_F64": "v_mul_f64", "SQ_INSTS_VALU_ADD_F64": "v_add_f64", "SQ_INSTS_VALU_CVT": "v_cvt_f32_u32",
+    "SQ_INSTS_VALU_FMA_F32": "v_fma_f32", "SQ_INSTS_VALU_MUL_F32": "v_mul_f32", "SQ_INSTS_VALU_ADD_F32": "v_add_f32",
+    "SQ_INSTS_VALU_INT32": "v_add_u32"}
+valu = {"what": "rocprofv3 --pmc SQ instruction counters of the fused rollout kernel, per wave and env step (value / (grid/64) / T), "
+                "and the VALU issue floor they imply: sum over classes of count x issue cost of that class (tools/instbench, ns per "
+                "wave-instruction per SIMD with 8 independent chains per wave).  'other' = SQ_INSTS_VALU minus the classified counters "
+                "(bit operations, moves, selects, fp64 compares / min / max ...), priced at the CHEAPEST measured VALU instruction "
+                "(v_xor_b32), and conversions at the cheapest conversion, so the floor is a lower bound and roofline.frac an "
+                "under-estimate.  waves_per_simd = N / 64 / 1024 = 4 at N = 262144: the w4 costs apply; w8 is the best case any "
+                "occupancy reaches.",
+        **stamp, "N": N, "T": T,
+        "issue_costs": {"source": f"profiles/{tag}/instbench.json",
+                        "ns": {op: {f"w{w}": cost[op][w] for w in (4, 8)} for op in sorted(set(CLASS_OP.values()) | {"v_xor_b32"})}},
+        "kernels": {}}
+for carry in ("f64", "f32"):
+    per, srcs = {}, []
+    for g in "abc":
+        c, nd, grid, f = counters(f"valu_{g}_{carry}", "mr_rollout_kernel<true, 2, false")
+        srcs.append(prov(f))
+        for k, v in c.items():
+            per[k] = v / (grid / 64) / T
+    classified = sum(per[k] for k in CLASS_OP)
+    other = per["SQ_INSTS_VALU"] - classified
+    floors = {}
+    for w in (4, 8):
+        floors[w] = sum(per[k] * cost[op][w] for k, op in CLASS_OP.items()) + other * cost["v_xor_b32"][w]
+    valu["kernels"]["rollout_" + carry] = {
+        "kernel": f"mr_rollout_kernel<RK45,fast,nominal,carry={carry}>", "per_wave_step": {k: round(v, 2) for k, v in sorted(per.items())},
+        "insts_valu_per_wave_step": round(per["SQ_INSTS_VALU"], 2), "other_valu_per_wave_step": round(other, 2),
+        "issue_floor_ns_per_wave_step": round(floors[4], 2), "issue_floor_ns_per_wave_step_w8": round(floors[8], 2),
+        "issue_floor_us_per_launch": round(floors[4] * (WAVES / 1024) * T * 1e-3, 2),
+        "issue_floor_us_per_launch_w8": round(floors[8] * (WAVES / 1024) * T * 1e-3, 2), "source": srcs}
+files["pmc_valu.json"] = json.dumps(valu, indent=1) + "\n"
+
+os.makedirs(dst, exist_ok=True)
+for name, text in files.items():
+    open(f"{dst}/{name}", "w").write(text)
+    print("wrote", f"{dst}/{name}")
+print(json.dumps({k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "bytes_per_env_step": v["bytes_per_env_step"]}
+                  for k, v in traffic["kernels"].items()}, indent=1))
+print(json.dumps({k: {x: v[x] for x in ("insts_valu_per_wave_step", "issue_floor_us_per_launch", "issue_floor_us_per_launch_w8")}
+                  for k, v in valu["kernels"].items()}, indent=1))

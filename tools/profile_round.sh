@@ -1,16 +1,39 @@
 #!/bin/bash
-# Collect the round's rocprofv3 evidence on the GPU box (run via gpurun):  tools/profile_round.sh r01
-# 1) kernel trace + stats of the default bench command; 2) PMC passes (separate, as the guide
-# prescribes): FETCH_SIZE / WRITE_SIZE for HBM traffic, plus a calibration run on tools/membench
-# whose bytes are known exactly.
-R=$GRAFT_REPO_ROOT; tag=${1:-r01}; O=$R/gpurun_out/prof_$tag; mkdir -p $O
+# Collect one round's rocprofv3 evidence on the GPU box (run via gpurun):  bash tools/profile_round.sh r02
+# Every pass writes its exit code to $O/status.txt; tools/collect_profiles.py refuses to build profiles/<tag>/ from a
+# round in which a pass failed or whose CSVs are older than the library / bench.py they claim to describe.
+#  1) kernel trace + stats of the default bench command (rollout) and of --mode step;
+#  2) PMC passes, each counter group in its own run with no trace flags (MI355X_MICROARCH.md, rocprofv3 PMC slots):
+#     FETCH_SIZE / WRITE_SIZE of the rollout kernel (both carries) and of the eager step path, calibrated on
+#     tools/membench whose bytes are known exactly; SQ instruction-mix and busy / wait counters of the rollout kernel;
+#  3) tools/instbench --json: per-instruction issue costs that price the instruction mix.
+# The PMC passes use the bench's own flags to skip its hipGraph leg (graph capture under --pmc crashes rocprofv3 on
+# ROCm 7.2 -- bench.py also skips it by itself when it sees ROCPROF_COUNTER_COLLECTION).
+R=$GRAFT_REPO_ROOT; tag=${1:-r02}; O=$R/gpurun_out/prof_$tag; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline > $O/kt_bench.json 2> $O/kt.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --mode step > $O/kt_step_bench.json 2> $O/kt_step.log
+: > $O/status.txt
+pass() {  # pass <name> <cmd...>: run, record the exit code
+  name=$1; shift
+  "$@" > $O/$name.out 2> $O/$name.log
+  echo "$name $?" >> $O/status.txt
+}
+PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
+pass kt rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline
+pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --mode step
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --no-cpu-baseline --steps 102 > /dev/null 2> $O/pmc_$c.log
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_step_$c -- python3 $R/bench.py --no-cpu-baseline --steps 102 --mode step --launch eager > /dev/null 2> $O/pmc_step_$c.log
-  rocprofv3 --pmc $c --output-format csv -d $O/cal_$c -- $R/tools/membench 16777216 20 > /dev/null 2> $O/cal_$c.log
-  rocprofv3 --pmc $c --output-format csv -d $O/cal262k_$c -- $R/tools/membench 262144 20 > /dev/null 2> $O/cal262k_$c.log
+  for carry in f64 f32; do
+    pass pmc_${carry}_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_${carry}_$c -- python3 $R/bench.py $PMCARGS --carry $carry
+  done
+  pass pmc_step_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_step_$c -- python3 $R/bench.py $PMCARGS --mode step --launch eager
+  pass cal_$c rocprofv3 --pmc $c --output-format csv -d $O/cal_$c -- $R/tools/membench 16777216 20
+  pass cal262k_$c rocprofv3 --pmc $c --output-format csv -d $O/cal262k_$c -- $R/tools/membench 262144 20
 done
+for carry in f64 f32; do
+  pass valu_a_$carry rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/valu_a_$carry -- python3 $R/bench.py $PMCARGS --carry $carry
+  pass valu_b_$carry rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VMEM_WR --output-format csv -d $O/valu_b_$carry -- python3 $R/bench.py $PMCARGS --carry $carry
+  pass valu_c_$carry rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD --output-format csv -d $O/valu_c_$carry -- python3 $R/bench.py $PMCARGS --carry $carry
+done
+pass instbench $R/tools/instbench --json
+sha256sum $R/bench.py $R/mr_rl_amd/libmrsim.so > $O/sha.txt
+cat $O/status.txt
 echo profile_round done
