@@ -44,6 +44,11 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_ENV_STEP = 97   # fp64 positions -> reads 40 + writes 57 per env-step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SIMDS = 1024                   # 256 CUs x 4 SIMDs
+PREROLL_EPISODES = 300         # untimed episodes issued right in front of every secondary timed region: after ANY host-side
+                               # pause of a millisecond or more (allocating buffers, creating or reading a thousand events)
+                               # the GPU has dropped its clock and needs ~40 ms of load to bring it back (rocprofv3 kernel
+                               # trace of this script, profiles/r02/rollout_kernel_by_region.json: 150 us per launch right
+                               # after a pause, 126 us from 300 launches on)
 
 _T0 = time.perf_counter()
 
@@ -240,22 +245,22 @@ def committed_traffic(args, n_local):
     return None, None
 
 
-def committed_valu_floor(args, n_local, T):
-    """Vector-issue floor of one launch, from the committed instruction mix of the rollout kernel (rocprofv3 --pmc
-    SQ_INSTS_VALU_* per wave-step, profiles/rNN/pmc_valu.json) priced with the per-instruction issue costs measured by
-    tools/instbench at the occupancy the launch runs at: floor = sum_class n_class x cost_class x waves per SIMD x T."""
+def committed_valu(args, n_local, T):
+    """VALU-issue roofline of the rollout kernel from the committed counters (profiles/rNN/pmc_valu.json, written by
+    tools/collect_profiles.py): the kernel's instruction mix per wave-step (rocprofv3 --pmc SQ_INSTS_VALU_*) priced with the
+    per-instruction issue costs tools/instbench measures at the launch's occupancy, against the kernel's own SQ_WAVE_CYCLES
+    -- shader cycles on both sides, so the clock the chip holds under load cancels.  Only for the profiled configuration."""
     f = newest_profile("pmc_valu.json")
     if f is None or args.mode != "rollout" or not profiled_config_matches(args, n_local):
         return None
     try:
         d = json.load(open(f))
         k = d["kernels"]["rollout_" + args.carry]
-        waves_per_simd = n_local / 64.0 / SIMDS
-        floor_us = k["issue_floor_ns_per_wave_step"] * waves_per_simd * T * 1e-3
-        return {"floor_us_per_launch": round(floor_us, 3), "insts_valu_per_wave_step": k["insts_valu_per_wave_step"],
-                "issue_floor_ns_per_wave_step": k["issue_floor_ns_per_wave_step"],
-                "waves_per_simd": waves_per_simd, "costs": d["issue_costs"]["source"],
-                "source": os.path.relpath(f, ROOT)}
+        return {"valu_issue_frac": k["valu_issue_frac"], "insts_valu_per_wave_step": k["insts_valu_per_wave_step"],
+                "issue_floor_cycles_per_wave_step": k["issue_floor_cycles_per_wave_step"],
+                "wave_cycles_per_wave_step": k["wave_cycles_per_wave_step"], "waves_per_simd": d["waves_per_simd"],
+                "floor_us_per_launch_at_burst_clock": k["floor_us_per_launch_at_burst_clock"],
+                "costs": d["issue_costs"]["source"], "source": os.path.relpath(f, ROOT)}
     except Exception:
         return None
 
@@ -275,7 +280,7 @@ def measure_step_path(cfg, n_local, dev, seed, steps=10200, samples=204):
         env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed)
         env.reset()
         graph = env.capture_steps(ep, policy=policy)
-        for _ in range(40):  # ~20 ms: lets the GPU clocks settle
+        for _ in range(100):  # ~45 ms: lets the GPU clocks settle
             graph.replay()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -389,7 +394,7 @@ def measure_mixed_set(args, n_local, env_id0, world, dev, seed, streams, steps=1
     tab = mixed_goal_table(cfg, seed)
     reg = make_region(args, cfg, n_local, env_id0, world, dev, seed, streams, goal_table=tab)
     ep = reg.ep
-    reg.run(20 * ep)
+    reg.run(PREROLL_EPISODES * ep)
     k = (steps // ep) * ep
     el, launches = reg.timed(k)
     reg.col.check_status()
@@ -534,6 +539,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # every event pair the timed regions will use is created NOW: a thousand hipEventCreate calls between the warm-up and
+    # the timed region would idle the GPU for milliseconds and the region would start on a dropped clock
+    one_stream = args.mode == "rollout" and streams == 1
+    ks = max(args.sustained_steps // ep, 1) * ep if (args.mode == "rollout" and args.sustained_steps > 0) else 0
+    ev_pool = [EventPair() for _ in range(min(K // ep + 1, 4096))] if (rank == 0 and one_stream) else None
+    sus_pool = [EventPair() for _ in range(ks // ep + 1)] if (rank == 0 and ks) else None
+    ev_used, sus_used = [], []
+
     # clock settle (tools/clock_ramp_probe.py: ~35 ms of load after idle), independent of the W the caller asks for
     trace("env ready; settle phase: %d episodes" % args.settle_episodes)
     run(args.settle_episodes * ep)
@@ -542,9 +555,6 @@ def main():
     barrier()
     trace("warm-up done; timed region")
     # ---- the contract's timed region: EXACTLY K steps between barrier + synchronize, max over ranks
-    one_stream = args.mode == "rollout" and streams == 1
-    ev_pool = [EventPair() for _ in range(min(K // ep + 1, 4096))] if (rank == 0 and one_stream) else None
-    ev_used = []
     if args.mode == "rollout":
         el, launches = reg.timed(K, ev_pool, ev_used)
     else:
@@ -561,49 +571,45 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
     trace("timed region done")
-    (reg.col if args.mode == "rollout" else env).check_status()
-    mean_ret = gatherer.last_mean()
-    region_ms = [e.elapsed_ms() for e in ev_used]
-    if ev_pool is not None:
-        for e in ev_pool:
-            e.close()
 
     # ---- sustained legs (every rank takes part): the same workload over its own >= 10 200-step region, (a) as
     # configured (S streams), (b) one launch per episode on ONE stream with a HIP event pair on every dispatch -- the
-    # kernel durations `roofline` is built from
+    # kernel durations `roofline` is built from.  Each leg = PREROLL_EPISODES untimed episodes, then the timed region.
     sustained = None
-    sus_ms = []
-    if args.mode == "rollout" and args.sustained_steps > 0:
-        ks = max(args.sustained_steps // ep, 1) * ep
+    if ks:
+        def leg(region, pool, used):
+            region.run(PREROLL_EPISODES * ep)
+            els, ls = region.timed(ks, pool, used)
+            return {"value": total * ks / els, "unit": "env-steps/s", "steps": ks, "launches": ls, "streams": region.col.S,
+                    "preroll_episodes": PREROLL_EPISODES, "ms_per_step": els / ks * 1e3}, els
 
-        def leg(region, with_events):
-            pool2 = [EventPair() for _ in range(ks // region.T + 1)] if (with_events and rank == 0) else None
-            used2 = []
-            els, ls = region.timed(ks, pool2, used2)
-            ms = [e.elapsed_ms() for e in used2]
-            if pool2 is not None:
-                for e in pool2:
-                    e.close()
-            d = {"value": total * ks / els, "unit": "env-steps/s", "steps": ks, "launches": ls, "streams": region.col.S,
-                 "ms_per_step": els / ks * 1e3}
-            if ms:
-                avg_us, med_us = stats_us(ms)
-                d.update({"avg_kernel_us": round(avg_us, 3), "median_kernel_us": round(med_us, 3),
-                          "kernel_time_over_wall": round(sum(ms) * 1e-3 / els, 4),
-                          "in_kernel_value": n_local * region.T / (avg_us * 1e-6)})
-            return d, ms
-
-        sustained, sus_ms = leg(reg, one_stream)
-        sustained["what"] = "the headline workload over its own region after the settle phase, independent of --steps"
+        sustained, els_main = leg(reg, sus_pool if one_stream else None, sus_used)
+        sustained["what"] = "the headline workload over its own region, independent of --steps"
+        els_one = els_main
         if not one_stream:
             reg1 = make_region(args, cfg, n_local, env_id0, world, dev, seed, 1, goal_table=goal_table, T=T)
-            reg1.run(40 * ep)  # its own buffers and state; the clocks are settled already
-            one, sus_ms = leg(reg1, True)
+            one, els_one = leg(reg1, sus_pool, sus_used)  # its own buffers and state
             reg1.col.check_status()
             one["what"] = "the same on ONE stream, one launch per episode: the per-dispatch kernel durations behind `roofline`"
             sustained["one_stream"] = one
             del reg1
         trace("sustained legs done")
+
+    (reg.col if args.mode == "rollout" else env).check_status()
+    mean_ret = gatherer.last_mean()
+    # events are read only now, after every timed region
+    region_ms = [e.elapsed_ms() for e in ev_used]
+    sus_ms = [e.elapsed_ms() for e in sus_used]
+    for pool in (ev_pool, sus_pool):
+        if pool is not None:
+            for e in pool:
+                e.close()
+    if sustained is not None and sus_ms:
+        avg_us, med_us = stats_us(sus_ms)
+        tgt = sustained if one_stream else sustained["one_stream"]
+        tgt.update({"avg_kernel_us": round(avg_us, 3), "median_kernel_us": round(med_us, 3),
+                    "kernel_time_over_wall": round(sum(sus_ms) * 1e-3 / els_one, 4),
+                    "in_kernel_value": n_local * args.rollout_len / (avg_us * 1e-6)})
 
     mixed = None
     if args.mode == "rollout" and args.workload == "ddpg" and not args.no_mixed_set:
@@ -633,14 +639,19 @@ def main():
             avg_us, med_us = stats_us(ms)
             units = n_local * T
             traffic, traffic_src = committed_traffic(args, n_local)
-            valu = committed_valu_floor(args, n_local, T)
+            valu = committed_valu(args, n_local, T)
             ach = units / (avg_us * 1e-6) / 1e9
-            roof = {"bound": "valu", "achieved": round(ach, 2),
-                    "peak": round(units / (valu["floor_us_per_launch"] * 1e-6) / 1e9, 2) if valu else None,
-                    "unit": "G env-steps/s in-kernel (peak = the kernel's measured VALU instruction mix issued at the "
-                            "per-instruction rates tools/instbench measures at this launch's occupancy)",
-                    "frac": round(valu["floor_us_per_launch"] / avg_us, 4) if valu else None,
-                    "valu": valu,
+            frac = valu["valu_issue_frac"] if valu else None
+            # in-kernel clock of THIS run: the kernel needs wave_cycles_per_wave_step x T shader cycles per wave, and the
+            # waves of a one-round launch live as long as the kernel
+            clock = valu["wave_cycles_per_wave_step"] * T / (avg_us * 1e3) if valu else None
+            roof = {"bound": "valu", "achieved": round(ach, 2), "peak": round(ach / frac, 2) if frac else None,
+                    "unit": "G env-steps/s in-kernel; peak = achieved / frac, frac = VALU issue cycles the kernel's measured "
+                            "instruction mix needs at the per-instruction issue costs of tools/instbench (4 waves per SIMD) / "
+                            "the kernel's SQ_WAVE_CYCLES, both from the committed rocprofv3 --pmc passes (cycles over cycles)",
+                    "frac": frac, "valu": valu,
+                    "in_kernel_clock_GHz": round(clock, 3) if clock else None,
+                    "frac_of_burst_clock_floor": round(valu["floor_us_per_launch_at_burst_clock"] / avg_us, 4) if valu else None,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "hbm_achieved_GBs": round(traffic / (avg_us * 1e-6) / 1e9, 1) if traffic else None,
                     "hbm_peak_GBs": HBM_PEAK_GBS,

@@ -151,31 +151,18 @@ __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const
 // ---------------------------------------------------------------------------
 // random policy
 // ---------------------------------------------------------------------------
-// Latency-bound (2 MiB of output at N = 262 144): four consecutive envs per lane -- four independent Philox calls in
-// flight, two 16-byte stores per lane, a quarter of the workgroups to dispatch and retire.
-constexpr int kPolicyPerLane = 4;
+// Latency-bound (2 MiB of output at N = 262 144; rocprof: 4.4 - 5 us inside the gym loop's graph, 2.4 us at best).  A
+// variant with four envs per lane (four Philox calls in flight, two 16-byte stores, a quarter of the workgroups) measured
+// the same to slightly slower (4.95 - 5.1 us, profiles/r02) and was dropped.
 __global__ __launch_bounds__(kBlock) void mr_policy_kernel(const KParams P, float* __restrict__ actions) {
-    const long long i0 = ((long long)blockIdx.x * kBlock + threadIdx.x) * kPolicyPerLane;
-    if (i0 >= P.n) return;
-    const uint32_t c0 = P.integrator == MRSIM_INT_RK45 ? policy_c0(true) : policy_c0(false);
-    const Rng R0 = make_rng(P, i0);
-    float a[2 * kPolicyPerLane];
-#pragma unroll
-    for (int j = 0; j < kPolicyPerLane; ++j) {  // the four calls differ in the env id (counter word 3) only
-        Rng R = R0;
-        R.env = R0.env + (uint32_t)j;
-        uint32_t w[4];
-        philox_call(R, c0, w);
-        action_from_words(P, w, a[2 * j], a[2 * j + 1]);
-    }
-    if (i0 + kPolicyPerLane <= P.n) {
-        float4* dst = reinterpret_cast<float4*>(actions + 2 * i0);
-        dst[0] = make_float4(a[0], a[1], a[2], a[3]);
-        dst[1] = make_float4(a[4], a[5], a[6], a[7]);
-    } else {
-        for (int j = 0; j < kPolicyPerLane && i0 + j < P.n; ++j)
-            reinterpret_cast<float2*>(actions)[i0 + j] = make_float2(a[2 * j], a[2 * j + 1]);
-    }
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    const Rng R = make_rng(P, i);
+    float f_t, al;
+    uint32_t w[4];
+    philox_call(R, P.integrator == MRSIM_INT_RK45 ? policy_c0(true) : policy_c0(false), w);
+    action_from_words(P, w, f_t, al);
+    reinterpret_cast<float2*>(actions)[i] = make_float2(f_t, al);
 }
 
 // ---------------------------------------------------------------------------
@@ -667,7 +654,7 @@ int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float
     if (!aligned16(actions)) return MRSIM_EALIGN;
     if ((rc = check_device())) return rc;
     const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
-    return launch(lc, mr_policy_kernel, (K.n + kPolicyPerLane - 1) / kPolicyPerLane, K, actions);
+    return launch(lc, mr_policy_kernel, K.n, K, actions);
 }
 
 static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,

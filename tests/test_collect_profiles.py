@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRIPT = os.path.join(ROOT, "tools", "collect_profiles.py")
-EXPECTED = ["kt", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
+EXPECTED = ["kt", "kt_s1", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
                                              for p in ("pmc_f64", "pmc_f32", "pmc_step", "cal", "cal262k")] + \
            [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")]
 
@@ -25,6 +25,7 @@ def _tree(tmp_path, status_lines, sha_ok=True):
     if not sha_ok:
         b = "0" * 64
     (src / "sha.txt").write_text(f"{b}  /x/bench.py\n{l}  /x/mr_rl_amd/libmrsim.so\n")
+    (src / "manifest.txt").write_text("status.txt\nsha.txt\n")
     return src
 
 

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Turn the scratch output of tools/profile_round.sh (gpurun_out/prof_<tag>/) into the committed evidence under
-profiles/<tag>/:  kernel_stats_bench_{rollout,step}.csv, bench_under_rocprof_rollout.json, pmc_traffic.json,
-pmc_valu.json, instbench.json.
+profiles/<tag>/:  kernel_stats_bench_{rollout,rollout_streams1,step}.csv (rocprofv3 --kernel-trace --stats of
+`bench.py`, `bench.py --streams 1` -- the one whose rollout-kernel average is the single-launch duration bench.py's
+roofline quotes -- and `bench.py --mode step`), the bench JSON lines of those runs, pmc_traffic.json, pmc_valu.json,
+instbench.json.
 
 STRICT (a crashed profiler pass was hidden behind an older CSV): exits non-zero and leaves profiles/<tag>/
 untouched when
   * status.txt is missing, lists a pass with a non-zero exit code, or lacks an expected pass;
-  * a pass left no CSV, or left more than one run directory (stale output mixed in);
+  * a pass left no CSV of this round (manifest.txt lists what the round wrote; gpurun merges into gpurun_out/, so files of
+    an earlier round may lie beside them and are ignored), or more than one;
   * the round was taken with another bench.py / libmrsim.so than the ones in this tree (sha256 in sha.txt).
 Every JSON records the source CSV, its mtime and the sha256 prefixes of bench.py / libmrsim.so it describes.
 
@@ -30,7 +33,7 @@ def sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
-EXPECTED = ["kt", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
+EXPECTED = ["kt", "kt_s1", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
                                              for p in ("pmc_f64", "pmc_f32", "pmc_step", "cal", "cal262k")] + \
            [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")]
 if not os.path.exists(f"{src}/status.txt"):
@@ -45,8 +48,14 @@ if shas != here:
     die(f"the round describes bench.py/libmrsim.so {shas}, this tree has {here}")
 
 
+if not os.path.exists(f"{src}/manifest.txt"):
+    die(f"{src}/manifest.txt not found")
+MANIFEST = set(open(f"{src}/manifest.txt").read().split())  # files of THIS round (gpurun merges into gpurun_out/: files of
+                                                            # an earlier round of the same tag may still lie beside them)
+
+
 def the_csv(dirname, suffix):
-    f = glob.glob(f"{src}/{dirname}/*/*{suffix}")
+    f = [x for x in glob.glob(f"{src}/{dirname}/*/*{suffix}") if os.path.relpath(x, src) in MANIFEST]
     if len(f) != 1:
         die(f"{src}/{dirname}: expected exactly one *{suffix}, found {len(f)}")
     return f[0]
@@ -75,12 +84,42 @@ stamp = {"bench_py_sha16": here["bench.py"], "libmrsim_so_sha16": here["libmrsim
 # ---- everything is gathered first; files are only written once nothing can fail any more
 files = {}
 files["kernel_stats_bench_rollout.csv"] = open(the_csv("kt", "kernel_stats.csv")).read()
+files["kernel_stats_bench_rollout_streams1.csv"] = open(the_csv("kt_s1", "kernel_stats.csv")).read()
 files["kernel_stats_bench_step.csv"] = open(the_csv("kt_step", "kernel_stats.csv")).read()
+line1 = [l for l in open(f"{src}/kt_s1.out").read().splitlines() if l.startswith("{")]
+if not line1:
+    die("kt_s1.out holds no bench JSON line")
+files["bench_under_rocprof_rollout_streams1.json"] = line1[-1] + "\n"
 line = [l for l in open(f"{src}/kt.out").read().splitlines() if l.startswith("{")]
 if not line:
     die("kt.out holds no bench JSON line")
 files["bench_under_rocprof_rollout.json"] = line[-1] + "\n"
 inst = json.load(open(f"{src}/instbench.out"))
+# per-region durations of the rollout kernel in the one-stream run, from the per-dispatch kernel trace: the same populations
+# bench.py's HIP events cover (its JSON of that very run is committed beside it), and the clock ramp after host-side pauses
+kt1 = the_csv("kt_s1", "kernel_trace.csv")
+d1 = json.loads(line1[-1])
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt1))
+       if "mr_rollout_kernel<true, 2, false, 7" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == N]
+seq = [("settle", 400), ("warm-up", d1["warmup"] // T), ("timed (the contract's region)", d1["steps"] // T),
+       ("pre-roll of the sustained leg", d1["sustained"].get("preroll_episodes", 0)), ("sustained", d1["sustained"]["steps"] // T)]
+if sum(n for _, n in seq) != len(dur):
+    die(f"{kt1}: {len(dur)} full-size rollout dispatches, expected {sum(n for _, n in seq)} from the bench line of that run")
+by_region, k0 = [], 0
+for name, n in seq:
+    x = sorted(dur[k0:k0 + n])
+    if n:
+        by_region.append({"region": name, "launches": n, "avg_us": round(sum(x) / n, 2), "median_us": round(x[n // 2], 2)})
+    k0 += n
+files["rollout_kernel_by_region.json"] = json.dumps({
+    "what": "rocprofv3 --kernel-trace of `bench.py --no-cpu-baseline --streams 1 --no-step-path --no-mixed-set`: duration of the "
+            "full-size rollout kernel per region of the run, and per block of 100 launches in dispatch order (the clock ramp "
+            "after each host-side pause); bench_events = what bench.py's own HIP events reported for the sustained region in "
+            "that same run",
+    **stamp, "source": prov(kt1), "by_region": by_region,
+    "blocks_of_100_us": [round(sum(dur[i:i + 100]) / len(dur[i:i + 100]), 1) for i in range(0, len(dur), 100)],
+    "bench_events": {"sustained_avg_kernel_us": d1["sustained"].get("avg_kernel_us"),
+                     "roofline_avg_kernel_us": d1["roofline"]["avg_kernel_us"]}}, indent=1) + "\n"
 files["instbench.json"] = json.dumps({"what": "tools/instbench --json: ns per wave-instruction per SIMD, 8 independent chains per wave",
                                       **stamp, "rows": inst}, indent=1) + "\n"
 
@@ -113,25 +152,31 @@ for label, pre, sub, units, carry in (
     traffic["kernels"][label] = k
 files["pmc_traffic.json"] = json.dumps(traffic, indent=1) + "\n"
 
-# ---- VALU issue floor: instruction mix per wave-step x measured issue cost per class
+# ---- VALU issue floor: instruction mix per wave-step x measured issue cost per class, in SHADER CYCLES on both sides
 cost = {}
 for r in inst:
-    cost.setdefault(r["op"], {})[r["waves_per_simd"]] = r["ns"]
+    cost.setdefault(r["op"], {})[r["waves_per_simd"]] = r
 CLASS_OP = {  # PMC class -> the instbench instruction that prices it
     "SQ_INSTS_VALU_INT64": "v_mad_u64_u32", "SQ_INSTS_VALU_TRANS_F32": "v_sin_f32", "SQ_INSTS_VALU_FMA_F64": "v_fma_f64",
-    "SQ_INSTS_VALU_MUL_F64": "v_mul_f64", "SQ_INSTS_VALU_ADD_F64": "v_add_f64", "SQ_INSTS_VALU_CVT": "v_cvt_f32_u32",
+    "SQ_INSTS_VALU_MUL_F64": "v_mul_f64", "SQ_INSTS_VALU_ADD_F64": "v_add_f64", "SQ_INSTS_VALU_CVT": "v_cvt_f64_f32",
     "SQ_INSTS_VALU_FMA_F32": "v_fma_f32", "SQ_INSTS_VALU_MUL_F32": "v_mul_f32", "SQ_INSTS_VALU_ADD_F32": "v_add_f32",
     "SQ_INSTS_VALU_INT32": "v_add_u32"}
-valu = {"what": "rocprofv3 --pmc SQ instruction counters of the fused rollout kernel, per wave and env step (value / (grid/64) / T), "
-                "and the VALU issue floor they imply: sum over classes of count x issue cost of that class (tools/instbench, ns per "
-                "wave-instruction per SIMD with 8 independent chains per wave).  'other' = SQ_INSTS_VALU minus the classified counters "
-                "(bit operations, moves, selects, fp64 compares / min / max ...), priced at the CHEAPEST measured VALU instruction "
-                "(v_xor_b32), and conversions at the cheapest conversion, so the floor is a lower bound and roofline.frac an "
-                "under-estimate.  waves_per_simd = N / 64 / 1024 = 4 at N = 262144: the w4 costs apply; w8 is the best case any "
-                "occupancy reaches.",
-        **stamp, "N": N, "T": T,
+WPS = WAVES // 1024  # waves per SIMD of the launch (N / 64 / 1024 = 4)
+valu = {"what": "rocprofv3 --pmc SQ counters of the fused rollout kernel per wave and env step (value / (grid/64) / T), and the VALU "
+                "issue floor they imply.  floor = sum over instruction classes of count x issue cost of that class (tools/instbench at "
+                "the launch's occupancy, 4 waves per SIMD, 8 independent chains per wave), in SHADER CYCLES per wave-instruction per "
+                "SIMD; the kernel's own time is SQ_WAVE_CYCLES (quad-cycles of wave residency; the 4 waves of a SIMD are resident "
+                "together for the whole launch, so wave cycles per wave-step = SIMD cycles per step).  valu_issue_frac = 4 waves x "
+                "floor / (4 x SQ_WAVE_CYCLES): cycles over cycles, so the clock the chip holds under load (DVFS: 1.9-2.1 GHz here vs "
+                "2.4 max) cancels.  'other' = SQ_INSTS_VALU minus the classified counters (bit operations, moves, selects, fp64 "
+                "compares / min / max ...) priced at the CHEAPEST measured VALU instruction (v_xor_b32) and conversions at the cheapest "
+                "conversion: the floor is a lower bound, the fraction an under-estimate.  The ns figures of the same instbench run "
+                "(taken at the burst clock of a 0.1 ms launch) give floor_us_at_burst_clock, what the mix would take if the chip "
+                "held that clock.",
+        **stamp, "N": N, "T": T, "waves_per_simd": WPS,
         "issue_costs": {"source": f"profiles/{tag}/instbench.json",
-                        "ns": {op: {f"w{w}": cost[op][w] for w in (4, 8)} for op in sorted(set(CLASS_OP.values()) | {"v_xor_b32"})}},
+                        "w4": {op: {"cycles": cost[op][4]["cycles"], "ns": cost[op][4]["ns"]}
+                               for op in sorted(set(CLASS_OP.values()) | {"v_xor_b32"})}},
         "kernels": {}}
 for carry in ("f64", "f32"):
     per, srcs = {}, []
@@ -142,15 +187,17 @@ for carry in ("f64", "f32"):
             per[k] = v / (grid / 64) / T
     classified = sum(per[k] for k in CLASS_OP)
     other = per["SQ_INSTS_VALU"] - classified
-    floors = {}
-    for w in (4, 8):
-        floors[w] = sum(per[k] * cost[op][w] for k, op in CLASS_OP.items()) + other * cost["v_xor_b32"][w]
+    fl = {}
+    for unit in ("cycles", "ns"):
+        fl[unit] = sum(per[k] * cost[op][4][unit] for k, op in CLASS_OP.items()) + other * cost["v_xor_b32"][4][unit]
+    wave_cycles = 4.0 * per["SQ_WAVE_CYCLES"]
     valu["kernels"]["rollout_" + carry] = {
         "kernel": f"mr_rollout_kernel<RK45,fast,nominal,carry={carry}>", "per_wave_step": {k: round(v, 2) for k, v in sorted(per.items())},
         "insts_valu_per_wave_step": round(per["SQ_INSTS_VALU"], 2), "other_valu_per_wave_step": round(other, 2),
-        "issue_floor_ns_per_wave_step": round(floors[4], 2), "issue_floor_ns_per_wave_step_w8": round(floors[8], 2),
-        "issue_floor_us_per_launch": round(floors[4] * (WAVES / 1024) * T * 1e-3, 2),
-        "issue_floor_us_per_launch_w8": round(floors[8] * (WAVES / 1024) * T * 1e-3, 2), "source": srcs}
+        "issue_floor_cycles_per_wave_step": round(fl["cycles"], 1), "wave_cycles_per_wave_step": round(wave_cycles, 1),
+        "valu_issue_frac": round(WPS * fl["cycles"] / wave_cycles, 4),
+        "issue_floor_ns_per_wave_step_at_burst_clock": round(fl["ns"], 2),
+        "floor_us_per_launch_at_burst_clock": round(fl["ns"] * WPS * T * 1e-3, 2), "source": srcs}
 files["pmc_valu.json"] = json.dumps(valu, indent=1) + "\n"
 
 os.makedirs(dst, exist_ok=True)
@@ -159,5 +206,6 @@ for name, text in files.items():
     print("wrote", f"{dst}/{name}")
 print(json.dumps({k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "bytes_per_env_step": v["bytes_per_env_step"]}
                   for k, v in traffic["kernels"].items()}, indent=1))
-print(json.dumps({k: {x: v[x] for x in ("insts_valu_per_wave_step", "issue_floor_us_per_launch", "issue_floor_us_per_launch_w8")}
+print(json.dumps({k: {x: v[x] for x in ("insts_valu_per_wave_step", "issue_floor_cycles_per_wave_step", "wave_cycles_per_wave_step",
+                                        "valu_issue_frac", "floor_us_per_launch_at_burst_clock")}
                   for k, v in valu["kernels"].items()}, indent=1))

@@ -1,12 +1,16 @@
 // instbench.hip -- measurement aid: issue cost (ns and cycles per wave-instruction per SIMD) of the VALU instructions
 // the rollout / step kernels are made of, at W = 1, 2, 4, 8 waves per SIMD, eight independent chains per wave.
 //   hipcc --offload-arch=gfx950 -O3 -o tools/instbench tools/instbench.hip ; tools/instbench [--json]
-// The ns figures (not the cycle figures, which assume 2.4 GHz) price the kernel's instruction mix in
-// tools/collect_profiles.py -> profiles/rNN/pmc_valu.json (the "VALU issue floor" of bench.py's roofline).
+// Two figures per instruction: ns (HIP events around the launch) and shader cycles (s_memtime around the loop, lifetime of the
+// last-finishing waves).  The CYCLE figures price the kernel's instruction mix in tools/collect_profiles.py -> profiles/rNN/pmc_valu.json
+// (the "VALU issue floor" of bench.py's roofline, compared with the kernel's own SQ_WAVE_CYCLES -- a ratio the clock the
+// chip happens to hold (DVFS) cancels out of); cycles / ns = the clock this short burst ran at.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 constexpr int ITERS = 2000;
 
@@ -34,13 +38,14 @@ static const char* kNames[N_OPS] = {"v_mad_u64_u32", "v_mul_hi_u32", "v_mul_lo_u
     "v_max_f64", "v_cmp_lt_f64", "v_cvt_f64_f32", "v_cvt_f32_f64", "v_cvt_f32_u32", "v_sin_f32", "v_cos_f32", "v_log_f32", "v_sqrt_f32", "v_rcp_f32"};
 
 template <int OP>
-__global__ __launch_bounds__(256) void k(unsigned* out, unsigned seed) {
+__global__ __launch_bounds__(256) void k(unsigned* out, unsigned seed, unsigned long long* cyc) {
     unsigned a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 + 11, a5 = a0 + 13, a6 = a0 + 17, a7 = a0 + 19;
     unsigned long long d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;
     float f0 = a0 * 1e-9f + 0.5f, f1 = a1 * 1e-9f + 0.5f, f2 = a2 * 1e-9f + 0.5f, f3 = a3 * 1e-9f + 0.5f, f4 = a4 * 1e-9f + 0.5f, f5 = a5 * 1e-9f + 0.5f, f6 = a6 * 1e-9f + 0.5f, f7 = a7 * 1e-9f + 0.5f;
     double g0 = f0, g1 = f1, g2 = f2, g3 = f3, g4 = f4, g5 = f5, g6 = f6, g7 = f7;
     f32x2 p0 = {f0, f1}, p1 = {f1, f2}, p2 = {f2, f3}, p3 = {f3, f4}, p4 = {f4, f5}, p5 = {f5, f6}, p6 = {f6, f7}, p7 = {f7, f0};
     const unsigned M = 0xD2511F53u;
+    const unsigned long long t0 = clock64();  // s_memtime: shader cycles
     for (int it = 0; it < ITERS; ++it) {
         if (OP == MAD_U64) {
             asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d0) : "v"((unsigned)d0), "s"(M) : "vcc"); asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d1) : "v"((unsigned)d1), "s"(M) : "vcc");
@@ -85,6 +90,8 @@ __global__ __launch_bounds__(256) void k(unsigned* out, unsigned seed) {
         } else if (OP == RCP) { F8U("v_rcp_f32 %0, %0")
         }
     }
+    const unsigned long long t1 = clock64();
+    if ((threadIdx.x & 63u) == 0) cyc[(blockIdx.x * 256 + threadIdx.x) >> 6] = t1 - t0;
     unsigned r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (unsigned)(d0 ^ d1 ^ d2 ^ d3 ^ d4 ^ d5 ^ d6 ^ d7);
     r ^= __float_as_uint(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7) ^ (unsigned)__double_as_longlong(g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7);
     r ^= __float_as_uint(p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y);
@@ -94,27 +101,42 @@ __global__ __launch_bounds__(256) void k(unsigned* out, unsigned seed) {
 static bool g_json = false;
 static bool g_first = true;
 
+static unsigned long long* g_cyc = nullptr;  // one slot per wave (8 waves/SIMD x 1024 SIMDs at most)
+static std::vector<unsigned long long> g_host(8192);
+
 template <int OP>
 void run(unsigned* out, int waves_per_simd) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     int blocks = 256 * waves_per_simd;  // 256 CUs x (waves_per_simd blocks of 4 waves) -> waves_per_simd per SIMD
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 1u);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 1u, g_cyc);
     CK(hipDeviceSynchronize());
     float best = 1e30f;
+    double best_cyc = 0;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 2u + rep);
+        hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 2u + rep, g_cyc);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        if (ms < best) best = ms;
+        if (ms < best) {
+            best = ms;
+            const int nw = blocks * 4;
+            CK(hipMemcpy(g_host.data(), g_cyc, nw * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            std::sort(g_host.begin(), g_host.begin() + nw);
+            // the waves of a SIMD are served oldest-first, so the oldest finish early: the SIMD is busy for as long as its
+            // LAST wave lives.  99th percentile of the wave lifetimes (shader cycles, s_memtime)
+            best_cyc = (double)g_host[(nw * 99) / 100];
+        }
     }
     double inst_per_simd = (double)waves_per_simd * ITERS * 8;
     double ns = best * 1e6 / inst_per_simd;
+    double cyc = best_cyc / inst_per_simd;  // cycles per wave-instruction per SIMD, independent of the clock the run held
     if (g_json) {
-        printf("%s{\"op\": \"%s\", \"waves_per_simd\": %d, \"ns\": %.4f}", g_first ? "" : ",\n", kNames[OP], waves_per_simd, ns);
+        printf("%s{\"op\": \"%s\", \"waves_per_simd\": %d, \"ns\": %.4f, \"cycles\": %.4f}", g_first ? "" : ",\n", kNames[OP],
+               waves_per_simd, ns, cyc);
         g_first = false;
     } else {
-        printf("%-16s waves/SIMD=%d  %.2f ns per wave-instr per SIMD (= %.1f cycles @2.4GHz)\n", kNames[OP], waves_per_simd, ns, ns * 2.4);
+        printf("%-16s waves/SIMD=%d  %.2f ns = %.2f shader cycles per wave-instr per SIMD (clock %.2f GHz)\n", kNames[OP], waves_per_simd,
+               ns, cyc, cyc / ns);
     }
     CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
 }
@@ -127,6 +149,7 @@ void run_all(unsigned* out, int w) {
 int main(int argc, char** argv) {
     g_json = argc > 1 && !strcmp(argv[1], "--json");
     unsigned* out; CK(hipMalloc(&out, 4096));
+    CK(hipMalloc(&g_cyc, 8192 * sizeof(unsigned long long)));
     if (g_json) printf("[\n");
     for (int w : {1, 2, 4, 8}) run_all<0>(out, w);
     if (g_json) printf("\n]\n");

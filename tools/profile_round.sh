@@ -2,7 +2,8 @@
 # Collect one round's rocprofv3 evidence on the GPU box (run via gpurun):  bash tools/profile_round.sh r02
 # Every pass writes its exit code to $O/status.txt; tools/collect_profiles.py refuses to build profiles/<tag>/ from a
 # round in which a pass failed or whose CSVs are older than the library / bench.py they claim to describe.
-#  1) kernel trace + stats of the default bench command (rollout) and of --mode step;
+#  1) kernel trace + stats of the default bench command (rollout, 2 sub-shard streams), of `--streams 1` (one launch per
+#     episode: the kernel duration bench.py's roofline quotes) and of --mode step;
 #  2) PMC passes, each counter group in its own run with no trace flags (MI355X_MICROARCH.md, rocprofv3 PMC slots):
 #     FETCH_SIZE / WRITE_SIZE of the rollout kernel (both carries) and of the eager step path, calibrated on
 #     tools/membench whose bytes are known exactly; SQ instruction-mix and busy / wait counters of the rollout kernel;
@@ -19,6 +20,7 @@ pass() {  # pass <name> <cmd...>: run, record the exit code
 }
 PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
 pass kt rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline
+pass kt_s1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1 -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-step-path --no-mixed-set
 pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --mode step
 for c in FETCH_SIZE WRITE_SIZE; do
   for carry in f64 f32; do
@@ -35,5 +37,6 @@ for carry in f64 f32; do
 done
 pass instbench $R/tools/instbench --json
 sha256sum $R/bench.py $R/mr_rl_amd/libmrsim.so > $O/sha.txt
+(cd $O && find . -type f ! -name manifest.txt | sed 's|^\./||' | sort) > $O/manifest.txt   # what THIS round wrote
 cat $O/status.txt
 echo profile_round done
