@@ -588,9 +588,12 @@ def main():
         els_one = els_main
         if not one_stream:
             reg1 = make_region(args, cfg, n_local, env_id0, world, dev, seed, 1, goal_table=goal_table, T=T)
-            one, els_one = leg(reg1, sus_pool, sus_used)  # its own buffers and state
+            one, _ = leg(reg1, None, None)                # its own buffers and state; plain launches: the throughput
+            ev_leg, els_one = leg(reg1, sus_pool, sus_used)  # again with a HIP event pair on every dispatch: the durations
             reg1.col.check_status()
-            one["what"] = "the same on ONE stream, one launch per episode: the per-dispatch kernel durations behind `roofline`"
+            one["what"] = ("the same on ONE stream, one launch per episode (plain launches); `with_events` = that region "
+                           "again with a HIP event pair attached to every dispatch, the kernel durations behind `roofline`")
+            one["with_events"] = {"value": ev_leg["value"], "ms_per_step": ev_leg["ms_per_step"]}
             sustained["one_stream"] = one
             del reg1
         trace("sustained legs done")
@@ -606,7 +609,7 @@ def main():
                 e.close()
     if sustained is not None and sus_ms:
         avg_us, med_us = stats_us(sus_ms)
-        tgt = sustained if one_stream else sustained["one_stream"]
+        tgt = sustained if one_stream else sustained["one_stream"]["with_events"]
         tgt.update({"avg_kernel_us": round(avg_us, 3), "median_kernel_us": round(med_us, 3),
                     "kernel_time_over_wall": round(sum(sus_ms) * 1e-3 / els_one, 4),
                     "in_kernel_value": n_local * args.rollout_len / (avg_us * 1e-6)})

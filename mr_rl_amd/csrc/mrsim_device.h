@@ -26,6 +26,9 @@ namespace mrsim {
 #ifndef MRSIM_ROLLOUT_TABLE
 #define MRSIM_ROLLOUT_TABLE 1
 #endif
+#ifndef MRSIM_FAST_STEP  // A/B switch: 0 = no straight-line fast step, every env step takes the general path
+#define MRSIM_FAST_STEP 1
+#endif
 #ifndef MRSIM_AB_CHEAP  // A/B switch (tools/ab_rollout.py): 0 = the cheap first-level tests are predicted not-taken and skipped
 #define MRSIM_AB_CHEAP 1
 #endif
@@ -352,14 +355,20 @@ __device__ __forceinline__ void sincos_f64(double a, double& s, double& c) {
 // 16 KiB table the block keeps in LDS (correctly rounded fp64 entries, tools/gen_sincos_table.py), sin r and cos r
 // from degree-5 / degree-4 Taylor polynomials (truncation 2.3e-15 / 1.2e-18), recombined by angle addition.
 // 15 fp64 operations + one ds_read_b128 instead of 24 fp64 + 15 quadrant-selection operations; same accuracy class
-// as sincos_f64 (<= 2 ulp).  Angles beyond +-4e6 rad (index conversion would saturate) take the polynomial path.
+// as sincos_f64 (<= 2 ulp).
 #include "mrsim_sincos_table.h"
 __device__ __forceinline__ void sincos_tab(const double2* __restrict__ tab, double a, double& s, double& c) {
-    if (__builtin_expect(!(__builtin_fabs(a) < 4.0e6), 0)) { sincos_f64(a, s, c); return; }
+    // Branch-free on purpose: a range check with a polynomial fall-back would end the basic block and keep the scheduler
+    // from interleaving this dependent fp64 chain with the Philox tail and the Box-Muller code around it (only four waves
+    // share a SIMD at N = 262 144, so in-wave ILP is what hides the fp64 latency).  The table index is reduced in fp64
+    // (k - 1024 rint(k / 1024), exact), so it is right for every finite angle whose k = rint(a * 1024 / 2 pi) is an exact
+    // integer (|a| < 2.7e13 rad); r = a - k * (2 pi / 1024) is formed with exact products (fma) and is good to 1e-16 up to
+    // |a| ~ 1e9 rad; NaN / inf give NaN.
     const double k = __builtin_rint(a * MRSIM_SINCOS_INV_STEP);
     double r = __builtin_fma(-k, MRSIM_SINCOS_STEP_HI, a);
     r = __builtin_fma(-k, MRSIM_SINCOS_STEP_LO, r);
-    const double2 t = tab[(int)k & (MRSIM_SINCOS_N - 1)];
+    const double kk = __builtin_fma(-(double)MRSIM_SINCOS_N, __builtin_rint(k * (1.0 / MRSIM_SINCOS_N)), k);  // in [-512, 512]
+    const double2 t = tab[(int)kk & (MRSIM_SINCOS_N - 1)];
     const double z = r * r;
     const double ps = __builtin_fma(z, 1.0 / 120, -1.0 / 6) * z;
     const double sr = __builtin_fma(ps, r, r);
@@ -395,7 +404,11 @@ __device__ __forceinline__ RhsCtx<MIS> make_ctx(const KParams& P, double f_t, do
         constexpr double kC01 = 0.99500416527802577, kS01 = 0.099833416646828152;   // cos, sin of 0.1
         constexpr double kC015 = 0.98877107793604229, kS015 = 0.14943813247359922;  // cos, sin of 0.15
         double s, c;
-        if (tab != nullptr) sincos_tab(tab, al, s, c); else sincos_f64(al, s, c);
+#if MRSIM_ROLLOUT_TABLE
+        sincos_tab(tab, al, s, c);
+#else
+        sincos_f64(al, s, c);
+#endif
         const double cA = __builtin_fma(c, kC01, -(s * kS01));
         const double sB = __builtin_fma(s, kC015, -(c * kS015));
         const double af = a0b * f_t;
@@ -405,7 +418,11 @@ __device__ __forceinline__ RhsCtx<MIS> make_ctx(const KParams& P, double f_t, do
         C.gy = (P.sigma4 * f_t) * sB;
     } else {
         double s, c;
-        if (tab != nullptr) sincos_tab(tab, al, s, c); else sincos_f64(al, s, c);
+#if MRSIM_ROLLOUT_TABLE
+        sincos_tab(tab, al, s, c);
+#else
+        sincos_f64(al, s, c);
+#endif
         const double af = P.a0 * f_t;
         C.vx = af * c;
         C.vy = af * s;
@@ -460,6 +477,40 @@ struct SubStep {
     float f0y;
     bool have3;
 };
+
+// ---- first-level test of select_initial_step (fp64, a dozen operations, no conversions): a SUFFICIENT condition for
+// h_abs == interval.  With m = min(|x|,|y|), sm / sM = the smaller / larger scale, F = max |f0|, G >= max |f1 - f0|:
+//   d0 >= m / sm,  F / (sM sqrt2) <= d1 <= F / sm,  d2 <= G / (sm h0),  h0 = min(0.01 d0/d1, dt) >= min(0.01 m/F, dt)
+//   F >= 2e-5 sM and m >= 2e-5 sM   =>  d1 >= 1.4e-5, d0 >= m / sm >= 2e-5          (no 1e-6 branch)
+//   TH sm / 1.05 >= F               =>  d1 <= TH
+// nominal law (|f0| <= a0 |f| + noise, a few tens):
+//   m >= 105 dt F  =>  0.01 d0/d1 >= dt  =>  h0 = dt;   TH sm / 1.05 >= G / dt  =>  d2 <= TH  =>  h1 >= dt
+// mismatched law (|f0| up to 100: m >= 3.15 F fails for half the actions at |y| ~ 100), the same without h0 = dt:
+//   m >= 1.05 dt F  =>  100 h0 >= dt;   d2 <= G / (sm min(0.01 m / F, dt)) <= TH  <=  TH sm / 1.05 >= G / dt  and
+//   (TH sm / 1.05) m >= 105 dt (G / dt) F
+// Gd = G / dt: exact when f1 was evaluated; otherwise its worst case over |z| <= Zmax (construct_gd_bound):
+// |f1 - f0| <= 2 Zmax (sigma + |g|).  Anything that fails -- NaNs included, every comparison is false on them -- goes on
+// to the fp32 test of rk45_construct and from there to the exact formulas.
+template <bool MIS>
+__device__ __forceinline__ double construct_gd_bound(const KParams& P, const RhsCtx<MIS>& C) {
+    if constexpr (MIS) return __builtin_fma(fmax(__builtin_fabs(C.gx), __builtin_fabs(C.gy)), P.zmax2_dt, P.gmax_dt);
+    else return P.gmax_dt;
+}
+template <bool MIS>
+__device__ __forceinline__ bool construct_level0(const KParams& P, double x, double y, double sc0, double sc1, double f0x,
+                                                 double f0y, double Gd) {
+    const double F = fmax(__builtin_fabs(f0x), __builtin_fabs(f0y));
+    const double c = 2e-5 * fmax(sc0, sc1);
+    const double u = P.h1_thresh_m * fmin(sc0, sc1);
+    if constexpr (MIS) {
+        const double K = fmax(0.01 * P.k_h0 * F, c);
+        return (__builtin_fabs(x) >= K) && (__builtin_fabs(y) >= K) && (F >= c) && (u >= fmax(F, Gd)) &&
+               (u * fmin(__builtin_fabs(x), __builtin_fabs(y)) >= P.k_h0 * (Gd * F));
+    } else {
+        const double kF = P.k_h0 * F;
+        return (__builtin_fabs(x) >= kF) && (__builtin_fabs(y) >= kF) && (F >= c) && (u >= fmax(F, Gd));
+    }
+}
 
 // ---------------------------------------------------------------------------
 // RungeKutta.__init__ + select_initial_step: what Simulator.step does after integrating
@@ -530,41 +581,11 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
     const double sc0 = __builtin_fma(__builtin_fabs(x), P.rtol, P.atol);
     const double sc1 = __builtin_fma(__builtin_fabs(y), P.rtol, P.atol);
 #if MRSIM_AB_CHEAP
-    // First-level test (fp64, a dozen operations, no conversions): a SUFFICIENT condition for h_abs == interval.
-    // With m = min(|x|,|y|), sm / sM = the smaller / larger scale, F = max |f0|, G >= max |f1 - f0|:
-    //   d0 >= m / sm,  F / (sM sqrt2) <= d1 <= F / sm,  d2 <= G / (sm h0),  h0 = min(0.01 d0/d1, dt) >= min(0.01 m/F, dt)
-    //   F >= 2e-5 sM and m >= 2e-5 sM   =>  d1 >= 1.4e-5, d0 >= m / sm >= 2e-5          (no 1e-6 branch)
-    //   TH sm / 1.05 >= F               =>  d1 <= TH
-    // nominal law (|f0| <= a0 |f| + noise, a few tens):
-    //   m >= 105 dt F  =>  0.01 d0/d1 >= dt  =>  h0 = dt;   TH sm / 1.05 >= G / dt  =>  d2 <= TH  =>  h1 >= dt
-    // mismatched law (|f0| up to 100: m >= 3.15 F fails for half the actions at |y| ~ 100), the same without h0 = dt:
-    //   m >= 1.05 dt F  =>  100 h0 >= dt;   d2 <= G / (sm min(0.01 m / F, dt)) <= TH  <=  TH sm / 1.05 >= G / dt  and
-    //   (TH sm / 1.05) m >= 105 dt (G / dt) F
-    // G is exact when f1 was evaluated; otherwise its worst case over |z| <= Zmax: |f1 - f0| <= 2 Zmax (sigma + |g|).
-    // Anything that fails -- NaNs included, every comparison is false on them -- goes on to the fp32 test below and
-    // from there to the exact formulas.
     {
-        const double F = fmax(__builtin_fabs(f0x), __builtin_fabs(f0y));
-        double Gd;  // G / dt
-        if (have1) {
-            Gd = fmax(__builtin_fabs(spx - f0x), __builtin_fabs(spy - f0y)) * P.inv_dt;
-        } else if constexpr (MIS) {
-            Gd = __builtin_fma(fmax(__builtin_fabs(C.gx), __builtin_fabs(C.gy)), P.zmax2_dt, P.gmax_dt);
-        } else {
-            Gd = P.gmax_dt;
-        }
-        const double c = 2e-5 * fmax(sc0, sc1);
-        const double u = P.h1_thresh_m * fmin(sc0, sc1);
-        bool pass;
-        if constexpr (MIS) {
-            const double K = fmax(0.01 * P.k_h0 * F, c);
-            pass = (__builtin_fabs(x) >= K) && (__builtin_fabs(y) >= K) && (F >= c) && (u >= fmax(F, Gd)) &&
-                   (u * fmin(__builtin_fabs(x), __builtin_fabs(y)) >= P.k_h0 * (Gd * F));
-        } else {
-            const double kF = P.k_h0 * F;
-            pass = (__builtin_fabs(x) >= kF) && (__builtin_fabs(y) >= kF) && (F >= c) && (u >= fmax(F, Gd));
-        }
-        if (__builtin_expect(pass, 1)) { h_abs = P.dt; return; }
+        double Gd;  // max |f1 - f0| / dt: exact when f1 was evaluated, else its worst case
+        if (have1) Gd = fmax(__builtin_fabs(spx - f0x), __builtin_fabs(spy - f0y)) * P.inv_dt;
+        else Gd = construct_gd_bound<MIS>(P, C);
+        if (__builtin_expect(construct_level0<MIS>(P, x, y, sc0, sc1, f0x, f0y, Gd), 1)) { h_abs = P.dt; return; }
     }
 #endif
     // Fast path (fp32, 5 % margins): decide "h_abs == interval_length" without divisions, square
@@ -783,6 +804,38 @@ __device__ __forceinline__ void finish_k6(const KParams& P, const RhsCtx<MIS>& C
 }
 
 
+// ---- one-sided accept tests on the LAST sub-step of an env step (K6 = f_new only enters the error estimate then; its
+// contribution is bounded by |z| <= Zmax).  Both return true only if error_norm < 1 is certain; false decides nothing.
+// They work on scale_lo = atol + rtol |y| <= the real scale atol + rtol max(|y|, |y_new|): a smaller scale only makes the
+// tests harder to pass.  Shared by the general attempt (rk45_attempt) and the straight-line fast step (rk45_fast_step).
+//
+// level 0 (max norm, nominal law): |err| <= h (|E0| max|K0 - V| + sigma (Zmax E6 + sum |E_i| r_i)) per component
+// (R32, attempt_noise); below 0.99 x the smaller scale, each ratio of the rms norm is < 1.  The E-weighted sums of the
+// stage normals are not even formed.  Not used under the mismatched law: its velocities (a0' = a0 + 0.2 f: up to 100)
+// and the extra g*z_a noise put error_norm near 0.5, where this test fails for half the waves and only adds work.
+__device__ __forceinline__ bool accept_level0(const KParams& P, const AttemptNoise& A, double dfx, double dfy, double h,
+                                              double l0, double l1) {
+    const double dmax = fmax(__builtin_fabs(dfx), __builtin_fabs(dfy));
+    const double eb = __builtin_fma(P.sigma, (double)A.R32, -kE0 * dmax);
+    return h * eb <= 0.99 * fmin(l0, l1);
+}
+// level 1 (rms norm with the exact stage sums ex32 / ey32 / ea32 and the worst-case K6): sqrt(2) less pessimistic
+template <bool MIS>
+__device__ __forceinline__ bool accept_level1(const KParams& P, const RhsCtx<MIS>& C, const AttemptNoise& A, double dfx,
+                                              double dfy, double h, double l0, double l1) {
+    double pex = __builtin_fma(P.sigma, (double)A.ex32, kE0 * dfx);
+    double pey = __builtin_fma(P.sigma, (double)A.ey32, kE0 * dfy);
+    if constexpr (MIS) {  // the g*z_a terms (K6a included) are already exact in ea32
+        pex = __builtin_fma(C.gx, (double)A.ea32, pex);
+        pey = __builtin_fma(C.gy, (double)A.ea32, pey);
+    }
+    const double b6 = h * P.zmax_e6_sigma;
+    const double l00 = l0 * l0, l11 = l1 * l1;
+    const double axw = __builtin_fabs(h * pex) + b6;
+    const double ayw = __builtin_fabs(h * pey) + b6;
+    return __builtin_fma(axw * axw, l11, (ayw * ayw) * l00) < 1.96 * (l00 * l11);
+}
+
 // one rk_step attempt + the accept / reject decision of _step_impl.  Returns true when the
 // attempt was accepted (state advanced to tau = tn).
 template <int NZ, bool MIS, bool FIRST>
@@ -815,33 +868,12 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
             if (last) {
                 const double l0 = __builtin_fma(__builtin_fabs(x), P.rtol, P.atol);
                 const double l1 = __builtin_fma(__builtin_fabs(y), P.rtol, P.atol);
-                // level 0 (max norm, nominal law): |err| <= h (|E0| max|K0 - V| + sigma (Zmax E6 + sum |E_i| r_i)) per
-                // component; if that is below 0.99 x the smaller scale, each ratio of the rms norm is < 1 =>
-                // error_norm < 1.  A handful of operations, and the E-weighted sums of the stage normals are not even
-                // formed; decides practically every step away from the origin (typical error_norm there is 0.03 .. 0.1).
-                // Not used under the mismatched law: its velocities (a0' = a0 + 0.2 f: up to 100) and the extra g*z_a
-                // noise put error_norm near 0.5, where this test fails for half the waves and only adds work (measured).
                 if constexpr (!MIS && MRSIM_AB_CHEAP) {
-                    const double dmax = fmax(__builtin_fabs(dfx), __builtin_fabs(dfy));
-                    const double eb = __builtin_fma(P.sigma, (double)A.R32, -kE0 * dmax);
-                    if (__builtin_expect(h * eb <= 0.99 * fmin(l0, l1), 1)) { accepted = true; decided = true; }
+                    if (__builtin_expect(accept_level0(P, A, dfx, dfy, h, l0, l1), 1)) { accepted = true; decided = true; }
                 }
                 if (!decided) {
-                    // level 1 (rms norm with the worst-case K6): sqrt(2) less pessimistic
                     finish_e(A);
-                    double pex = __builtin_fma(P.sigma, (double)A.ex32, kE0 * dfx);
-                    double pey = __builtin_fma(P.sigma, (double)A.ey32, kE0 * dfy);
-                    if constexpr (MIS) {  // the g*z_a terms (K6a included) are already exact in ea32
-                        pex = __builtin_fma(C.gx, (double)A.ea32, pex);
-                        pey = __builtin_fma(C.gy, (double)A.ea32, pey);
-                    }
-                    const double b6 = h * P.zmax_e6_sigma;
-                    const double l00 = l0 * l0, l11 = l1 * l1;
-                    const double axw = __builtin_fabs(h * pex) + b6;
-                    const double ayw = __builtin_fabs(h * pey) + b6;
-                    if (__builtin_fma(axw * axw, l11, (ayw * ayw) * l00) < 1.96 * (l00 * l11)) {
-                        accepted = true; decided = true;
-                    }
+                    if (accept_level1<MIS>(P, C, A, dfx, dfy, h, l0, l1)) { accepted = true; decided = true; }
                 }
             }
             if (!decided) finish_e(A);
@@ -915,6 +947,66 @@ __device__ __forceinline__ SubStep rk45_integrate(const KParams& P, const RhsCtx
     return S;
 }
 
+// ---------------------------------------------------------------------------
+// per-env registers
+// ---------------------------------------------------------------------------
+struct EnvRegs {
+    double x, y;        // integrator.y
+    double f0x, f0y;    // integrator.f (K[0] of the next step), stored fp32
+    double h_abs;       // integrator.h_abs, stored as fp32 ratio h_abs/dt
+    int32_t counter;    // MR_Env.counter
+    float ep_ret;
+};
+
+// ---------------------------------------------------------------------------
+// The common env step as ONE straight-line block.  Away from the coordinate axes practically every step is: carried
+// h_abs >= dt, ONE rk_step attempt over the whole interval, accepted by the first-level test, and a constructor whose
+// first-level test certifies h_abs == dt for the next step.  rk45_fast_step evaluates exactly that -- the same helper
+// functions and the same arithmetic the general path (rk45_integrate + rk45_construct) uses -- with no branch in it, so
+// the scheduler can interleave the Philox tail, the table sin/cos, five Box-Muller pairs and the fp64 chains of the
+// tests (only four waves share a SIMD at N = 262 144: in-wave ILP is what hides the fp64 / transcendental latencies; every
+// branch of the general path ends a scheduling region).  Returns true and commits the new state if all three conditions
+// hold; otherwise returns false with the env untouched and the caller runs the general path, which reaches the same bits
+// whenever the fast step would have (tested: MRSIM_FAST_STEP = 0 builds, tools/ab_rollout.py reports max |pos| difference 0).
+// Needs nothing of F1 (Simulator.state_prime): callers that want it use the general path.
+// ---------------------------------------------------------------------------
+template <int NZ, bool MIS>
+__device__ __forceinline__ bool rk45_fast_step(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, const uint32_t* d0,
+                                               EnvRegs& e) {
+    static_assert(NZ != kNoNoise, "the sigma = 0 kernels have nothing to hide: general path");
+    AttemptNoise A = attempt_noise<NZ, MIS, true>(P, C, R, 0u, d0);
+    const double h = P.dt;
+    // rk_step, first (and last) attempt: same expressions as rk45_attempt
+    const double dfx = e.f0x - C.vx, dfy = e.f0y - C.vy;
+    double sx = __builtin_fma(kB0, dfx, C.vx), sy = __builtin_fma(kB0, dfy, C.vy);
+    sx = __builtin_fma(P.sigma, (double)A.bx32, sx); sy = __builtin_fma(P.sigma, (double)A.by32, sy);
+    if constexpr (MIS) { sx = __builtin_fma(C.gx, (double)A.ba32, sx); sy = __builtin_fma(C.gy, (double)A.ba32, sy); }
+    const double xn = __builtin_fma(h, sx, e.x);
+    const double yn = __builtin_fma(h, sy, e.y);
+    const double l0 = __builtin_fma(__builtin_fabs(e.x), P.rtol, P.atol);
+    const double l1 = __builtin_fma(__builtin_fabs(e.y), P.rtol, P.atol);
+    bool acc;
+    if constexpr (!MIS) {
+        acc = accept_level0(P, A, dfx, dfy, h, l0, l1);
+    } else {
+        acc = accept_level1<MIS>(P, C, A, dfx, dfy, h, l0, l1);  // the mismatched attempt forms its E sums eagerly
+    }
+    // RungeKutta.__init__ of the next step: f0 = simulate() with the F0 draws of this attempt's block
+    float z0, z1;
+    box_muller<NZ>(A.f0a, A.f0b, z0, z1);
+    double f0x, f0y;
+    if constexpr (MIS) rhs_value<MIS>(P, C, z0, z1, A.f0y, f0x, f0y);
+    else rhs_value<MIS>(P, C, 0.f, z0, z1, f0x, f0y);
+    const double sc0 = __builtin_fma(__builtin_fabs(xn), P.rtol, P.atol);
+    const double sc1 = __builtin_fma(__builtin_fabs(yn), P.rtol, P.atol);
+    const bool pass = construct_level0<MIS>(P, xn, yn, sc0, sc1, f0x, f0y, construct_gd_bound<MIS>(P, C));
+    const bool ok = (e.h_abs >= P.dt) && acc && pass;
+    if (ok) {
+        e.x = xn; e.y = yn; e.f0x = f0x; e.f0y = f0y; e.h_abs = P.dt;
+    }
+    return ok;
+}
+
 // Build extension (BASELINE configs 2/3): fixed-step Euler / classical RK4, noise added to the
 // derivative at every RHS evaluation exactly as `simulate` does.  Mirrors the oracle's loop.
 template <int NZ, bool MIS>
@@ -957,16 +1049,6 @@ __device__ __forceinline__ void fixed_integrate(const KParams& P, const RhsCtx<M
     }
 }
 
-// ---------------------------------------------------------------------------
-// per-env registers
-// ---------------------------------------------------------------------------
-struct EnvRegs {
-    double x, y;        // integrator.y
-    double f0x, f0y;    // integrator.f (K[0] of the next step), stored fp32
-    double h_abs;       // integrator.h_abs, stored as fp32 ratio h_abs/dt
-    int32_t counter;    // MR_Env.counter
-    float ep_ret;
-};
 
 __device__ __forceinline__ void load_env(const double* __restrict__ pos, const float* __restrict__ aux,
                                          const float* __restrict__ ep_ret, long long i, const KParams& P, EnvRegs& e) {
@@ -1109,9 +1191,16 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     const RhsCtx<MIS> C = make_ctx<MIS>(P, act_f, act_a, sincos_lds);
     double spx = 0.0, spy = 0.0;
     if constexpr (RK45) {
-        SubStep LS = rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, &W.w[0][0]);  // MR_simulator.py:42-45
-        rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy,           // :46-50
-                                (fl & kFOutStatePrime) != 0, NZ != kNoNoise ? &LS : nullptr);
+        bool fast = false;
+        // (noise_math = spec is the test-oriented bit-exact mode: its long Box-Muller would only be duplicated)
+        if constexpr (NZ == kNoiseFast && MRSIM_FAST_STEP != 0) {
+            if (!(fl & kFOutStatePrime)) fast = rk45_fast_step<NZ, MIS>(P, C, R, &W.w[0][0], e);
+        }
+        if (__builtin_expect(!fast, 0)) {
+            SubStep LS = rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, &W.w[0][0]);  // MR_simulator.py:42-45
+            rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy,           // :46-50
+                                    (fl & kFOutStatePrime) != 0, NZ != kNoNoise ? &LS : nullptr);
+        }
     } else {
         fixed_integrate<NZ, MIS>(P, C, R, e.x, e.y, spx, spy);
         e.f0x = spx; e.f0y = spy; e.h_abs = P.dt;
