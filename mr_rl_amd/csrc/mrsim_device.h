@@ -26,6 +26,9 @@ namespace mrsim {
 #ifndef MRSIM_ROLLOUT_TABLE
 #define MRSIM_ROLLOUT_TABLE 1
 #endif
+#ifndef MRSIM_PRIO_MODE  // wave-priority rotation of the rollout kernel: 0 = none, 1 = every step, 2 / 4 = every 2nd / 4th step
+#define MRSIM_PRIO_MODE 1
+#endif
 #ifndef MRSIM_FAST_STEP  // A/B switch: 0 = no straight-line fast step, every env step takes the general path
 #define MRSIM_FAST_STEP 1
 #endif

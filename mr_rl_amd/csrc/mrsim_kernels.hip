@@ -241,7 +241,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     int fail = 0;
     const unsigned slot = hw_wave_slot();
     for (int t = 0; t < ra.T; ++t) {
+#if MRSIM_PRIO_MODE == 1
         rotate_wave_priority((unsigned)t, slot);
+#elif MRSIM_PRIO_MODE == 2
+        if ((t & 1) == 0) rotate_wave_priority((unsigned)t >> 1, slot);
+#elif MRSIM_PRIO_MODE == 4
+        if ((t & 3) == 0) rotate_wave_priority((unsigned)t >> 2, slot);
+#endif
         const uint32_t fl = FL != 0 ? FL : live_flags(P.flags);  // one SGPR; every uniform yes/no below is a bit test
         const Rng R = make_rng(P, i, (unsigned long long)t);
         const long long row = (long long)t * ra.row_stride + blk0;  // uniform
