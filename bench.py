@@ -17,8 +17,8 @@ seed 7.  One "step" = one MR_Env.step() of all N envs.
 MASTER_* in their environment, rendezvous on 127.0.0.1) BEFORE anything touches the GPU, relays rank 0's
 JSON line and exits non-zero if any rank does.  Under a launcher that already set WORLD_SIZE (the driver's
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) it is a rank.  Every rank owns
-a contiguous shard of N x 262144 envs (weak scaling), there is no data-path collective, and episode
-returns are all-gathered over RCCL at episode boundaries (every 51 steps) inside the timed region.
+a contiguous shard of N x 262144 envs (weak scaling), there is no data-path collective, and the returns of every
+episode are all-gathered over RCCL inside the timed region, --gather-interval (8) episodes per collective.
 
 Prints ONE JSON line on rank 0.  Besides the contract's fields:
   roofline      the dominant kernel against the resource that binds it.  Rollout mode: bound = "valu" (vector-issue
@@ -82,6 +82,11 @@ def parse(argv=None):
                     help="rollout mode: the envs of a GPU run as this many sub-shard launches on as many HIP streams "
                          "(mr_rl_amd.collector; 1 = one launch per episode).  Kernel durations for `roofline` always come "
                          "from a one-stream region")
+    ap.add_argument("--gather-interval", type=int, default=8,
+                    help="rollout mode, N > 1 ranks: episodes per RCCL all-gather of returns -- the returns of EVERY episode are "
+                         "gathered, E episodes ([E, n_local] per rank) per collective (the reference logs per 100 episodes, "
+                         "RL/MR_ddpg.py:317-320); 1 = one collective per episode, which is bound by the ~100 us of Python / RCCL "
+                         "enqueue per episode, not by the GPU")
     ap.add_argument("--policy", choices=["kernel", "overlap", "fused"], default="kernel",
                     help="step mode only: policy kernel -> HBM -> step kernel; the same with step t+1's policy kernel on a "
                          "second captured stream beside step t; or drawn inside the step kernel")
@@ -321,8 +326,8 @@ def mixed_goal_table(cfg, seed):
 
 class RolloutRegion:
     """Timed regions of the fused-rollout workload on a RolloutCollector (S sub-shard launches per episode on S HIP
-    streams): `steps` env steps in launch groups of <= T cut at episode boundaries, returns all-gathered at every episode
-    boundary, barrier + synchronize on both sides, max over ranks.  With S = 1, rank 0 can attach a HIP event pair to
+    streams): `steps` env steps in launch groups of <= T cut at episode boundaries, the returns of every episode
+    all-gathered (gather() is called at every episode boundary and starts one collective per --gather-interval episodes), barrier + synchronize on both sides, max over ranks.  With S = 1, rank 0 can attach a HIP event pair to
     every full-length dispatch (non-blocking, hipExtLaunchKernelGGL on the launch stream)."""
 
     def __init__(self, col, gatherer, ep, world, dev, dist_backend):
@@ -374,13 +379,13 @@ class RolloutRegion:
 
 
 def make_region(args, cfg, n_local, env_id0, world, dev, seed, streams, goal_table=None, T=None):
-    from mr_rl_amd.collector import RolloutCollector
-    from mr_rl_amd.dist import ReturnGatherer
+    from mr_rl_amd.collector import BlockReturnGatherer, RolloutCollector
     ep = cfg.max_timesteps + 1
     col = RolloutCollector(n_local, cfg=cfg, device=dev, seed=seed, env_id0=env_id0, goal_table=goal_table,
-                           streams=streams, T=T if T is not None else ep, carry=args.carry)
+                           streams=streams, T=T if T is not None else ep, carry=args.carry,
+                           returns_interval=args.gather_interval)
     col.reset()
-    g = ReturnGatherer(col.env, world, source=lambda: col.ready()["final_ret"], release=col.release)
+    g = BlockReturnGatherer(col, world, force_collective=bool(os.environ.get("MRSIM_BENCH_FORCE_DIST")))
     return RolloutRegion(col, g, ep, world, dev, args.dist_backend)
 
 
@@ -468,6 +473,10 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if world == 1 and os.environ.get("MRSIM_BENCH_FORCE_DIST"):
+        # rehearsal of the per-episode collective's HOST cost on a one-GPU box: a one-rank RCCL group, same call path
+        dist.init_process_group(args.dist_backend, init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                                **({"device_id": torch.device("cuda", 0)} if args.dist_backend == "nccl" else {}))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     pmc = under_pmc()
@@ -709,8 +718,9 @@ def main():
                   "mean_episode_return": mean_ret,
                   "ranks": dist.get_world_size() if world > 1 else 1,
                   "rank_launcher": os.environ.get("MRSIM_BENCH_LAUNCHER", "external (torchrun)" if world > 1 else "none"),
-                  "returns_allgather": ("%s all_gather_into_tensor (%s) every 51 steps"
-                                        % (args.dist_backend, gatherer.mode)) if world > 1 else "local"}
+                  "returns_allgather": ("%s all_gather_into_tensor (%s), the returns of every episode, %d episodes per collective"
+                                        % (args.dist_backend, gatherer.mode, args.gather_interval if args.mode == "rollout" else 1))
+                  if (world > 1 or gatherer._force) else "local"}
         config.update(launch_desc)
         if args.mode == "rollout" and args.carry == "f64":
             dtype = "f64 positions and carried RK45 state; f32 Box-Muller normals and stage-noise sums"
@@ -731,7 +741,7 @@ def main():
         if pmc:
             out["note"] = "run under rocprofv3 counter collection: kernels are serialised, timings are not representative"
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 

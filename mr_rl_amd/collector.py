@@ -2,7 +2,7 @@
 set split into S contiguous sub-shards that run as S fused-rollout launches on S HIP streams.
 
 Why sub-shards.  At N = 262 144 one launch is exactly one resident round of waves (4 per SIMD).  The waves of a SIMD do
-not finish together (the oldest run ahead: DESIGN.md section 7), so every launch ends with a tail in which SIMDs hold one
+not finish together (the oldest run ahead: DESIGN.md section 7b), so every launch ends with a tail in which SIMDs hold one
 or two waves, and on ONE stream the next launch cannot start before the last wave of the previous one has left.  Two
 half-size launch chains on two streams depend only on their own halves: the head of one chain's next episode fills the
 slots the other chain's tail frees.  No env ever waits for an env of another sub-shard -- the path has no data
@@ -10,14 +10,18 @@ dependence between envs -- and results are bit-identical to the sing
 step indices; tests/test_gpu_round2.py).
 
 Data flow.  Transitions go to `depth` (default 2) rotating sets of [T, N, ...] buffers, the sub-shards writing their
-columns (MrsimRolloutIO.row_stride); episode returns / lengths to rotating [N] buffers.  collect() only enqueues;
-ready(k) makes the CURRENT stream wait for episode k's launches and hands out its buffers; release(k) (called by the
-consumer once it is done with them, on the current stream) lets the sub-shard streams overwrite that set `depth`
-episodes later.  A learner therefore reads episode k while the envs produce episode k + 1.
-"""
-import numpy as np
+columns (MrsimRolloutIO.row_stride).  collect() only enqueues; ready(k) makes the CURRENT stream wait for episode k's
+launches and hands out its buffers; release(k) (called by the consumer once it is done with them, on the current
+stream) lets the sub-shard streams overwrite that set `depth` episodes later.  A learner therefore reads episode k while
+the envs produce episode k + 1.
 
-from . import _lib
+Episode returns / lengths go to row (k mod E) of one of two [E, N] blocks (E = returns_interval): BlockReturnGatherer
+all-gathers a whole block -- the returns of E consecutive episodes of every env -- with ONE collective, so the per-episode
+host work of the collection loop is just the S launches.  (The reference logs once per 100 episodes, RL/MR_ddpg.py:317-320;
+E = 1 gives one collective per episode, which at ~115 us per episode is bound by the ~100 us of Python / RCCL enqueue it
+costs, not by the GPU.)
+"""
+from . import _lib  # noqa: F401  (the ctypes binding must be loadable: no CPU fallback)
 from .config import MRConfig
 from .dist import all_shards
 from .vec_env import MRVecEnv
@@ -27,17 +31,17 @@ class RolloutCollector:
     WANT = ("obs", "rew", "done", "actions")
 
     def __init__(self, num_envs, cfg=None, device="cuda", seed=None, env_id0=0, goal_table=None, streams=2, T=None,
-                 want=WANT, carry="f64", depth=2):
+                 want=WANT, carry="f64", depth=2, returns_interval=1):
         import torch
         self.env = MRVecEnv(num_envs, cfg=cfg if cfg is not None else MRConfig(auto_reset=True), device=device, seed=seed,
                             env_id0=env_id0, goal_table=goal_table)
         env = self.env
         self.N, self.S, self.depth, self.carry = env.num_envs, max(1, int(streams)), int(depth), carry
         self.T = int(T) if T is not None else env.cfg.max_timesteps + 1   # one episode per launch by default
+        self.E = max(1, int(returns_interval))
         self.want = tuple(want)
         dev = env.device
         self.shards = [(a, n) for a, n in all_shards(self.N, self.S) if n > 0]
-        # a sub-shard should start on a 256-env block boundary only for tidiness; any split is correct
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.shards]
         T_, N = self.T, self.N
         soa = env._soa
@@ -46,11 +50,13 @@ class RolloutCollector:
                   "done": ((T_, N), torch.uint8), "actions": ((T_, N, 2), torch.float32)}
         self.sets = [{k: torch.empty(shapes[k][0], dtype=shapes[k][1], device=dev) for k in self.want}
                      for _ in range(self.depth)]
-        self.final_ret = [torch.zeros(N, dtype=torch.float32, device=dev) for _ in range(self.depth)]
-        self.final_len = [torch.zeros(N, dtype=torch.int32, device=dev) for _ in range(self.depth)]
+        self.ret_blocks = [torch.zeros((self.E, N), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.len_blocks = [torch.zeros((self.E, N), dtype=torch.int32, device=dev) for _ in range(2)]
         self._done_ev = [[torch.cuda.Event() for _ in self.shards] for _ in range(self.depth)]
         self._free_ev = [None] * self.depth     # recorded by release(): set b may be overwritten after it
+        self._ret_free_ev = [None, None]        # recorded by free_returns_block(): block b may be overwritten after it
         self._start_ev = torch.cuda.Event()
+        self._prepared = {}                     # (shard, set, block, row, steps) -> prepared launch
         self.episodes = 0
         self._synced_streams = False
 
@@ -59,11 +65,15 @@ class RolloutCollector:
         """MR_Env.reset of every env (current stream); the sub-shard streams start behind it."""
         import torch
         obs = self.env.reset(**kw)
+        self._prepared.clear()                  # reset() kwargs may have replaced the parameter block
         self._start_ev.record(torch.cuda.current_stream(self.env.device))
         for st in self.streams:
             st.wait_event(self._start_ev)
         self._synced_streams = True
         return obs
+
+    def _where(self, k):
+        return k % self.depth, (k // self.E) % 2, k % self.E   # buffer set, returns block, row of the block
 
     def collect(self, events=None, steps=None):
         """Enqueue the next launch group: `steps` (default T = one episode) steps per sub-shard, each sub-shard on its
@@ -73,36 +83,53 @@ class RolloutCollector:
         assert self._synced_streams, "call reset() first"
         T = self.T if steps is None else int(steps)
         assert 1 <= T <= self.T
-        b = k % self.depth
+        b, blk, row = self._where(k)
         bufs = self.sets[b]
+        free_set, free_blk = self._free_ev[b], (self._ret_free_ev[blk] if row == 0 else None)
         for s, ((first, n), st) in enumerate(zip(self.shards, self.streams)):
-            if self._free_ev[b] is not None:
-                st.wait_event(self._free_ev[b])       # the consumer has released this set
-            env.launch_rollout(T, first, n, traj=bufs.get("traj"), sp_T=bufs.get("state_prime"), obs_T=bufs.get("obs"),
-                               rew_T=bufs.get("rew"), done_T=bufs.get("done"), acts_T=bufs.get("actions"),
-                               final_ret=self.final_ret[b], final_len=self.final_len[b], carry=self.carry, stream=st,
-                               events=None if events is None else events[s])
+            if free_set is not None:
+                st.wait_event(free_set)         # the consumer has released this buffer set
+            if free_blk is not None:
+                st.wait_event(free_blk)         # the collective that read this returns block has finished
+            key = (s, b, blk, row, T)
+            launch = self._prepared.get(key)
+            if launch is None:
+                launch = self._prepared[key] = env.launch_rollout(
+                    T, first, n, traj=bufs.get("traj"), sp_T=bufs.get("state_prime"), obs_T=bufs.get("obs"),
+                    rew_T=bufs.get("rew"), done_T=bufs.get("done"), acts_T=bufs.get("actions"),
+                    final_ret=self.ret_blocks[blk][row], final_len=self.len_blocks[blk][row], carry=self.carry, stream=st,
+                    prepare_only=True)
+            launch(env.step_idx, events=None if events is None else events[s])
             self._done_ev[b][s].record(st)
+        if row == 0:
+            self._ret_free_ev[blk] = None
         env.step_idx += T
         self.episodes += 1
         return k
 
-    def ready(self, k=None):
-        """Make the current stream wait for episode k (default: the newest) and return its buffers: the [T, N, ...]
-        transition tensors plus "final_ret" / "final_len" [N].  Valid until release(k) + `depth` further collect()s."""
+    def wait_episode(self, k=None):
+        """Make the current stream wait for the launches of episode k (default: the newest)."""
         import torch
         k = self.episodes - 1 if k is None else k
-        assert 0 <= k < self.episodes and k >= self.episodes - self.depth, "that episode's buffers were overwritten"
-        b = k % self.depth
+        assert 0 <= k < self.episodes and k >= self.episodes - self.depth, "that episode's events were reused"
         cur = torch.cuda.current_stream(self.env.device)
-        for ev in self._done_ev[b]:
+        for ev in self._done_ev[k % self.depth]:
             cur.wait_event(ev)
+        return k
+
+    def ready(self, k=None):
+        """Make the current stream wait for episode k (default: the newest) and return its buffers: the [T, N, ...]
+        transition tensors plus "final_ret" / "final_len" [N] (returns / lengths of the episodes that ended in that
+        launch).  The transition buffers stay valid until release(k) + `depth` further collect()s."""
+        import torch
+        k = self.wait_episode(k)
+        b, blk, row = self._where(k)
         out = dict(self.sets[b])
         if "obs" in out and self.env._soa:
             out["obs"] = out["obs"].transpose(1, 2)
         if "done" in out:
             out["done"] = out["done"].view(torch.bool)
-        out["final_ret"], out["final_len"] = self.final_ret[b], self.final_len[b]
+        out["final_ret"], out["final_len"] = self.ret_blocks[blk][row], self.len_blocks[blk][row]
         return out
 
     def release(self, k=None):
@@ -112,6 +139,13 @@ class RolloutCollector:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.env.device))
         self._free_ev[k % self.depth] = ev
+
+    def free_returns_block(self, blk):
+        """Whatever the current stream has enqueued so far is the last reader of returns block `blk`."""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.env.device))
+        self._ret_free_ev[blk] = ev
 
     def join(self):
         """Current stream waits for everything enqueued so far on the sub-shard streams (env state included)."""
@@ -125,3 +159,97 @@ class RolloutCollector:
     def check_status(self):
         self.join()
         return self.env.check_status()
+
+
+class BlockReturnGatherer:
+    """Episode-return reduction for a RolloutCollector: gather() is called once per episode (right after collect()) and
+    every E = collector.E episodes starts ONE asynchronous all_gather_into_tensor of the [E, n_local] block of returns
+    those episodes wrote (RCCL over xGMI when the group's backend is "nccl").  The comm stream waits for the block's last
+    episode through the collector's events; the sub-shard chains never wait for the collective -- only, one block
+    later, for the event that says the collective has read the block they are about to overwrite.  Result layout:
+    [world, E, n_local] = returns of E consecutive episodes in global env order.  Single process (and not forced):
+    no collective at all."""
+
+    def __init__(self, col, world_size=1, group=None, force_collective=False):
+        import torch
+        self.col, self.world, self.group = col, int(world_size), group
+        self._force = bool(force_collective)
+        self._all = [torch.zeros((self.world, col.E, col.N), dtype=torch.float32, device=col.env.device) for _ in range(2)]
+        self._pending = [None, None]
+        self._last = None          # block index of the newest gathered (or, single process, completed) block
+        self.n_gathers = 0         # episodes seen
+        self.n_collectives = 0
+        self.mode = "async"
+
+    def _distributed(self):
+        import torch.distributed as dist
+        return (self.world > 1 or self._force) and dist.is_available() and dist.is_initialized()
+
+    def _retire(self, blk):
+        """stream-side wait for the collective that read block blk, then let the collector overwrite the block"""
+        if self._pending[blk] is not None:
+            self._pending[blk].wait()
+            self._pending[blk] = None
+            self.col.free_returns_block(blk)
+
+    def gather(self):
+        import torch.distributed as dist
+        col = self.col
+        k = self.n_gathers
+        self.n_gathers += 1
+        if (k + 1) % col.E:
+            return
+        blk = (k // col.E) % 2
+        self._last = blk
+        if not self._distributed():
+            return
+        self._retire(1 - blk)          # the chains are about to write the other block again
+        self._retire(blk)              # (only if this block's previous collective is still un-waited: E = 1 corner)
+        col.wait_episode(k)            # the block's last episode; the chains run their episodes in order
+        src, dst = col.ret_blocks[blk].view(-1), self._all[blk].view(-1)
+        if dist.get_backend(self.group) == "gloo" and src.is_cuda:
+            from .dist import gather_returns
+            gather_returns(src, out=dst, group=self.group)   # rehearsal path (gloo has no device collective), synchronous
+            col.free_returns_block(blk)
+        elif self.mode == "async":
+            try:
+                self._pending[blk] = dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
+            except (RuntimeError, TypeError, NotImplementedError) as exc:
+                import sys
+                print(f"[mr_rl_amd.collector] async all_gather_into_tensor unavailable ({exc}); using the blocking form",
+                      file=sys.stderr, flush=True)
+                self.mode = "sync"
+                dist.all_gather_into_tensor(dst, src, group=self.group)
+                col.free_returns_block(blk)
+        else:
+            dist.all_gather_into_tensor(dst, src, group=self.group)
+            col.free_returns_block(blk)
+        self.n_collectives += 1
+
+    def latest(self):
+        """[world, E, n_local] returns of the newest complete block (waits, stream-side, for its collective); None before
+        the first block is complete."""
+        if self._last is None:
+            return None
+        blk = self._last
+        if not self._distributed():
+            self.col.wait_episode()
+            return self.col.ret_blocks[blk].unsqueeze(0)
+        if self._pending[blk] is not None:
+            self._pending[blk].wait()
+            self._pending[blk] = None
+            self.col.free_returns_block(blk)
+        return self._all[blk]
+
+    def finish(self):
+        """Wait (stream-side) for every outstanding collective; call before the final synchronize."""
+        for blk in range(2):
+            self._retire(blk)
+
+    def last_mean(self):
+        r = self.latest()
+        if r is None:   # fewer than E episodes so far: the newest episode's local returns
+            if self.col.episodes == 0:
+                return None
+            return float(self.col.ready()["final_ret"].mean().item())
+        return float(r.mean().item())

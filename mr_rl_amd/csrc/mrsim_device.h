@@ -1216,8 +1216,9 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     if (__builtin_expect((fl & kFSymBounds) != 0, 1)) {
         // the reference's Box is symmetric and equal in x, y, goal_x, goal_y (+-5000): one bound, two
         // SGPRs instead of sixteen (the per-component form below spills scalar registers in the loop)
-        inb = (fmax(__builtin_fabs(e.x), __builtin_fabs(e.y)) <= P.sym_bound) &&
-              (fmax(__builtin_fabs(gx), __builtin_fabs(gy)) <= P.sym_bound);
+        // (two compares with |.| source modifiers each; fmax(|x|, |y|) costs two canonicalising v_max_f64 more)
+        inb = (__builtin_fabs(e.x) <= P.sym_bound) && (__builtin_fabs(e.y) <= P.sym_bound) &&
+              (__builtin_fabs(gx) <= P.sym_bound) && (__builtin_fabs(gy) <= P.sym_bound);
     } else {
         inb = (e.x >= P.obs_lo[0]) && (e.x <= P.obs_hi[0]) && (e.y >= P.obs_lo[1]) && (e.y <= P.obs_hi[1]) &&
               (gx >= P.obs_lo[2]) && (gx <= P.obs_hi[2]) && (gy >= P.obs_lo[3]) && (gy <= P.obs_hi[3]);

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.f0x), "+v"(e.f0y), "+v"(e.h_abs), "+v"(e.counter), "+v"(e.ep_ret));
     int fail = 0;
     const unsigned slot = hw_wave_slot();
+    float* obs_lane = ra.obs_T != nullptr ? ra.obs_T + (blk0 + tid) * 5 : nullptr;  // row t = 0 of this lane's [N][5] record
     for (int t = 0; t < ra.T; ++t) {
 #if MRSIM_PRIO_MODE == 1
         rotate_wave_priority((unsigned)t, slot);
@@ -287,9 +288,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         }
         if (fl & kFOutObs) {
             if (fl & kFObsAos) {
-                float* __restrict__ b = ra.obs_T + row * 5;
+                // per-lane running pointer (one 64-bit add per step): `obs_T + (t * stride + blk0) * 5` would be a 64-bit
+                // multiply by 20 on the vector unit every step (two v_mad_u64_u32 + moves)
 #pragma unroll
-                for (int j = 0; j < 5; ++j) __builtin_nontemporal_store(o.obs[j], &b[tid * 5u + j]);
+                for (int j = 0; j < 5; ++j) __builtin_nontemporal_store(o.obs[j], &obs_lane[j]);
+                obs_lane += ra.row_stride * 5;
             } else {
 #pragma unroll
                 for (int j = 0; j < 5; ++j)

@@ -76,7 +76,7 @@ class ReturnGatherer:
     waited on (stream-side wait, no host block).  latest() / last_mean() wait for the newest gather.
     """
 
-    def __init__(self, env, world_size=1, group=None, source=None, release=None):
+    def __init__(self, env, world_size=1, group=None, source=None, release=None, force_collective=False):
         """source: optional callable returning the [n_local] returns of the episode that just ended, after making the
         current stream wait for whatever produces them (mr_rl_amd.collector.RolloutCollector: `lambda:
         collector.ready()["final_ret"]`); default env.final_ret.  release: optional callable invoked once the returns
@@ -85,6 +85,7 @@ class ReturnGatherer:
         self.env, self.world, self.group = env, int(world_size), group
         self._source = source if source is not None else (lambda: env.final_ret)
         self._release = release
+        self._force = bool(force_collective)  # run the collective path on a one-rank group too (host-overhead rehearsal)
         n = env.num_envs
         self._stage = [torch.zeros(n, dtype=torch.float32, device=env.device) for _ in range(2)]
         self._all = [torch.zeros(self.world * n, dtype=torch.float32, device=env.device) for _ in range(2)]
@@ -94,7 +95,7 @@ class ReturnGatherer:
 
     def _distributed(self):
         import torch.distributed as dist
-        return self.world > 1 and dist.is_available() and dist.is_initialized()
+        return (self.world > 1 or self._force) and dist.is_available() and dist.is_initialized()
 
     def gather(self):
         import torch.distributed as dist

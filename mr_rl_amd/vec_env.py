@@ -314,12 +314,14 @@ class MRVecEnv:
 
     def launch_rollout(self, T, first, n, act_t=None, shared_actions=False, act64=False, traj=None, sp_T=None, obs_T=None,
                        rew_T=None, done_T=None, acts_T=None, final_ret=None, final_len=None, carry="f32", step_idx=None,
-                       stream=None, timed_into=None, events=None):
+                       stream=None, timed_into=None, events=None, prepare_only=False):
         """One mrsim_rollout launch over the envs [first, first + n) of this env set (a sub-shard when n < num_envs):
         state, final_* and every [T, N, ...] buffer are passed advanced to env `first`, the buffers keep their row
         length N (MrsimRolloutIO.row_stride), the RNG keys stay the GLOBAL env ids.  Does not advance step_idx (the
         caller launches all sub-shards of a rollout with the same step_idx and advances once).  mr_rl_amd.collector
-        uses it to put sub-shards on different HIP streams."""
+        uses it to put sub-shards on different HIP streams.  Returns the prepared launch `f(step_idx, events=None)`:
+        with prepare_only=True nothing is launched now and a caller that repeats the same launch every episode (same
+        buffers, new step index) pays only the C call, not the construction of the argument structures."""
         N = self.num_envs
         assert 0 <= first and n >= 1 and first + n <= N
         fr = self.final_ret if final_ret is None else final_ret
@@ -344,17 +346,25 @@ class MRVecEnv:
                                  self.goal_table.data_ptr(), P(traj), P(sp_T), P(obs_T, soa_obs=self._soa), P(rew_T),
                                  P(done_T), P(acts_T), P(fr, 1), P(fl, 1), self.status.data_ptr(),
                                  0 if n == N else N, int(carry == "f64"), int(act64))
-        sidx = self.step_idx if step_idx is None else int(step_idx)
         strm = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
-        args = [C.byref(self._params), n, self.env_id0 + first, C.byref(st), C.byref(io), self.seed_value, sidx, strm]
-        if timed_into is not None:
-            ms = C.c_float(0.0)
-            _lib.check(self._L.mrsim_rollout_timed(*args, C.byref(ms)), "mrsim_rollout_timed")
-            timed_into["kernel_ms"] = ms.value
-        elif events is not None:
-            _lib.check(self._L.mrsim_rollout_events(*args, events.start, events.stop), "mrsim_rollout_events")
-        else:
-            _lib.check(self._L.mrsim_rollout(*args), "mrsim_rollout")
+        head = (C.byref(self._params), n, self.env_id0 + first, C.byref(st), C.byref(io), self.seed_value)
+        L = self._L
+
+        def launch(step_idx, events=None, timed_into=None):
+            """the prepared launch; the ctypes structures above stay alive in this closure"""
+            if timed_into is not None:
+                ms = C.c_float(0.0)
+                _lib.check(L.mrsim_rollout_timed(*head, int(step_idx), strm, C.byref(ms)), "mrsim_rollout_timed")
+                timed_into["kernel_ms"] = ms.value
+            elif events is not None:
+                _lib.check(L.mrsim_rollout_events(*head, int(step_idx), strm, events.start, events.stop), "mrsim_rollout_events")
+            else:
+                _lib.check(L.mrsim_rollout(*head, int(step_idx), strm), "mrsim_rollout")
+
+        if prepare_only:
+            return launch
+        launch(self.step_idx if step_idx is None else int(step_idx), events=events, timed_into=timed_into)
+        return launch
 
     def capture_steps(self, G, policy="kernel"):
         """Capture G env steps into one hipGraph (torch.cuda.CUDAGraph is only the capture plumbing).

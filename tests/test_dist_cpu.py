@@ -135,3 +135,70 @@ def test_return_gatherer_double_buffering_world2():
             want = np.concatenate([np.arange(5) + 100 * r + 1000 * ep for r in range(world)]).astype(np.float32)
             np.testing.assert_array_equal(o, want)
         assert mean == pytest.approx(float(np.concatenate([np.arange(5) + 100 * r + 4000 for r in range(world)]).mean()))
+
+
+def _block_gatherer_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mr_rl_amd.collector import BlockReturnGatherer
+
+        class FakeEnv:
+            device = torch.device("cpu")
+
+        class FakeCollector:  # the members BlockReturnGatherer touches
+            E, N, env = 3, 4, FakeEnv()
+            episodes = 0
+
+            def __init__(self):
+                self.ret_blocks = [torch.zeros(self.E, self.N) for _ in range(2)]
+                self.freed, self.waited = [], []
+
+            def wait_episode(self, k=None):
+                self.waited.append(k)
+
+            def free_returns_block(self, blk):
+                self.freed.append(blk)
+
+        col = FakeCollector()
+        g = BlockReturnGatherer(col, world)
+        outs = []
+        for k in range(4 * col.E):   # 4 blocks over 2 buffers
+            blk, row = (k // col.E) % 2, k % col.E
+            col.ret_blocks[blk][row] = torch.arange(col.N, dtype=torch.float32) + 10 * k + 1000 * rank
+            col.episodes = k + 1
+            g.gather()
+            if (k + 1) % col.E == 0:
+                outs.append(g.latest().clone().numpy())
+        g.finish()
+        q.put((rank, outs, g.n_collectives, col.waited, col.freed))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_block_return_gatherer_world2():
+    """BlockReturnGatherer over gloo, world size 2: every E-th gather() all-gathers the [E, n] block of returns; every rank
+    ends up with [world, E, n] in rank order; a block is handed back to the collector only after its collective."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_block_gatherer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    E, N = 3, 4
+    for rank, outs, ncoll, waited, freed in got:
+        assert ncoll == 4 and waited == [2, 5, 8, 11]
+        assert len(freed) >= 3 and set(freed) <= {0, 1}
+        for b, o in enumerate(outs):
+            assert o.shape == (world, E, N)
+            for r in range(world):
+                for j in range(E):
+                    k = b * E + j
+                    np.testing.assert_array_equal(o[r, j], np.arange(N) + 10 * k + 1000 * r)

@@ -464,3 +464,41 @@ def test_overlapped_policy_graph_equals_the_sequential_one():
         assert torch.equal(a.pos, b.pos) and torch.equal(a.obs, b.obs) and torch.equal(a.aux, b.aux), rep
         assert torch.equal(a.pos, c.pos) and torch.equal(a.final_len, c.final_len), rep
     a.check_status()
+
+
+def test_block_return_gatherer_single_rank_collective():
+    """BlockReturnGatherer on a one-rank group with the collective forced (the RCCL call path on this one-GPU box): the
+    returns of EVERY episode arrive, E per collective, in episode order; the chains keep running while a block is read;
+    blocks are only overwritten after the collective that read them (4 blocks > 2 buffers exercises the reuse)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from mr_rl_amd import MRConfig
+    from mr_rl_amd.collector import BlockReturnGatherer, RolloutCollector
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        E, N = 3, 20000
+        cfg = dict(noise_var=1.0, auto_reset=True, reward_mode="goal")
+        col = RolloutCollector(N, cfg=MRConfig(**cfg), seed=3, streams=2, returns_interval=E)
+        col.reset()
+        g = BlockReturnGatherer(col, 1, force_collective=True)
+        ref = _env(N, seed=3, **cfg); ref.reset()
+        want = []
+        for k in range(4 * E):
+            col.collect()
+            g.gather()
+            ref.rollout(col.T, want=("rew",))
+            want.append(ref.final_ret.clone())
+            if (k + 1) % E == 0:
+                got = g.latest()                      # [1, E, N]
+                assert got.shape == (1, E, N)
+                for j in range(E):
+                    assert torch.equal(got[0, j], want[k + 1 - E + j]), (k, j)
+        g.finish()
+        assert g.n_collectives == 4 and g.mode == "async"
+        assert abs(g.last_mean() - float(torch.stack(want[-E:]).mean())) < 1e-3
+        col.check_status()
+    finally:
+        dist.destroy_process_group()
