@@ -1186,11 +1186,13 @@ __device__ __forceinline__ void pack_obs(double x, double y, double gx, double g
 template <bool RK45, int NZ, bool MIS>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
                                          EnvRegs& e, double act_f, double act_a, const StepWords<RK45, NZ, MIS>& W,
-                                         uint32_t fl, StepOut& o, int& fail, const double2* __restrict__ sincos_lds = nullptr) {
+                                         uint32_t fl, StepOut& o, int& fail, const double2* __restrict__ sincos_lds = nullptr,
+                                         const float2* goal_pre = nullptr) {
     e.counter += 1;  // :80
-    // the goal of this step only depends on the counter: fetch it now so that the table read (an L1/L2 hit,
-    // but hundreds of cycles) completes behind the integrator instead of stalling the termination check
-    const float2 goal_f = goal_fetch(P, fl, goal_table, R.env, e.counter);
+    // the goal of this step only depends on the counter: the one-launch-per-step kernel fetches it now, so that the table
+    // read (an L1/L2 hit, but hundreds of cycles) completes behind the integrator instead of stalling the termination
+    // check; the fused rollout hands in the goal it prefetched before the PREVIOUS step's stores (see mr_rollout_kernel)
+    const float2 goal_f = goal_pre != nullptr ? *goal_pre : goal_fetch(P, fl, goal_table, R.env, e.counter);
     const RhsCtx<MIS> C = make_ctx<MIS>(P, act_f, act_a, sincos_lds);
     double spx = 0.0, spy = 0.0;
     if constexpr (RK45) {

@@ -241,6 +241,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     int fail = 0;
     const unsigned slot = hw_wave_slot();
     float* obs_lane = ra.obs_T != nullptr ? ra.obs_T + (blk0 + tid) * 5 : nullptr;  // row t = 0 of this lane's [N][5] record
+    float2 goal_next = goal_fetch(P, FL != 0 ? FL : P.flags, ra.goal_table, P.env_id0 + (uint32_t)i, e.counter + 1);
+    // consumed HERE for the same reason as the state above: otherwise the in-loop use of the first goal carries an
+    // s_waitcnt vmcnt(0) that, on every later iteration, drains the previous step's stores
+    asm volatile("" : "+v"(goal_next.x), "+v"(goal_next.y));
     for (int t = 0; t < ra.T; ++t) {
 #if MRSIM_PRIO_MODE == 1
         rotate_wave_priority((unsigned)t, slot);
@@ -271,7 +275,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         step_prologue<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa);
         if (!(fl & kFActions64)) { adf = (double)af; ada = (double)aa; }
         StepOut o;
-        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds);
+        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next);
+        // Goal of the NEXT step (row counter + 1 of this env's trajectory; counter is already 0 after an auto-reset), loaded
+        // BEFORE this step's stores are issued: vmcnt counts loads and stores together in issue order, so a load issued
+        // after the stores makes its s_waitcnt vmcnt(0) wait for every one of them; issued before, the wait is vmcnt(5)
+        // (the stores stay in flight).  Measured +0.7 % on the mixed trajectory set: the stores have long retired by then
+        // (what that workload really pays for is its frequent divergent auto-resets, 398 vs 272 VALU per wave-step).
+        goal_next = goal_fetch(P, fl, ra.goal_table, R.env, e.counter + 1);
+        asm volatile("" ::: "memory");  // the stores below stay below the load
         // default: carry K0 / h_abs exactly as a step-by-step run stores them in HBM (fp32), so that a rollout and T
         // single steps give identical bits; kFCarry64 keeps them in fp64 registers until the launch ends
         if (!(fl & kFCarry64)) quantise_env(P, e);
