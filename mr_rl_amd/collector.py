@@ -57,6 +57,7 @@ class RolloutCollector:
         self._ret_free_ev = [None, None]        # recorded by free_returns_block(): block b may be overwritten after it
         self._start_ev = torch.cuda.Event()
         self._prepared = {}                     # (shard, set, block, row, steps) -> prepared launch
+        self._prepared_version = env._params_version
         self.episodes = 0
         self._synced_streams = False
 
@@ -65,7 +66,6 @@ class RolloutCollector:
         """MR_Env.reset of every env (current stream); the sub-shard streams start behind it."""
         import torch
         obs = self.env.reset(**kw)
-        self._prepared.clear()                  # reset() kwargs may have replaced the parameter block
         self._start_ev.record(torch.cuda.current_stream(self.env.device))
         for st in self.streams:
             st.wait_event(self._start_ev)
@@ -83,6 +83,9 @@ class RolloutCollector:
         assert self._synced_streams, "call reset() first"
         T = self.T if steps is None else int(steps)
         assert 1 <= T <= self.T
+        if env._params_version != self._prepared_version:   # reset() kwargs / set_init_space replaced the parameter block
+            self._prepared.clear()
+            self._prepared_version = env._params_version
         b, blk, row = self._where(k)
         bufs = self.sets[b]
         free_set, free_blk = self._free_ev[b], (self._ret_free_ev[blk] if row == 0 else None)

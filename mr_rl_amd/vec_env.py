@@ -108,6 +108,7 @@ class MRVecEnv:
     # ------------------------------------------------------------------ helpers
     def _refresh_params(self):
         self._params = self.cfg.to_params(self._gK, self._gT)
+        self._params_version = getattr(self, "_params_version", 0) + 1  # prepared launches hold the old block
         sb = getattr(self, "_step_base", None)
         self._params.step_base = None if sb is None else sb.data_ptr()
 

@@ -502,3 +502,25 @@ def test_block_return_gatherer_single_rank_collective():
         col.check_status()
     finally:
         dist.destroy_process_group()
+
+
+def test_collector_follows_parameter_changes():
+    """The collector prepares its launch argument structures once; anything that replaces the env's parameter block
+    (reset kwargs, set_init_space) must invalidate them -- otherwise later episodes would run with the old sigma / box."""
+    import torch
+    from mr_rl_amd import MRConfig
+    from mr_rl_amd.collector import RolloutCollector
+    N = 6000
+    col = RolloutCollector(N, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=8, streams=2, carry="f32")
+    ref = _env(N, seed=8, noise_var=1.0, auto_reset=True)
+    col.reset(); ref.reset()
+    col.collect(); ref.rollout(col.T, want=("rew",))
+    col.join()
+    col.env.set_init_space([0.0, 0.0], [1.0, 1.0]); ref.set_init_space([0.0, 0.0], [1.0, 1.0])
+    col.reset(noise_var=0.25); ref.reset(noise_var=0.25)      # new sigma AND new init box
+    for _ in range(2):
+        col.collect(); ref.rollout(col.T, want=("rew",))
+    col.join()
+    assert torch.equal(col.env.pos, ref.pos) and torch.equal(col.env.aux, ref.aux)
+    p = col.env.pos.cpu().numpy()
+    assert (p >= 0).all() and (p <= 1).all()   # the last step of episode 3 auto-reset into the new box
