@@ -87,9 +87,9 @@ def parse(argv=None):
                          "gathered, E episodes ([E, n_local] per rank) per collective (the reference logs per 100 episodes, "
                          "RL/MR_ddpg.py:317-320); 1 = one collective per episode, which is bound by the ~100 us of Python / RCCL "
                          "enqueue per episode, not by the GPU")
-    ap.add_argument("--policy", choices=["kernel", "overlap", "fused"], default="kernel",
+    ap.add_argument("--policy", choices=["kernel", "overlap", "episode", "fused"], default="kernel",
                     help="step mode only: policy kernel -> HBM -> step kernel; the same with step t+1's policy kernel on a "
-                         "second captured stream beside step t; or drawn inside the step kernel")
+                         "second captured stream beside step t; one policy launch per episode (51 rows); or drawn inside the step kernel")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph", help="step mode only")
     ap.add_argument("--graph-len", type=int, default=51)
     ap.add_argument("--obs-layout", choices=["aos", "soa"], default="aos")
@@ -302,11 +302,16 @@ def measure_step_path(cfg, n_local, dev, seed, steps=10200, samples=204):
     avg_ms = sum(ms) / len(ms)
     ach = n_local * ALGO_BYTES_PER_ENV_STEP / (avg_ms * 1e-3) / 1e9
     _, el_f = run("fused")
+    _, el_e = run("episode")
     return {"mode": "step (one launch per env.step, hipGraph of 51 steps, policy kernel + step kernel)",
             "value": n_local * k / el, "unit": "env-steps/s", "steps": k, "ms_per_step": el / k * 1e3,
             "kernel": "mr_step_kernel", "avg_kernel_us": round(avg_ms * 1e3, 3),
             "roofline_frac": round(ach / HBM_PEAK_GBS, 4),
-            "policy_in_step_kernel": {"value": n_local * k / el_f, "unit": "env-steps/s", "ms_per_step": el_f / k * 1e3}}
+            "policy_in_step_kernel": {"value": n_local * k / el_f, "unit": "env-steps/s", "ms_per_step": el_f / k * 1e3},
+            # still a separate policy kernel writing actions to HBM, but ONE launch per episode draws all 51 rows (the
+            # exploration policy reads no state); an observation-dependent actor cannot do this
+            "policy_kernel_once_per_episode": {"value": n_local * k / el_e, "unit": "env-steps/s",
+                                               "ms_per_step": el_e / k * 1e3}}
 
 
 def mixed_goal_table(cfg, seed):
@@ -514,7 +519,7 @@ def main():
         n_launches = [0]
 
         def eager_step():
-            if args.policy in ("kernel", "overlap"):
+            if args.policy in ("kernel", "overlap", "episode"):  # eager remainder: same action values, drawn per step
                 env.step(env.random_policy(out=act))
             else:
                 env.step(None)

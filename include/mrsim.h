@@ -145,6 +145,13 @@ int mrsim_step_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
 int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float* actions,
                         uint64_t seed, uint64_t step_idx, void* stream);
 
+/* The same policy for T consecutive steps in one launch: actions_T[t][n][2], row t bit-identical
+ * to mrsim_random_policy(..., step_idx0 + t).  The exploration policy does not read the state, so
+ * a whole episode's actions can be drawn ahead of its steps (MR_ddpg.py:277 draws them one by
+ * one; the values are the same).  T <= 65535. */
+int mrsim_random_policy_steps(const MrsimParams* p, int64_t n, uint32_t env_id0, float* actions_T,
+                              int32_t T, uint64_t seed, uint64_t step_idx0, void* stream);
+
 /* Inputs / outputs of a fused rollout.  Optional pointers may be NULL. */
 typedef struct MrsimRolloutIO {
     int32_t T;               /* steps in this launch; step_idx0 .. step_idx0+T-1 are consumed          */

@@ -16,7 +16,7 @@ ABI_VERSION = 2
 # every symbol include/mrsim.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
     "mrsim_abi_version", "mrsim_strerror", "mrsim_default_params", "mrsim_reset", "mrsim_step",
-    "mrsim_step_timed", "mrsim_random_policy", "mrsim_rollout", "mrsim_rollout_timed", "mrsim_advance_step_base", "mrsim_velocity", "mrsim_debug_normals",
+    "mrsim_step_timed", "mrsim_random_policy", "mrsim_random_policy_steps", "mrsim_rollout", "mrsim_rollout_timed", "mrsim_advance_step_base", "mrsim_velocity", "mrsim_debug_normals",
     "mrsim_device_count", "mrsim_device_name",
     "mrsim_event_create", "mrsim_event_destroy", "mrsim_event_elapsed_ms", "mrsim_rollout_events", "mrsim_step_events",
 )
@@ -85,6 +85,7 @@ def load(path):
     L.mrsim_step.argtypes = [PP, i64, u32, PS, PIO, u64, u64, vp]
     L.mrsim_step_timed.argtypes = [PP, i64, u32, PS, PIO, u64, u64, vp, C.POINTER(C.c_float)]
     L.mrsim_random_policy.argtypes = [PP, i64, u32, vp, u64, u64, vp]
+    L.mrsim_random_policy_steps.argtypes = [PP, i64, u32, vp, C.c_int32, u64, u64, vp]
     L.mrsim_rollout.argtypes = [PP, i64, u32, PS, C.POINTER(MrsimRolloutIO), u64, u64, vp]
     L.mrsim_rollout_timed.argtypes = L.mrsim_rollout.argtypes + [C.POINTER(C.c_float)]
     L.mrsim_velocity.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp]

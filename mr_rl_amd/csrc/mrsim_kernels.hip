@@ -154,15 +154,18 @@ __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const
 // Latency-bound (2 MiB of output at N = 262 144; rocprof: 4.4 - 5 us inside the gym loop's graph, 2.4 us at best).  A
 // variant with four envs per lane (four Philox calls in flight, two 16-byte stores, a quarter of the workgroups) measured
 // the same to slightly slower (4.95 - 5.1 us, profiles/r02) and was dropped.
+// blockIdx.y = step offset t (1 row for the per-step form; T rows when the state-independent exploration policy is
+// drawn for a whole episode in one launch -- mrsim_random_policy_steps): row t holds exactly what a per-step launch with
+// step_idx + t writes, the step index stays wave-uniform so Philox rounds 0-2 remain scalar.
 __global__ __launch_bounds__(kBlock) void mr_policy_kernel(const KParams P, float* __restrict__ actions) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
-    const Rng R = make_rng(P, i);
+    const Rng R = make_rng(P, i, blockIdx.y);
     float f_t, al;
     uint32_t w[4];
     philox_call(R, P.integrator == MRSIM_INT_RK45 ? policy_c0(true) : policy_c0(false), w);
     action_from_words(P, w, f_t, al);
-    reinterpret_cast<float2*>(actions)[i] = make_float2(f_t, al);
+    reinterpret_cast<float2*>(actions)[(long long)blockIdx.y * P.n + i] = make_float2(f_t, al);
 }
 
 // ---------------------------------------------------------------------------
@@ -675,6 +678,20 @@ int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float
     if ((rc = check_device())) return rc;
     const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
     return launch(lc, mr_policy_kernel, K.n, K, actions);
+}
+
+int mrsim_random_policy_steps(const MrsimParams* p, int64_t n, uint32_t env_id0, float* actions_T, int32_t T,
+                              uint64_t seed, uint64_t step_idx0, void* stream) {
+    KParams K;
+    int rc = make_kparams(p, n, env_id0, seed, step_idx0, K);
+    if (rc) return rc;
+    if (actions_T == nullptr || T < 0 || T > 65535) return MRSIM_EINVAL;  // grid.y limit
+    if (!aligned16(actions_T)) return MRSIM_EALIGN;
+    if (T == 0 || K.n == 0) return MRSIM_OK;
+    if ((rc = check_device())) return rc;
+    const dim3 grid((unsigned)((K.n + kBlock - 1) / kBlock), (unsigned)T);
+    hipLaunchKernelGGL(mr_policy_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), K, actions_T);
+    return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 
 static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,

@@ -256,6 +256,20 @@ class MRVecEnv:
         _lib.check(rc, "mrsim_random_policy")
         return out
 
+    def random_policy_steps(self, T, out=None):
+        """The exploration policy of the next T steps in one launch: actions_T[T,N,2], row t equal to what
+        random_policy() returns right before step t (the policy reads no state, so a whole episode can be drawn
+        ahead of its steps)."""
+        torch = _torch()
+        if out is None:
+            out = torch.empty((int(T), self.num_envs, 2), dtype=torch.float32, device=self.device)
+        if tuple(out.shape) != (int(T), self.num_envs, 2) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("random_policy_steps: out must be a contiguous float32 [T, N, 2] tensor")
+        rc = self._L.mrsim_random_policy_steps(C.byref(self._params), self.num_envs, self.env_id0, self._p(out), int(T),
+                                               self.seed_value, self.step_idx, self._stream())
+        _lib.check(rc, "mrsim_random_policy_steps")
+        return out
+
     def rollout(self, T, actions=None, shared_actions=False, want=("traj",), out=None, timed=False, events=None,
                 carry=None):
         """T fused steps in one launch (batched utils.run_sim / DDPG rollout).  actions: [T,N,2], or [T,2]
@@ -374,11 +388,16 @@ class MRVecEnv:
         t + 1 -- which depends on nothing but (seed, step index, env id) -- runs on a second captured stream while the
         step kernel of step t runs (two rotating action buffers).  Measured SLOWER on MI355X / ROCm 7.2 (14.7 vs 9.1 us per
         step at N = 262 144: graph replay pays ~5 us for every cross-stream dependency), kept for the record and tested;
+        "episode" = ONE policy launch draws the G rows of actions ahead of the G step kernels (exploration only: the policy
+        reads no state; 8 B x G x N of HBM, 107 MB at G = 51, N = 262 144), each step kernel reads its row;
         "fused" = the step kernel draws the policy itself.
         Each replay advances the device step base by G, so replays draw fresh noise."""
         torch = _torch()
         self.enable_device_step_base()
+        if policy not in ("kernel", "overlap", "episode", "fused"):
+            raise ValueError(f"capture_steps: unknown policy mode {policy!r}")
         acts = [torch.empty((self.num_envs, 2), dtype=torch.float32, device=self.device) for _ in range(2)]
+        acts_T = torch.empty((G, self.num_envs, 2), dtype=torch.float32, device=self.device) if policy == "episode" else None
         side2 = torch.cuda.Stream(device=self.device) if policy == "overlap" else None
 
         def body():
@@ -393,6 +412,10 @@ class MRVecEnv:
                             self.random_policy(out=acts[(g + 1) % 2], lookahead=1)
                     self.step(acts[g % 2])
                     main.wait_stream(side2)          # step g+1 reads what side2 has just been asked to write
+            elif policy == "episode":
+                self.random_policy_steps(G, out=acts_T)
+                for g in range(G):
+                    self.step(acts_T[g])
             else:
                 for _ in range(G):
                     if policy == "kernel":
@@ -411,7 +434,7 @@ class MRVecEnv:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             body()
-        self._graph_keepalive = (acts, side2)
+        self._graph_keepalive = (acts, acts_T, side2)
         return graph
 
     def check_status(self):

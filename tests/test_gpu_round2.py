@@ -466,6 +466,37 @@ def test_overlapped_policy_graph_equals_the_sequential_one():
     a.check_status()
 
 
+def test_policy_rows_drawn_per_episode_equal_the_per_step_policy():
+    """mrsim_random_policy_steps: row t of one T-row launch == the per-step policy kernel's output at step t (both
+    integrator key spaces, an odd env count, a rank offset), and the graph that draws the whole episode's actions first
+    (capture_steps(policy="episode")) walks the same trajectory as the per-step capture and the fused rollout."""
+    import torch
+    for kw in (dict(noise_var=1.0), dict(noise_var=0.0, integrator="euler")):
+        e = _env(4999, seed=11, env_id0=123457, **kw); e.reset()
+        e.step_idx = 7
+        rows = e.random_policy_steps(9)
+        for t in range(9):
+            assert torch.equal(rows[t], e.random_policy(lookahead=t)), (kw, t)
+    n, G = 5000, 17
+    a = _env(n, seed=5, noise_var=1.0, auto_reset=True); a.reset()
+    b = _env(n, seed=5, noise_var=1.0, auto_reset=True); b.reset()
+    c = _env(n, seed=5, noise_var=1.0, auto_reset=True); c.reset()
+    ga = a.capture_steps(G, policy="episode")
+    gb = b.capture_steps(G, policy="kernel")
+    c.rollout(G, want=("rew",))
+    torch.cuda.synchronize()
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.pos, c.pos)
+    for rep in range(4):   # 5 x 17 steps: crosses an auto-reset (step 51)
+        ga.replay(); gb.replay()
+        c.rollout(G, want=("rew",))
+        torch.cuda.synchronize()
+        assert torch.equal(a.pos, b.pos) and torch.equal(a.obs, b.obs) and torch.equal(a.aux, b.aux), rep
+        assert torch.equal(a.pos, c.pos) and torch.equal(a.final_len, c.final_len), rep
+    a.check_status()
+    with pytest.raises(ValueError):
+        a.capture_steps(3, policy="nope")
+
+
 def test_block_return_gatherer_single_rank_collective():
     """BlockReturnGatherer on a one-rank group with the collective forced (the RCCL call path on this one-GPU box): the
     returns of EVERY episode arrive, E per collective, in episode order; the chains keep running while a block is read;
