@@ -285,13 +285,6 @@ __device__ __forceinline__ void normals_from_words(const uint32_t (*w)[4], float
     }
 }
 
-__device__ __forceinline__ void uniform2(const Rng& R, uint32_t c0, double& u0, double& u1) {
-    uint32_t o[4];
-    philox_call(R, c0, o);
-    u0 = ((double)o[0] + 0.5) * 2.3283064365386963e-10;
-    u1 = ((double)o[1] + 0.5) * 2.3283064365386963e-10;
-}
-
 // ---------------------------------------------------------------------------
 // small fp64 math, written for few registers (ocml's pow/sincos inline to hundreds of
 // instructions and ~150 VGPRs, which caps the kernel at 3 waves/SIMD)
@@ -524,7 +517,7 @@ template <int NZ, bool MIS>
 __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, uint32_t stream,
                                                double x, double y, double& f0x, double& f0y, double& h_abs,
                                                double& spx, double& spy, bool need_f1 = true,
-                                               SubStep* LS = nullptr) {
+                                               SubStep* LS = nullptr, const uint32_t* wr = nullptr) {
     double n0x = 0.0, n0y = 0.0, n1x = 0.0, n1y = 0.0;
     bool have1 = true;
     // After a step (LS != nullptr) F0 and F1 live in the last attempt's block.  Nominal law: F0 = words 2,3 of
@@ -533,6 +526,16 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
     // Simulator.state_prime is wanted or when the bound below cannot certify h_abs == interval.
     auto eval_f1 = [&]() {
         if constexpr (NZ != kNoNoise) {
+            if (LS == nullptr) {  // nominal reset constructor: F1 = draws 0,1 of its own block
+                if constexpr (!MIS) {
+                    uint32_t o[4];
+                    float z2, z3;
+                    philox_call(R, c0_of(stream, 0, 0), o);
+                    box_muller<NZ>(o[0], o[1], z2, z3);
+                    noise_vec<MIS>(P, C, 0.f, z2, z3, n1x, n1y);
+                }
+                return;
+            }
             if (!LS->have3) {
                 philox_call(R, c0_of(kStreamDyn, LS->last_attempt, MIS ? 5u : 3u), LS->w3);
                 LS->have3 = true;
@@ -564,18 +567,22 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
             if (have1) eval_f1();
         }
     }
-    if constexpr (NZ != kNoNoise) if (LS == nullptr) {  // reset constructor: sequential draws of its own block
-        constexpr int NC = MIS ? 2 : 1;
-        float z[NC * 4];
-        block_normals<NZ, NC>(R, c0_of(stream, 0, 0), z);
-        if constexpr (MIS) {
+    if constexpr (NZ != kNoNoise) if (LS == nullptr) {  // reset constructor
+        if constexpr (MIS) {  // sequential draws of its own block
+            float z[8];
+            block_normals<NZ, 2>(R, c0_of(stream, 0, 0), z);
             noise_vec<MIS>(P, C, z[0], z[1], z[2], n0x, n0y);
             rhs_value<MIS>(P, C, z[0], z[1], z[2], f0x, f0y);
             noise_vec<MIS>(P, C, z[3], z[4], z[5], n1x, n1y);
         } else {
-            noise_vec<MIS>(P, C, 0.f, z[0], z[1], n0x, n0y);
-            rhs_value<MIS>(P, C, 0.f, z[0], z[1], f0x, f0y);
-            noise_vec<MIS>(P, C, 0.f, z[2], z[3], n1x, n1y);
+            // F0 = the Box-Muller pair of words 2,3 of the reset call `wr` (its words 0,1 are the init position, sample_init):
+            // an auto-reset costs one Philox call; F1 as lazily as after a step
+            float z0, z1;
+            box_muller<NZ>(wr[2], wr[3], z0, z1);
+            noise_vec<MIS>(P, C, 0.f, z0, z1, n0x, n0y);
+            rhs_value<MIS>(P, C, 0.f, z0, z1, f0x, f0y);
+            have1 = need_f1;
+            if (have1) eval_f1();
         }
     }
     if constexpr (NZ == kNoNoise) { f0x = C.vx; f0y = C.vy; }
@@ -1113,23 +1120,28 @@ struct StepOut {
 // MR_Env.reset body for one env (MR_env.py:164-201 -> MR_simulator.py:21-34)
 template <bool RK45, int NZ, bool MIS_CTOR>
 __device__ __forceinline__ void reset_env(const KParams& P, const Rng& R, double x0, double y0, EnvRegs& e,
-                                          double& spx, double& spy) {
+                                          double& spx, double& spy, const uint32_t* wr, bool need_f1 = true) {
     e.x = x0; e.y = y0;
     e.counter = 0;
     e.ep_ret = 0.f;
     spx = spy = 0.0;
     if constexpr (RK45) {
         const RhsCtx<MIS_CTOR> Z = zero_ctx<MIS_CTOR>(P);
-        rk45_construct<NZ, MIS_CTOR>(P, Z, R, kStreamResetCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy);
+        rk45_construct<NZ, MIS_CTOR>(P, Z, R, kStreamResetCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy, need_f1, nullptr,
+                                     wr);
     } else {
         e.f0x = e.f0y = 0.0;
         e.h_abs = P.dt;
     }
 }
 
-__device__ __forceinline__ void sample_init(const KParams& P, const Rng& R, double& x0, double& y0) {
-    double u0, u1;
-    uniform2(R, c0_of(kStreamResetPos, 0, 0), u0, u1);
+// The one Philox call of a reset: words 0,1 -> init position, words 2,3 -> the nominal constructor's F0 normals.
+__device__ __forceinline__ void reset_words(const Rng& R, uint32_t (&w)[4]) {
+    philox_call(R, c0_of(kStreamResetPos, 0, 0), w);
+}
+__device__ __forceinline__ void sample_init(const KParams& P, const uint32_t (&w)[4], double& x0, double& y0) {
+    const double u0 = ((double)w[0] + 0.5) * 2.3283064365386963e-10;
+    const double u1 = ((double)w[1] + 0.5) * 2.3283064365386963e-10;
     // init_space.sample() returns float32 (MR_env.py:40-42,173)
     x0 = (double)(float)(P.init_lo[0] + P.init_span[0] * u0);
     y0 = (double)(float)(P.init_lo[1] + P.init_span[1] * u1);
@@ -1246,8 +1258,10 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         o.fret = e.ep_ret;
         o.flen = e.counter;
         double x0, y0, rx, ry;
-        sample_init(P, R, x0, y0);
-        reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry);
+        uint32_t wr[4];
+        reset_words(R, wr);
+        sample_init(P, wr, x0, y0);
+        reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry, wr, (fl & kFOutStatePrime) != 0);
         if constexpr (RK45) { o.spx = (float)rx; o.spy = (float)ry; }  // state_prime = last RHS value
         goal_at(P, fl, goal_table, R.env, 0, gx, gy);
         const double ex = gx - e.x, ey = gy - e.y;

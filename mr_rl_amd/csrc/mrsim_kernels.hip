@@ -125,15 +125,17 @@ __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const
     if (mask != nullptr && mask[i] == 0) return;
     const Rng R = make_rng(P, i);
     double x0, y0;
+    uint32_t wr[4];
+    reset_words(R, wr);  // words 0,1: init position; words 2,3: the nominal constructor's F0 normals
     if (init_xy != nullptr) {
         const double2 p = reinterpret_cast<const double2*>(init_xy)[i];
         x0 = p.x; y0 = p.y;
     } else {
-        sample_init(P, R, x0, y0);
+        sample_init(P, wr, x0, y0);
     }
     EnvRegs e;
     double spx, spy;
-    reset_env<RK45, NZ, MIS_CTOR>(P, R, x0, y0, e, spx, spy);
+    reset_env<RK45, NZ, MIS_CTOR>(P, R, x0, y0, e, spx, spy, wr, /*need_f1=*/false);
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
     if (obs != nullptr) {
         double gx, gy;

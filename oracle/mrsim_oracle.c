@@ -255,7 +255,9 @@ static const double RK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 172
  *     draws 0..1: K1 (dead; policy words as above)   2..4: K2   5..7: K3   8..10: K4   11..13: K5
  *     14..16: F0   17..19: K6   20..22: F1   (23 unused)
  *   so that calls 0..4 are needed eagerly, the pair (K6x, K6y) and call 5 (F1) almost never.
- *   Reset constructors: sequential in RESET_CTOR(0) for both laws. */
+ *   Reset constructors.  Nominal law: F0 = draws 2,3 of the RESET_POS call whose words 0,1 are the init position
+ *   (orc_sample_init), F1 = draws 0,1 of RESET_CTOR(0) -- an auto-reset then costs the GPU one Philox call, F1 being
+ *   needed as rarely as after a step.  Mismatched law: sequential in RESET_CTOR(0). */
 #define NOM_POS_K6 12
 #define NOM_POS_F0 10
 #define NOM_POS_F1 14
@@ -265,7 +267,7 @@ static const double RK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 172
 #define MIS_POS_F1 20
 
 static void rk45_construct(const OrcParams* p, int mismatched, OrcEnv* e, const double act[2], OrcNoise* nz,
-                           uint32_t env_id, int stream, uint32_t block, int pos_f0, int pos_f1) {
+                           uint32_t env_id, int stream, uint32_t block, int pos_f0, int pos_f1, int stream_f1) {
     NStream ns;
     ns_open(&ns, nz, env_id, stream, block);
     const double t0 = e->t, t_bound = e->t + p->time_span;
@@ -282,6 +284,7 @@ static void rk45_construct(const OrcParams* p, int mismatched, OrcEnv* e, const 
     double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
     h0 = fmin(h0, interval_length);
     /* y1 = y0 + h0*f0 is formed and passed to fun, which ignores it */
+    if (stream_f1 >= 0) ns_open(&ns, nz, env_id, stream_f1, block); /* F1 lives in another stream's block */
     if (pos_f1 >= 0) ns_seek(&ns, pos_f1);
     simulate(p, mismatched, e, act, &ns, f1);
     const double d2 = rms2((f1[0] - f0[0]) / sc0, (f1[1] - f0[1]) / sc1) / h0;
@@ -298,7 +301,11 @@ void orc_sim_reset(const OrcParams* p, OrcEnv* e, double x0, double y0, int ctor
     e->t = 0.0;                           /* scipy_runge_kutta default t0 = 0, :90 */
     const double zero[2] = {0.0, 0.0};    /* :30 */
     e->n_rhs = 0; e->n_attempts = 0; e->status = 0;
-    rk45_construct(p, ctor_mismatched, e, zero, nz, env_id, ctor_stream ? ctor_stream : STREAM_RESET_CTOR, 0, -1, -1);
+    const int cs = ctor_stream ? ctor_stream : STREAM_RESET_CTOR;
+    if (!ctor_mismatched && cs == STREAM_RESET_CTOR)
+        rk45_construct(p, 0, e, zero, nz, env_id, STREAM_RESET_POS, 0, 2, 0, STREAM_RESET_CTOR);
+    else
+        rk45_construct(p, ctor_mismatched, e, zero, nz, env_id, cs, 0, -1, -1, -1);
 }
 
 /* Simulator.step.  MR_simulator.py:36-52 */
@@ -399,7 +406,7 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
     }
     /* last_state = integrator.y (:45); new RK45 from (t, y) to t + time_span (:46-50) */
     rk45_construct(p, mis, e, act, nz, env_id, STREAM_DYN, attempt ? attempt - 1 : 0,
-                   mis ? MIS_POS_F0 : NOM_POS_F0, mis ? MIS_POS_F1 : NOM_POS_F1);
+                   mis ? MIS_POS_F0 : NOM_POS_F0, mis ? MIS_POS_F1 : NOM_POS_F1, -1);
     return 0;
 }
 
