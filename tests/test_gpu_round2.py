@@ -555,3 +555,99 @@ def test_collector_follows_parameter_changes():
     assert torch.equal(col.env.pos, ref.pos) and torch.equal(col.env.aux, ref.aux)
     p = col.env.pos.cpu().numpy()
     assert (p >= 0).all() and (p <= 1).all()   # the last step of episode 3 auto-reset into the new box
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# randomised configurations against the oracle (the hand-picked cases of test_gpu_parity.py leave the cross terms open:
+# law x sigma x init box x reward mode x episode length x layout x launch form)
+# ----------------------------------------------------------------------------------------------------------------------
+def _random_case(k):
+    rng = np.random.default_rng(1000 + k)
+    boxes = [((100.0, 100.0), (120.0, 120.0)),        # the reference's init space
+             ((-40.0, -40.0), (40.0, 40.0)),          # crosses both axes: step-size control splits steps, goal reach (d < 30)
+             ((4960.0, -4995.0), (4999.0, -4950.0)),  # next to the observation bounds: out-of-bounds terminations
+             ((-130.0, 90.0), (-90.0, 130.0))]        # another quadrant (sign handling of the |y| scales)
+    lo, hi = boxes[k % 4]
+    T = int(rng.choice([5, 50, 64]))
+    return dict(noise_var=float(rng.choice([0.0, 0.05, 0.7, 3.0])), a0=float(rng.uniform(0.3, 3.0)),
+                is_mismatched=bool(k & 4), init_low=lo, init_high=hi,
+                reward_mode=("goal" if rng.integers(2) else "constant10"), min_dist2goal=float(rng.choice([30.0, 5.0])),
+                max_timesteps=int(rng.choice([3, 20, 50])), auto_reset=bool(rng.integers(4) > 0),
+                obs_layout=("soa" if rng.integers(3) == 0 else "aos"), noise_math="spec"), T, rng
+
+
+@pytest.mark.parametrize("k", range(16))
+def test_randomised_config_vs_oracle(k):
+    """16 seeded configurations, 600 envs each (not a multiple of the wave or block size), spec noise (normals bit-identical
+    to the oracle's): odd cases are driven through step() -- explicit actions and the in-kernel policy alternating -- even
+    ones through fused rollouts of 7 steps.  Positions to 1e-6, observations to float32 resolution, reward / done /
+    counter / episode length exact, every step.  An env may leave the comparison only the way
+    test_step_vs_oracle_noise_near_origin allows: at a step where the oracle saw an attempt with |error_norm - 1| < 1e-6."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    kw, T, rng = _random_case(k)
+    n = 600
+    cfg = MRConfig(**kw)
+    env = MRVecEnv(n, cfg=cfg, seed=77 + k, env_id0=1000 * k)
+    orc = O.VecOracle(n, orc_params_from_cfg(cfg), seed=77 + k, env_id0=1000 * k)
+    og = env.reset(); oo = orc.reset(0)
+    og = og.cpu().numpy()   # [N, 5] whatever the layout in HBM (a transposed view for "soa")
+    np.testing.assert_array_equal(env.pos.cpu().numpy(), orc.envs["y"])
+    assert np.abs(og - oo.astype(np.float32)).max() <= 1e-3   # the distance entry: v_sqrt_f32 vs sqrt (values ~ 7000)
+    alive = np.ones(n, bool)
+    unexplained = []
+    lo_p, hi_p = cfg.policy_low, cfg.policy_high
+
+    ndone = [0]
+
+    def check(t, pos, obs, rew, done):
+        ndone[0] += int(orc.done.sum())
+        bad = alive & ~(np.abs(pos - orc.envs["y"]).max(axis=1) <= 1e-6)
+        for i in np.nonzero(bad)[0]:
+            if not (orc.envs["err_margin"][i] < 1e-6):
+                unexplained.append((t, int(i), float(orc.envs["err_margin"][i])))
+        alive[bad] = False
+        a = alive
+        np.testing.assert_array_equal(done[a].astype(np.uint8), orc.done[a], err_msg=f"done, step {t}")
+        np.testing.assert_array_equal(rew[a], orc.rew[a].astype(np.float32), err_msg=f"rew, step {t}")
+        want = orc.obs[a].astype(np.float32)
+        tol = 2 * np.spacing(np.abs(want)) + 1e-6
+        tol[:, 4] += 1e-3 * (np.abs(want[:, 4]) > 1000)   # sqrt of ~5e7 in fp32 hardware sqrt: 1 ulp of 7000 = 5e-4
+        assert (np.abs(obs[a].astype(np.float64) - want) <= tol).all(), f"obs, step {t}"
+
+    t = 0
+    while t < T:
+        if k % 2:   # one launch per step
+            a_o = orc.random_policy(t + 1, lo_p, hi_p)
+            if t % 2:
+                obs, rew, done, info = env.step(a_o)
+            else:
+                obs, rew, done, info = env.step(None)
+            orc.step(a_o, step_idx=t + 1)
+            obs = obs.cpu().numpy()
+            check(t, env.pos.cpu().numpy(), obs, rew.cpu().numpy(), done.cpu().numpy())
+            if cfg.auto_reset:
+                d = orc.done.astype(bool) & alive
+                np.testing.assert_array_equal(info["final_len"].cpu().numpy()[d], orc.final_len[d])
+            t += 1
+        else:       # fused rollouts of 7 steps (the last one shorter)
+            m = min(7, T - t)
+            r = env.rollout(m, want=("traj", "obs", "rew", "done", "actions"), carry=("f64" if k % 4 == 0 else "f32"))
+            torch.cuda.synchronize()
+            for j in range(m):
+                a_o = orc.random_policy(t + j + 1, lo_p, hi_p)
+                np.testing.assert_array_equal(r["actions"][j].cpu().numpy(), a_o)
+                orc.step(a_o, step_idx=t + j + 1)
+                obs = r["obs"][j].cpu().numpy()
+                pos = r["traj"][j].cpu().numpy()
+                if cfg.auto_reset:   # traj holds the position BEFORE the auto-reset; the oracle's y the one after it
+                    d = orc.done.astype(bool)
+                    pos = np.where(d[:, None], orc.envs["y"], pos) if j < m - 1 else env.pos.cpu().numpy()
+                check(t + j, pos, obs, r["rew"][j].cpu().numpy(), r["done"][j].cpu().numpy())
+            t += m
+            np.testing.assert_array_equal(env.counter.cpu().numpy()[alive], orc.envs["counter"][alive])
+    assert not unexplained, (kw, unexplained[:6])
+    assert alive.mean() >= 0.97, (kw, alive.mean())
+    if cfg.max_timesteps + 1 <= T:
+        assert ndone[0] >= n   # every env ran into the timeout at least (the termination / auto-reset code was exercised)
+    env.check_status()
