@@ -557,6 +557,41 @@ def test_collector_follows_parameter_changes():
     assert (p >= 0).all() and (p <= 1).all()   # the last step of episode 3 auto-reset into the new box
 
 
+def test_collector_prime_only_warms_the_launch_cache():
+    """RolloutCollector.prime(schedule) builds the argument blocks of the coming collect() calls and enqueues nothing: the
+    same irregular schedule (5, 20, 26 = one episode, then full episodes) with and without it walks the same states and
+    writes the same transitions; a prime() issued before a parameter change is discarded with the rest of the cache."""
+    import torch
+    from mr_rl_amd import MRConfig
+    from mr_rl_amd.collector import RolloutCollector
+    N, sched = 5000, [5, 20, 26, 51, 51]
+    a = RolloutCollector(N, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=3, streams=2, carry="f64")
+    b = RolloutCollector(N, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=3, streams=2, carry="f64")
+    a.reset(); b.reset()
+    pos0 = a.env.pos.clone()
+    a.prime(sched)
+    a.join(); torch.cuda.synchronize()
+    assert torch.equal(a.env.pos, pos0) and a.episodes == 0 and a.env.step_idx == b.env.step_idx
+    n_keys = len(a._prepared)
+    assert n_keys == 2 * len(sched)
+    for T in sched:
+        ka, kb = a.collect(steps=T), b.collect(steps=T)
+        ra, rb = a.ready(ka), b.ready(kb)
+        torch.cuda.synchronize()
+        for key in ("obs", "rew", "done", "actions"):
+            assert torch.equal(ra[key][:T], rb[key][:T]), (T, key)
+        a.release(ka); b.release(kb)
+    assert len(a._prepared) == n_keys          # every launch came from the primed cache
+    a.join(); b.join()
+    assert torch.equal(a.env.pos, b.env.pos) and torch.equal(a.env.aux, b.env.aux)
+    a.prime([51])
+    a.reset(noise_var=0.25); b.reset(noise_var=0.25)
+    a.collect(); b.collect()
+    a.join(); b.join()
+    assert torch.equal(a.env.pos, b.env.pos)
+    a.check_status()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # randomised configurations against the oracle (the hand-picked cases of test_gpu_parity.py leave the cross terms open:
 # law x sigma x init box x reward mode x episode length x layout x launch form)
