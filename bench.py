@@ -171,7 +171,10 @@ def launch_ranks(args, argv):
             if p.poll() is None:
                 p.kill()
     out0.seek(0)
-    sys.stdout.write(out0.read().decode(errors="replace"))
+    # the contract is ONE JSON line on stdout: libraries of the child may have written there too (gloo announces its
+    # connections on stdout), that goes to stderr
+    for line in out0.read().decode(errors="replace").splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return rc
 
