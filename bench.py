@@ -479,6 +479,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))
     ensure_built()
+    # The contract is ONE JSON line on stdout.  Native libraries write to file descriptor 1 as well (RCCL prints a five-line
+    # version banner there when its first communicator comes up, gloo announces its connections): from here on fd 1 is
+    # stderr, and the JSON line goes to the saved descriptor at the very end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from mr_rl_amd import MRConfig, MRVecEnv
@@ -772,7 +778,10 @@ def main():
             out["mixed_trajectory_set"] = mixed
         if pmc:
             out["note"] = "run under rocprofv3 counter collection: kernels are serialised, timings are not representative"
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        line = (json.dumps(out) + "\n").encode()
+        while line:
+            line = line[os.write(json_fd, line):]
     if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
