@@ -497,6 +497,29 @@ def test_policy_rows_drawn_per_episode_equal_the_per_step_policy():
         a.capture_steps(3, policy="nope")
 
 
+@pytest.mark.parametrize("policy", ["kernel", "episode", "fused"])
+def test_sub_shard_step_graph_equals_the_whole_env_graph(policy):
+    """capture_steps(shards=3): three contiguous sub-shards (cut at multiples of 256; the last one ragged), each with its
+    own chain of step kernels on its own captured stream.  Same envs, same global ids, same step indices => bit-identical
+    to the one-kernel-per-step graph, replay after replay (auto-resets included), for every policy form."""
+    import torch
+    n, G = 5000, 17
+    a = _env(n, seed=9, noise_var=1.0, auto_reset=True); a.reset()
+    b = _env(n, seed=9, noise_var=1.0, auto_reset=True); b.reset()
+    ga = a.capture_steps(G, policy=policy, shards=3)
+    gb = b.capture_steps(G, policy=policy)
+    torch.cuda.synchronize()
+    assert torch.equal(a.pos, b.pos)
+    for rep in range(4):
+        ga.replay(); gb.replay()
+        torch.cuda.synchronize()
+        for name in ("pos", "aux", "obs", "rew", "done", "final_ret", "final_len", "ep_ret"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (rep, name)
+    a.check_status()
+    with pytest.raises(ValueError):
+        a.capture_steps(G, policy="overlap", shards=2)
+
+
 def test_block_return_gatherer_single_rank_collective():
     """BlockReturnGatherer on a one-rank group with the collective forced (the RCCL call path on this one-GPU box): the
     returns of EVERY episode arrive, E per collective, in episode order; the chains keep running while a block is read;
