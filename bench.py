@@ -357,8 +357,9 @@ class RolloutRegion:
             self.launches += len(col.shards)
             self.done_steps += chunk
             left -= chunk
-            if self.done_steps % ep == 0:
-                self.g.gather()  # RCCL all-gather of this episode's returns
+            # after EVERY launch group (normally = one episode): the gatherer counts them and all-gathers a block of
+            # returns per --gather-interval groups
+            self.g.gather()
 
     def schedule(self, nsteps):
         """The launch-group lengths run(nsteps) will use from here."""

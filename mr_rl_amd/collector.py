@@ -183,9 +183,12 @@ class RolloutCollector:
 
 
 class BlockReturnGatherer:
-    """Episode-return reduction for a RolloutCollector: gather() is called once per episode (right after collect()) and
-    every E = collector.E episodes starts ONE asynchronous all_gather_into_tensor of the [E, n_local] block of returns
-    those episodes wrote (RCCL over xGMI when the group's backend is "nccl").  The comm stream waits for the block's last
+    """Episode-return reduction for a RolloutCollector: gather() is called after every collect() and, every E =
+    collector.E launch groups, starts ONE asynchronous all_gather_into_tensor of the [E, n_local] block of returns those
+    launch groups wrote (RCCL over xGMI when the group's backend is "nccl").  Rows are indexed by the COLLECTOR's launch
+    group, whatever its length: with one episode per launch (the default T) a row is an episode; a schedule that cuts an
+    episode into several launch groups (bench.py --steps 20) spends a row per group, and a row only holds the returns of
+    the envs whose episode ended in that group.  The comm stream waits for the block's last
     episode through the collector's events; the sub-shard chains never wait for the collective -- only, one block
     later, for the event that says the collective has read the block they are about to overwrite.  Result layout:
     [world, E, n_local] = returns of E consecutive episodes in global env order.  Single process (and not forced):
@@ -198,7 +201,8 @@ class BlockReturnGatherer:
         self._all = [torch.zeros((self.world, col.E, col.N), dtype=torch.float32, device=col.env.device) for _ in range(2)]
         self._pending = [None, None]
         self._last = None          # block index of the newest gathered (or, single process, completed) block
-        self.n_gathers = 0         # episodes seen
+        self._k_seen = -1          # newest launch group gather() has been called for
+        self.n_gathers = 0         # launch groups seen
         self.n_collectives = 0
         self.mode = "async"
 
@@ -216,7 +220,13 @@ class BlockReturnGatherer:
     def gather(self):
         import torch.distributed as dist
         col = self.col
-        k = self.n_gathers
+        k = col.episodes - 1           # the launch group collect() has just enqueued: its index is what rows / events go by
+        if k < 0 or k == self._k_seen:
+            return
+        if k != self._k_seen + 1:
+            raise RuntimeError(f"BlockReturnGatherer.gather() must follow every collect(): launch groups "
+                               f"{self._k_seen + 1}..{k - 1} were skipped")
+        self._k_seen = k
         self.n_gathers += 1
         if (k + 1) % col.E:
             return

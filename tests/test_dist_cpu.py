@@ -202,3 +202,38 @@ def test_block_return_gatherer_world2():
                 for j in range(E):
                     k = b * E + j
                     np.testing.assert_array_equal(o[r, j], np.arange(N) + 10 * k + 1000 * r)
+
+
+def test_block_return_gatherer_follows_the_collectors_launch_groups():
+    """Rows and events are indexed by the collector's launch groups (collect() calls), not by a count the gatherer keeps
+    itself: calling gather() twice for one group is harmless, skipping a group is an error (a schedule that cuts
+    episodes into several groups -- bench.py --steps 20 --warmup 5 -- once made the two counts drift apart)."""
+    import torch
+    from mr_rl_amd.collector import BlockReturnGatherer
+
+    class FakeEnv:
+        device = "cpu"
+
+    class FakeCollector:
+        E, N, env, episodes = 2, 3, FakeEnv(), 0
+
+        def __init__(self):
+            self.ret_blocks = [torch.zeros(self.E, self.N) for _ in range(2)]
+
+        def wait_episode(self, k=None):
+            pass
+
+    col = FakeCollector()
+    g = BlockReturnGatherer(col, 1)
+    g.gather()                       # nothing collected yet
+    assert g.n_gathers == 0 and g.latest() is None
+    for k in range(5):
+        col.ret_blocks[(k // 2) % 2][k % 2] = float(k)
+        col.episodes = k + 1
+        g.gather(); g.gather()       # the second call is a no-op
+        assert g.n_gathers == k + 1
+        if k % 2:
+            assert g.latest().shape == (1, 2, 3) and float(g.latest()[0, 1, 0]) == k
+    col.episodes = 8                 # groups 5 and 6 never reported
+    with pytest.raises(RuntimeError, match="skipped"):
+        g.gather()

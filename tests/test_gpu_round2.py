@@ -553,6 +553,24 @@ def test_block_return_gatherer_single_rank_collective():
         g.finish()
         assert g.n_collectives == 4 and g.mode == "async"
         assert abs(g.last_mean() - float(torch.stack(want[-E:]).mean())) < 1e-3
+        # an episode cut into three launch groups (what `bench.py --steps 20 --warmup 5` does), then whole episodes again:
+        # rows and events go by the collector's launch groups, so the gatherer keeps in step with it (it once counted
+        # episodes by itself and then waited for an event the collector had already reused)
+        rows = {}
+        for steps in (5, 20, 26, 51, 51, 51, 51, 51, 51):
+            k = col.collect(steps=steps)
+            g.gather()
+            ref.rollout(steps, want=("rew",))
+            if steps != 5 and steps != 20:            # groups in which every env's episode ends: the whole row is new
+                rows[k] = ref.final_ret.clone()
+            if (k + 1) % E == 0:
+                got = g.latest()
+                for j in range(E):
+                    kk = k + 1 - E + j
+                    if kk in rows:
+                        assert torch.equal(got[0, j], rows[kk]), (k, j)
+        g.finish()
+        assert g.n_collectives == 7 and g.n_gathers == 21
         col.check_status()
     finally:
         dist.destroy_process_group()
