@@ -136,6 +136,9 @@ def rank_commands(n_ranks, argv, port, python=None, script=None, base_env=None):
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
                     "MRSIM_BENCH_LAUNCHER": "bench.py"})
+        # as torch.distributed.run does: N ranks x all host cores of OpenMP / intra-op threads oversubscribe the box
+        # (measured with two gloo ranks: 230 ms per host-staged collective without this, ~2 ms with it)
+        env.setdefault("OMP_NUM_THREADS", "1")
         out.append((cmd, env))
     return out
 
