@@ -58,6 +58,8 @@ struct KParams {
     double h1_thresh_m;    // h1_thresh / 1.05                  (first-level tests, 5 % margins)
     double k_h0;           // 105 * dt: |y| >= k_h0 * F  =>  0.01 * d0/d1 >= dt, i.e. h0 == dt
     double gmax_dt;        // 2 * Zmax * sigma / dt: worst case of |f1 - f0| / dt under the nominal law
+    double reset_fmin;     // >= 0: over the whole init box construct_level0 of a nominal reset constructor reduces to
+                           // max|f0| >= reset_fmin (make_kparams certifies the other three conditions); < 0: not certified
     double zmax2_dt;       // 2 * Zmax / dt
     double zmax_e6_sigma;  // Zmax * E6 * sigma: worst-case contribution of K6 to the error estimate
     float h1_thresh2_f, dt2_f;
@@ -517,7 +519,8 @@ template <int NZ, bool MIS>
 __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, uint32_t stream,
                                                double x, double y, double& f0x, double& f0y, double& h_abs,
                                                double& spx, double& spy, bool need_f1 = true,
-                                               SubStep* LS = nullptr, const uint32_t* wr = nullptr) {
+                                               SubStep* LS = nullptr, const uint32_t* wr = nullptr,
+                                               bool in_init_box = false) {
     double n0x = 0.0, n0y = 0.0, n1x = 0.0, n1y = 0.0;
     bool have1 = true;
     // After a step (LS != nullptr) F0 and F1 live in the last attempt's block.  Nominal law: F0 = words 2,3 of
@@ -583,6 +586,16 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
             rhs_value<MIS>(P, C, 0.f, z0, z1, f0x, f0y);
             have1 = need_f1;
             if (have1) eval_f1();
+            // Position sampled from the init box, zero action, F1 not needed: with |f0| <= sigma Zmax and |y| confined to the
+            // box, three of the four conditions of construct_level0 hold for every draw (checked once on the host,
+            // make_kparams) and the fourth, F >= 2e-5 max(scale), is implied by F >= reset_fmin.  Same outcome
+            // (h_abs = dt) as the full test whenever this passes; anything else goes on to the full test.
+            if (!have1 && in_init_box && P.reset_fmin >= 0.0 &&
+                fmax(__builtin_fabs(f0x), __builtin_fabs(f0y)) >= P.reset_fmin) {
+                spx = C.vx; spy = C.vy;
+                h_abs = P.dt;
+                return;
+            }
         }
     }
     if constexpr (NZ == kNoNoise) { f0x = C.vx; f0y = C.vy; }
@@ -1120,7 +1133,8 @@ struct StepOut {
 // MR_Env.reset body for one env (MR_env.py:164-201 -> MR_simulator.py:21-34)
 template <bool RK45, int NZ, bool MIS_CTOR>
 __device__ __forceinline__ void reset_env(const KParams& P, const Rng& R, double x0, double y0, EnvRegs& e,
-                                          double& spx, double& spy, const uint32_t* wr, bool need_f1 = true) {
+                                          double& spx, double& spy, const uint32_t* wr, bool need_f1 = true,
+                                          bool in_init_box = false) {
     e.x = x0; e.y = y0;
     e.counter = 0;
     e.ep_ret = 0.f;
@@ -1128,7 +1142,7 @@ __device__ __forceinline__ void reset_env(const KParams& P, const Rng& R, double
     if constexpr (RK45) {
         const RhsCtx<MIS_CTOR> Z = zero_ctx<MIS_CTOR>(P);
         rk45_construct<NZ, MIS_CTOR>(P, Z, R, kStreamResetCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy, need_f1, nullptr,
-                                     wr);
+                                     wr, in_init_box);
     } else {
         e.f0x = e.f0y = 0.0;
         e.h_abs = P.dt;
@@ -1199,7 +1213,7 @@ template <bool RK45, int NZ, bool MIS>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
                                          EnvRegs& e, double act_f, double act_a, const StepWords<RK45, NZ, MIS>& W,
                                          uint32_t fl, StepOut& o, int& fail, const double2* __restrict__ sincos_lds = nullptr,
-                                         const float2* goal_pre = nullptr) {
+                                         const float2* goal_pre = nullptr, const float2* goal0_pre = nullptr) {
     e.counter += 1;  // :80
     // the goal of this step only depends on the counter: the one-launch-per-step kernel fetches it now, so that the table
     // read (an L1/L2 hit, but hundreds of cycles) completes behind the integrator instead of stalling the termination
@@ -1261,9 +1275,15 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         uint32_t wr[4];
         reset_words(R, wr);
         sample_init(P, wr, x0, y0);
-        reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry, wr, (fl & kFOutStatePrime) != 0);
+        // The host-certified shortcut of the constructor test only where resets are hot: on a goal table episodes end at
+        // different steps, so some lane of almost every wave resets at almost every step.  With the constant goal all
+        // episodes of the DDPG workload end together every max_timesteps + 1 steps, and its flag-specialised kernel keeps
+        // the code (and the register allocation of its time loop) it had.
+        reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry, wr, (fl & kFOutStatePrime) != 0,
+                                   /*in_init_box=*/(fl & kFGoalTable) != 0);
         if constexpr (RK45) { o.spx = (float)rx; o.spy = (float)ry; }  // state_prime = last RHS value
-        goal_at(P, fl, goal_table, R.env, 0, gx, gy);
+        if (goal0_pre != nullptr) { gx = (double)goal0_pre->x; gy = (double)goal0_pre->y; }  // row 0: loaded once per launch
+        else goal_at(P, fl, goal_table, R.env, 0, gx, gy);
         const double ex = gx - e.x, ey = gy - e.y;
         pack_obs(e.x, e.y, gx, gy, __builtin_fma(ex, ex, ey * ey), o.obs);
     }

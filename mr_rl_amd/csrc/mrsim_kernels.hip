@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const
     }
     EnvRegs e;
     double spx, spy;
-    reset_env<RK45, NZ, MIS_CTOR>(P, R, x0, y0, e, spx, spy, wr, /*need_f1=*/false);
+    reset_env<RK45, NZ, MIS_CTOR>(P, R, x0, y0, e, spx, spy, wr, /*need_f1=*/false, /*in_init_box=*/init_xy == nullptr);
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
     if (obs != nullptr) {
         double gx, gy;
@@ -250,6 +250,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     // consumed HERE for the same reason as the state above: otherwise the in-loop use of the first goal carries an
     // s_waitcnt vmcnt(0) that, on every later iteration, drains the previous step's stores
     asm volatile("" : "+v"(goal_next.x), "+v"(goal_next.y));
+    // goal of an auto-reset's observation (row 0 of this env's trajectory): the same for every reset of the launch
+    // (kernels specialised for the constant goal (0, 0) keep no registers for it)
+    constexpr bool kGoal0 = FL == 0 || (FL & kFGoalTable) != 0;
+    float2 goal0 = make_float2(0.f, 0.f);
+    if constexpr (kGoal0) {
+        goal0 = goal_fetch(P, FL != 0 ? FL : P.flags, ra.goal_table, P.env_id0 + (uint32_t)i, 0);
+        asm volatile("" : "+v"(goal0.x), "+v"(goal0.y));
+    }
     for (int t = 0; t < ra.T; ++t) {
 #if MRSIM_PRIO_MODE == 1
         rotate_wave_priority((unsigned)t, slot);
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         step_prologue<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa);
         if (!(fl & kFActions64)) { adf = (double)af; ada = (double)aa; }
         StepOut o;
-        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next);
+        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr);
         // Goal of the NEXT step (row counter + 1 of this env's trajectory; counter is already 0 after an auto-reset), loaded
         // BEFORE this step's stores are issued: vmcnt counts loads and stores together in issue order, so a load issued
         // after the stores makes its s_waitcnt vmcnt(0) wait for every one of them; issued before, the wait is vmcnt(5)
@@ -455,6 +463,23 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
     K.k_h0 = 105.0 * p->time_span;
     K.gmax_dt = 2.0 * 6.78 * p->sigma / p->time_span;
     K.zmax2_dt = 2.0 * 6.78 / p->time_span;
+    {   // nominal reset constructor on a position sampled from the init box (float32 of lo + span u: within 1e-6 relative
+        // of the box), zero action, f0 = sigma z with |z| <= 6.78: construct_level0's conditions
+        //   |x|, |y| >= k_h0 F      <=  min |coordinate| >= k_h0 sigma Zmax
+        //   u = h1_thresh_m min(scale) >= max(F, Gd)   <=  h1_thresh_m (atol + rtol min|coordinate|) >= max(sigma Zmax, gmax_dt)
+        // hold for every draw or for none that matter; F >= 2e-5 max(scale) is implied by F >= reset_fmin.
+        const double fmax_ = 6.78 * p->sigma;
+        double cmin = INFINITY, cmax = 0.0;
+        for (int j = 0; j < 2; ++j) {
+            const double lo = p->init_low[j], hi = p->init_high[j];
+            const double a = (lo <= 0.0 && hi >= 0.0) ? 0.0 : std::fmin(std::fabs(lo), std::fabs(hi)) * (1.0 - 1e-6);
+            cmin = std::fmin(cmin, a);
+            cmax = std::fmax(cmax, std::fmax(std::fabs(lo), std::fabs(hi)) * (1.0 + 1e-6));
+        }
+        const bool ok = p->sigma > 0.0 && std::isfinite(cmax) && cmin >= K.k_h0 * fmax_ &&
+                        K.h1_thresh_m * (p->atol + p->rtol * cmin) >= std::fmax(fmax_, K.gmax_dt);
+        K.reset_fmin = ok ? 2e-5 * (p->atol + p->rtol * cmax) : -1.0;
+    }
     K.zmax_e6_sigma = kZmaxE6 * p->sigma;
     K.h1_thresh2_f = (float)(K.h1_thresh * K.h1_thresh);
     K.dt2_f = (float)(p->time_span * p->time_span);
