@@ -82,3 +82,20 @@ def test_main_takes_launcher_path_only_without_world_size(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 0 and called["argv"] == ["--gpus", "2", "--steps", "20"]
+
+
+def test_region_schedule_cuts_launch_groups_at_episode_boundaries():
+    """RolloutRegion.schedule(n) = the launch-group lengths run(n) will use (what the timed region primes): groups of at
+    most T steps, cut where an episode (ep steps) ends, starting from the steps already done."""
+    import bench
+    reg = object.__new__(bench.RolloutRegion)
+    reg.T, reg.ep, reg.done_steps = 51, 51, 0
+    assert reg.schedule(20) == [20]
+    assert reg.schedule(51000) == [51] * 1000
+    reg.done_steps = 5                      # the driver's --warmup 5
+    assert reg.schedule(20) == [20]
+    assert reg.schedule(100) == [46, 51, 3]
+    reg.T = 20                              # --rollout-len 20: groups never straddle an episode boundary
+    reg.done_steps = 0
+    assert reg.schedule(60) == [20, 20, 11, 9]
+    assert sum(reg.schedule(12345)) == 12345 and reg.schedule(0) == []
