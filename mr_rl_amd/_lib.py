@@ -74,6 +74,11 @@ def load(path):
         raise ImportError(
             f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` or `make -C mr_rl_amd/csrc`. mr_rl_amd has no CPU fallback.")
+    # One HIP runtime per process.  torch ships its own libamdhip64 / libhsa-runtime64; dlopen'ing libmrsim.so BEFORE torch
+    # maps /opt/rocm's copies instead, torch then maps its own next to them and finds no device (seen on the MI355X box:
+    # build() followed by smoke() in one process).  With torch imported first, libmrsim's NEEDED libamdhip64 resolves to the
+    # copy that is already mapped.  (A C / C++ consumer without torch links /opt/rocm's runtime: examples/abi_demo.cpp.)
+    import torch  # noqa: F401
     L = C.CDLL(path)
     vp, i64, u32, u64, i32 = C.c_void_p, C.c_int64, C.c_uint32, C.c_uint64, C.c_int32
     PP, PS, PIO = C.POINTER(MrsimParams), C.POINTER(MrsimState), C.POINTER(MrsimStepIO)
