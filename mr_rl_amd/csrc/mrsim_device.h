@@ -1227,6 +1227,9 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         if constexpr (NZ == kNoiseFast && MRSIM_FAST_STEP != 0) {
             if (!(fl & kFOutStatePrime)) fast = rk45_fast_step<NZ, MIS>(P, C, R, &W.w[0][0], e);
         }
+#ifdef MRSIM_BUDGET_BUILD  // tools/isa_budget.py only: drop the general path so that the time loop is the common path alone
+        if (!fast) __builtin_trap();
+#endif
         if (__builtin_expect(!fast, 0)) {
             SubStep LS = rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, &W.w[0][0]);  // MR_simulator.py:42-45
             rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy,           // :46-50
@@ -1264,6 +1267,9 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     o.spx = o.spx0 = (float)spx; o.spy = o.spy0 = (float)spy;
     o.px = e.x; o.py = e.y;
     o.has_final = false;
+#ifdef MRSIM_BUDGET_BUILD
+    if (done) __builtin_trap();  // ... and the auto-reset block (cold in the DDPG workload: once per 51 steps)
+#endif
     if (__builtin_expect(done && (fl & kFAutoReset), 0)) {
         // extension: same-step auto-reset; terminal values go to the final_* outputs
         o.has_final = true;
