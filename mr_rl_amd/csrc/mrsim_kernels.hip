@@ -310,7 +310,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
             const f32x2 v = {o.spx0, o.spy0};
             __builtin_nontemporal_store(v, &(reinterpret_cast<f32x2*>(ra.state_prime_T) + row)[tid]);
         }
-        if (fl & kFOutObs) {
+#ifndef MRSIM_AB_NOSTORE
+#define MRSIM_AB_NOSTORE 0
+#endif
+        // experiment only (tools/ab_rollout.py, tools/power_probe.py --lib): MRSIM_AB_NOSTORE = bit mask of transition
+        // stores compiled out (1 obs, 2 rew, 4 done, 8 actions) with the arithmetic kept -- what each output costs at the
+        // package power cap (energy budget)
+        if (MRSIM_AB_NOSTORE != 0)
+            asm volatile("" :: "v"(o.obs[0]), "v"(o.obs[1]), "v"(o.obs[2]), "v"(o.obs[3]), "v"(o.obs[4]), "v"(o.rew), "v"((int)o.done), "v"(af), "v"(aa));
+        if (!(MRSIM_AB_NOSTORE & 1) && (fl & kFOutObs)) {
             if (fl & kFObsAos) {
                 // per-lane running pointer (one 64-bit add per step): `obs_T + (t * stride + blk0) * 5` would be a 64-bit
                 // multiply by 20 on the vector unit every step (two v_mad_u64_u32 + moves)
@@ -323,9 +331,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
                     __builtin_nontemporal_store(o.obs[j], &(ra.obs_T + ((long long)t * 5 + j) * ra.row_stride + blk0)[tid]);
             }
         }
-        if (fl & kFOutRew) __builtin_nontemporal_store(o.rew, &(ra.rew_T + row)[tid]);
-        if (fl & kFOutDone) __builtin_nontemporal_store(o.done, &(ra.done_T + row)[tid]);
-        if (fl & kFOutActions) {
+        if (!(MRSIM_AB_NOSTORE & 2) && (fl & kFOutRew)) __builtin_nontemporal_store(o.rew, &(ra.rew_T + row)[tid]);
+        if (!(MRSIM_AB_NOSTORE & 4) && (fl & kFOutDone)) __builtin_nontemporal_store(o.done, &(ra.done_T + row)[tid]);
+        if (!(MRSIM_AB_NOSTORE & 8) && (fl & kFOutActions)) {
             const f32x2 v = {af, aa};
             __builtin_nontemporal_store(v, &(reinterpret_cast<f32x2*>(ra.actions_out_T) + row)[tid]);
         }
