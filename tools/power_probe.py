@@ -14,6 +14,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="ddpg")
 ap.add_argument("--seconds", type=float, default=2.0)
 ap.add_argument("--obs-layout", default="aos")
+ap.add_argument("--T", type=int, default=51, help="steps per launch group")
+ap.add_argument("--depth", type=int, default=2, help="rotating [T, N, ...] buffer sets")
+ap.add_argument("--envs", type=int, default=262144)
 ap.add_argument("--lib", default=None, help="an A/B build: mr_rl_amd/variants/libmrsim_<tag>.so (make -C mr_rl_amd/csrc variants)")
 a = ap.parse_args()
 mons = [h for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.exists(h + "/power1_input")]
@@ -31,7 +34,7 @@ tab = None
 if a.workload == "mixed":
     import bench
     tab = bench.mixed_goal_table(cfg, 7)
-col = RolloutCollector(262144, cfg=cfg, seed=7, streams=2, goal_table=tab)
+col = RolloutCollector(a.envs, cfg=cfg, seed=7, streams=2, goal_table=tab, T=a.T, depth=a.depth)
 if a.lib:
     from mr_rl_amd import _lib
     col.env._L = _lib.load(os.path.join(ROOT, "mr_rl_amd", "variants", f"libmrsim_{a.lib}.so"))
@@ -65,8 +68,10 @@ idle = [s for s in samples if s[0] < t0 - 0.05]
 j = max(range(len(mons)), key=lambda k: sum(s[1][k] for s in load))
 W = lambda ss: sum(s[1][j] for s in ss) / len(ss) * 1e-6
 F = lambda ss: sum(s[2][j] for s in ss) / len(ss) * 1e-6
-print(f"workload {a.workload}{' [' + a.lib + ']' if a.lib else ''} obs {a.obs_layout}: {n} episodes in {t1 - t0:.3f} s = {(t1 - t0) / n * 1e6:.1f} us per episode "
-      f"({262144 * 51 * n / (t1 - t0) / 1e9:.1f} G env-steps/s)")
+mb = a.depth * a.T * a.envs * 33 / 1e6
+print(f"workload {a.workload}{' [' + a.lib + ']' if a.lib else ''} obs {a.obs_layout}, {a.envs} envs, {a.T} steps per launch group, "
+      f"{a.depth} buffer set(s) = {mb:.0f} MB of transition buffers: {n} groups in {t1 - t0:.3f} s = {(t1 - t0) / n * 1e6:.1f} us per group "
+      f"({a.envs * a.T * n / (t1 - t0) / 1e9:.1f} G env-steps/s)")
 print(f"sensor {mons[j]}: power cap {rd(mons[j] + '/power1_cap') * 1e-6:.0f} W")
 print(f"  before the load : {W(idle):7.1f} W   sclk {F(idle):6.0f} MHz")
 print(f"  under load      : {W(load):7.1f} W   sclk {F(load):6.0f} MHz   (mean of the second half of the load window, "
