@@ -108,6 +108,7 @@ def parse(argv=None):
     ap.add_argument("--sustained-steps", type=int, default=10200, help="length of the `sustained` leg (0 = skip)")
     ap.add_argument("--no-step-path", action="store_true", help="skip the extra one-launch-per-step measurement")
     ap.add_argument("--no-mixed-set", action="store_true", help="skip the extra mixed-trajectory-set measurement")
+    ap.add_argument("--no-power", action="store_true", help="skip the 1.5 s package-power leg (hwmon sysfs)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--master-port", type=int, default=0, help="--gpus N launcher: rendezvous port (0 = pick a free one)")
@@ -419,6 +420,69 @@ def make_region(args, cfg, n_local, env_id0, world, dev, seed, streams, goal_tab
     col.reset()
     g = BlockReturnGatherer(col, world, force_collective=bool(os.environ.get("MRSIM_BENCH_FORCE_DIST")))
     return RolloutRegion(col, g, ep, world, dev, args.dist_backend)
+
+
+def hwmon_of(dev):
+    """hwmon directory of torch device `dev`, matched by PCI address (the host shows the sensors of all its GPUs)"""
+    import glob
+    import torch
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        return None
+    for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+        if os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))) == bdf and os.path.exists(h + "/power1_input"):
+            return h
+    return None
+
+
+def measure_power(reg, dev, total, seconds=1.5):
+    """Package power (hwmon power1_input = PPT, against power1_cap) and the driver's shader-clock reading while the headline
+    workload runs for `seconds` on its collector: the rollout kernel runs at the package power limit, which is what sets
+    its clock (tools/power_probe.py is the stand-alone form).  The sensor averages over a few hundred
+    milliseconds, hence a leg of its own; the mean of the second half of the window is reported.  None if the sensors
+    are not readable."""
+    import threading
+    import torch
+    h = hwmon_of(dev)
+    if h is None:
+        return None
+
+    def rd(name):
+        try:
+            return int(open(os.path.join(h, name)).read())
+        except (OSError, ValueError):
+            return None
+    if rd("power1_input") is None:
+        return None
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            samples.append((time.perf_counter(), rd("power1_input"), rd("freq1_input")))
+            time.sleep(0.02)
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds:
+        reg.run(400 * reg.ep)
+        torch.cuda.synchronize(dev)
+        steps += 400 * reg.ep
+    t1 = time.perf_counter()
+    stop[0] = True
+    th.join()
+    load = [x for x in samples if t0 + 0.5 * (t1 - t0) < x[0] < t1 and x[1] is not None]
+    if not load:
+        return None
+    cap = rd("power1_cap")
+    clk = [x[2] for x in load if x[2] is not None]
+    return {"package_W": round(sum(x[1] for x in load) / len(load) * 1e-6, 1), "cap_W": round(cap * 1e-6, 1) if cap else None,
+            "sclk_MHz_driver_reading": round(sum(clk) / len(clk) * 1e-6) if clk else None,
+            "window_s": round(t1 - t0, 3), "samples": len(load), "value_in_window": total * steps / (t1 - t0),
+            "what": "hwmon power1_input (PPT) of this GPU, mean of the second half of a window in which the headline "
+                    "workload runs back to back; at the cap the kernel's clock is what the power limit leaves"}
 
 
 def measure_mixed_set(args, n_local, env_id0, world, dev, seed, streams, steps=10200):
@@ -745,6 +809,11 @@ def main():
             step_path = measure_step_path(cfg, n_local, dev, seed)
         trace("step path done")
 
+    power = None
+    if rank == 0 and world == 1 and args.mode == "rollout" and not args.no_power and not pmc:
+        power = measure_power(reg, dev, total)
+        trace("power leg done")
+
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -780,6 +849,8 @@ def main():
             out["step_path"] = step_path
         if mixed is not None:
             out["mixed_trajectory_set"] = mixed
+        if power is not None:
+            out["power"] = power
         if pmc:
             out["note"] = "run under rocprofv3 counter collection: kernels are serialised, timings are not representative"
         sys.stdout.flush()

@@ -18,10 +18,10 @@ pass() {  # pass <name> <cmd...>: run, record the exit code
   "$@" > $O/$name.out 2> $O/$name.log
   echo "$name $?" >> $O/status.txt
 }
-PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
-pass kt rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline
-pass kt_s1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1 -- python3 $R/bench.py --no-cpu-baseline --streams 1 --no-step-path --no-mixed-set
-pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --mode step
+PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
+pass kt rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-power
+pass kt_s1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1 -- python3 $R/bench.py --no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set
+pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --no-power --mode step
 for c in FETCH_SIZE WRITE_SIZE; do
   for carry in f64 f32; do
     pass pmc_${carry}_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_${carry}_$c -- python3 $R/bench.py $PMCARGS --carry $carry
