@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRSIM_ABI_VERSION 2
+#define MRSIM_ABI_VERSION 3
 
 enum {
     MRSIM_OK = 0,
@@ -96,6 +96,62 @@ typedef struct MrsimState {
     float* ep_ret;
 } MrsimState;
 
+/* ---------------------------------------------------------------------------------------------------------
+ * The DDPG actor as an on-device policy source (ABI 3) -- RL/MR_ddpg.py:80-160 ActorNetwork, :59-78 OUNoise.
+ *
+ * The consumer of this path is the collection loop of RL/MR_ddpg.py:270-311:
+ *     action = actor.predict(state) + actor_noise();  next_state, reward, done, _ = env.step(action)
+ * With the actor in host Python between two kernel launches that loop runs two orders of magnitude below the env
+ * kernels, so the policy is a policy SOURCE of the kernels: mrsim_step / mrsim_rollout evaluate the network on the
+ * observation they hold in registers (MrsimStepIO.actor / MrsimRolloutIO.actor), and mrsim_actor_forward is the same
+ * arithmetic as a kernel of its own (the gym-loop form: obs[n][5] -> actions[n][2]).  All three produce equal bits.
+ *
+ * Network (create_actor_network, :120-137): 5 -> fully_connected 64 -> batch_normalization -> relu -> fully_connected 64
+ * -> batch_normalization -> relu -> fully_connected 2 (tanh), scaled_out = out * action_bound.  predict() runs the
+ * batch normalisation on its moving statistics (inference mode), a per-feature affine map: fold it into the preceding
+ * layer with mrsim_actor_fold_bn_host, then pack the six arrays with mrsim_actor_pack_host into the parameter block the
+ * kernels read (layout private to the library: weights pre-permuted for the f32 MFMA operand maps).  The two 64-wide
+ * layers run on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32: bit-for-bit an fmaf chain in the documented order),
+ * the output layer and tanh (specified fp32 arithmetic) on the vector unit.
+ *
+ * Exploration noise (OUNoise.__call__, :69-73, mu = 0): x += -theta x dt + sigma sqrt(dt) N(0,1) per action component,
+ * one process per env, state in ou_state[n][2]; its two normals are words 0,1 of RNG call DYN(0,0) of the step -- the
+ * words the uniform exploration policy would use (mrsim_random_policy): the two policy sources are alternatives.
+ * --------------------------------------------------------------------------------------------------------- */
+#define MRSIM_ACTOR_HIDDEN 64
+#define MRSIM_ACTOR_BLOB_FLOATS 4744   /* size of the packed parameter block */
+
+typedef struct MrsimActorWeights {   /* HOST pointers, row-major float32: the network in inference form */
+    const float* w1;        /* [64][5]   first fully_connected (+ folded batch norm)   RL/MR_ddpg.py:122-123 */
+    const float* b1;        /* [64]                                                                          */
+    const float* w2;        /* [64][64]  second fully_connected (+ folded batch norm)  :125-126              */
+    const float* b2;        /* [64]                                                                          */
+    const float* w3;        /* [2][64]   output layer, tanh                            :130-134              */
+    const float* b3;        /* [2]                                                                           */
+    float obs_scale[5];     /* input scaling folded into w1 (1 = the reference: raw observations)            */
+    float action_bound[2];  /* scaled_out = tanh(.) * action_bound   :136-137, :345 (env.action_space.high)  */
+} MrsimActorWeights;
+
+/* y = gamma (W x + b - mean) / sqrt(var + eps) + beta  ==  W' x + b'  (tflearn batch_normalization at inference;
+ * w [rows][cols], everything else [rows]).  Host arithmetic in double, rounded once.  No device needed. */
+int mrsim_actor_fold_bn_host(int32_t rows, int32_t cols, const float* w, const float* b, const float* gamma,
+                             const float* beta, const float* mean, const float* var, float eps, float* w_out,
+                             float* b_out);
+/* Pack the inference-form network into blob_host[MRSIM_ACTOR_BLOB_FLOATS]; copy that block to device memory
+ * (16-byte aligned) and pass it as MrsimActor.blob.  No device needed. */
+int mrsim_actor_pack_host(const MrsimActorWeights* w, float* blob_host);
+
+typedef struct MrsimActor {
+    const float* blob;        /* DEVICE: packed parameters; NULL = no actor                                   */
+    float* ou_state;          /* DEVICE [n][2] OUNoise.x_prev per env, updated in place; NULL = no exploration */
+                              /*   noise (actor.predict alone)                                                */
+    float ou_theta;           /* 0.15   OUNoise defaults, RL/MR_ddpg.py:60                                    */
+    float ou_sigma;           /* 0.3                                                                          */
+    float ou_dt;              /* 1e-2                                                                         */
+    int32_t ou_reset_on_done; /* 0 = the reference (the process is never reset, :270-311); 1 = x_prev := 0 at  */
+                              /*   the first step of every episode (MR_Env.counter == 0)                      */
+} MrsimActor;
+
 /* Inputs / outputs of one step.  Optional pointers may be NULL. */
 typedef struct MrsimStepIO {
     const float* actions;    /* [n][2] {f_t, alpha_t}  (MR_env.py:81-82).  NULL: draw the     */
@@ -111,6 +167,9 @@ typedef struct MrsimStepIO {
     int32_t* final_len;      /* optional [n]: episode length where done                       */
     int32_t* status;         /* optional [1]: OR-ed per-env flags; bit0 = RK45 attempt guard  */
                              /*   tripped (the reference would raise "failed solver")         */
+    const MrsimActor* actor; /* optional (HOST pointer; ABI 3): the policy source is the      */
+                             /*   in-kernel actor on the env's current observation; actions   */
+                             /*   must then be NULL and the integrator RK45                   */
 } MrsimStepIO;
 
 int mrsim_abi_version(void);
@@ -179,6 +238,11 @@ typedef struct MrsimRolloutIO {
                              /*   (closer to the reference, which carries fp64; not bit-identical to steps).   */
     int32_t actions_f64;     /* non-zero: `actions` holds fp64 values ([T][2] or [T][n][2] doubles) -- the     */
                              /*   reference's action tables (main.py:14-50) are float64 linspace tables        */
+    const MrsimActor* actor; /* optional (HOST pointer; ABI 3): every step's action is actor.predict(obs) +    */
+                             /*   actor_noise() evaluated in-kernel on the observation of the previous step:   */
+                             /*   the collection loop of RL/MR_ddpg.py:270-311 in one launch.  actions must be */
+                             /*   NULL and the integrator RK45.  Bit-identical to T x (mrsim_actor_forward ->  */
+                             /*   mrsim_step) with carry_f64 = 0.                                              */
 } MrsimRolloutIO;
 
 /* Fused open-loop rollout, the batched utils.run_sim (utils.py:43-61) and the DDPG rollout workload:
@@ -207,6 +271,14 @@ int mrsim_rollout_events(const MrsimParams* p, int64_t n, uint32_t env_id0, cons
 int mrsim_step_events(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
                       const MrsimStepIO* io, uint64_t seed, uint64_t step_idx, void* stream,
                       void* start_event, void* stop_event);
+
+/* actions[n][2] = actor.predict(obs) + actor_noise() (RL/MR_ddpg.py:277) as a kernel of its own -- the gym-loop form:
+ * feed `actions` to mrsim_step with the SAME (seed, step_idx).  obs: [n][5] or [5][n] per p->obs_layout (what
+ * mrsim_reset / mrsim_step wrote).  st: the env state, read only when actor->ou_reset_on_done (MR_Env.counter); may be
+ * NULL otherwise. */
+int mrsim_actor_forward(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimActor* actor,
+                        const MrsimState* st, const float* obs, float* actions, uint64_t seed, uint64_t step_idx,
+                        void* stream);
 
 /* Velocity post-processing that every consumer of run_sim applies to the recorded positions
  * (Learning_module.py:46-59,72-93; main.py:102-109):

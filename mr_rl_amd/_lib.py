@@ -11,7 +11,8 @@ INT_RK45, INT_EULER, INT_RK4 = 0, 1, 2
 REW_CONSTANT10, REW_GOAL = 0, 1
 OBS_AOS, OBS_SOA = 0, 1
 NOISE_FAST, NOISE_SPEC = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
+ACTOR_HIDDEN, ACTOR_BLOB_FLOATS = 64, 4744
 
 # every symbol include/mrsim.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
@@ -19,6 +20,7 @@ SYMBOLS = (
     "mrsim_step_timed", "mrsim_random_policy", "mrsim_random_policy_steps", "mrsim_rollout", "mrsim_rollout_timed", "mrsim_advance_step_base", "mrsim_velocity", "mrsim_debug_normals",
     "mrsim_device_count", "mrsim_device_name",
     "mrsim_event_create", "mrsim_event_destroy", "mrsim_event_elapsed_ms", "mrsim_rollout_events", "mrsim_step_events",
+    "mrsim_actor_fold_bn_host", "mrsim_actor_pack_host", "mrsim_actor_forward",
 )
 
 
@@ -40,12 +42,22 @@ class MrsimState(C.Structure):
     _fields_ = [("pos", C.c_void_p), ("aux", C.c_void_p), ("ep_ret", C.c_void_p)]
 
 
+class MrsimActorWeights(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p),
+                ("b3", C.c_void_p), ("obs_scale", C.c_float * 5), ("action_bound", C.c_float * 2)]
+
+
+class MrsimActor(C.Structure):
+    _fields_ = [("blob", C.c_void_p), ("ou_state", C.c_void_p), ("ou_theta", C.c_float), ("ou_sigma", C.c_float),
+                ("ou_dt", C.c_float), ("ou_reset_on_done", C.c_int32)]
+
+
 class MrsimStepIO(C.Structure):
     _fields_ = [
         ("actions", C.c_void_p), ("actions_out", C.c_void_p), ("goal_table", C.c_void_p),
         ("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("state_prime", C.c_void_p),
         ("final_obs", C.c_void_p), ("final_ret", C.c_void_p), ("final_len", C.c_void_p),
-        ("status", C.c_void_p),
+        ("status", C.c_void_p), ("actor", C.POINTER(MrsimActor)),
     ]
 
 
@@ -56,6 +68,7 @@ class MrsimRolloutIO(C.Structure):
         ("done_T", C.c_void_p), ("actions_out_T", C.c_void_p), ("final_ret", C.c_void_p),
         ("final_len", C.c_void_p), ("status", C.c_void_p),
         ("row_stride", C.c_int64), ("carry_f64", C.c_int32), ("actions_f64", C.c_int32),
+        ("actor", C.POINTER(MrsimActor)),
     ]
 
 
@@ -101,6 +114,9 @@ def load(path):
     L.mrsim_rollout_events.argtypes = L.mrsim_rollout.argtypes + [vp, vp]
     L.mrsim_step_events.argtypes = L.mrsim_step.argtypes + [vp, vp]
     L.mrsim_debug_normals.argtypes = [i64, u32, u64, u64, u32, i32, vp, vp]
+    L.mrsim_actor_fold_bn_host.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]
+    L.mrsim_actor_pack_host.argtypes = [C.POINTER(MrsimActorWeights), vp]
+    L.mrsim_actor_forward.argtypes = [PP, i64, u32, C.POINTER(MrsimActor), PS, vp, vp, u64, u64, vp]
     L.mrsim_device_count.restype = C.c_int
     L.mrsim_device_name.argtypes = [C.c_int, C.c_char_p, i32]
     for name in SYMBOLS:
@@ -109,7 +125,8 @@ def load(path):
     if L.mrsim_abi_version() != ABI_VERSION:
         raise ImportError(f"{path}: ABI {L.mrsim_abi_version()} != binding ABI {ABI_VERSION}")
     assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 10 + 8
-    assert C.sizeof(MrsimRolloutIO) == 8 + 8 * 11 + 8 + 4 + 4
+    assert C.sizeof(MrsimRolloutIO) == 8 + 8 * 11 + 8 + 4 + 4 + 8
+    assert C.sizeof(MrsimActor) == 32 and C.sizeof(MrsimActorWeights) == 48 + 28 + 4
     return L
 
 

@@ -31,7 +31,7 @@ class RolloutCollector:
     WANT = ("obs", "rew", "done", "actions")
 
     def __init__(self, num_envs, cfg=None, device="cuda", seed=None, env_id0=0, goal_table=None, streams=2, T=None,
-                 want=WANT, carry="f64", depth=2, returns_interval=1):
+                 want=WANT, carry="f64", depth=2, returns_interval=1, policy=None):
         import torch
         self.env = MRVecEnv(num_envs, cfg=cfg if cfg is not None else MRConfig(auto_reset=True), device=device, seed=seed,
                             env_id0=env_id0, goal_table=goal_table)
@@ -40,6 +40,7 @@ class RolloutCollector:
         self.T = int(T) if T is not None else env.cfg.max_timesteps + 1   # one episode per launch by default
         self.E = max(1, int(returns_interval))
         self.want = tuple(want)
+        self.policy = policy   # None: the uniform exploration policy drawn in-kernel; a DeviceActor: actor + OU noise in-kernel
         dev = env.device
         self.shards = [(a, n) for a, n in all_shards(self.N, self.S) if n > 0]
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.shards]
@@ -113,7 +114,7 @@ class RolloutCollector:
                 T, first, n, traj=bufs.get("traj"), sp_T=bufs.get("state_prime"), obs_T=bufs.get("obs"),
                 rew_T=bufs.get("rew"), done_T=bufs.get("done"), acts_T=bufs.get("actions"),
                 final_ret=self.ret_blocks[blk][row], final_len=self.len_blocks[blk][row], carry=self.carry,
-                stream=self.streams[s], prepare_only=True)
+                stream=self.streams[s], prepare_only=True, actor=self.policy)
         return launch
 
     def prime(self, schedule):

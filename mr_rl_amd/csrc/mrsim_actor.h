@@ -1,0 +1,189 @@
+// mrsim_actor.h -- the DDPG actor as an in-kernel policy source for gfx950 (MI355X, wave64).
+//
+// What is restated here (reference citations are /root/reference/<file>:<line>):
+//   ActorNetwork.create_actor_network   RL/MR_ddpg.py:120-137   5 -> FC64 -> BN -> ReLU -> FC64 -> BN -> ReLU -> FC2,
+//                                                               tanh, * action_bound
+//   ActorNetwork.predict                RL/MR_ddpg.py:145-148   inference: tflearn's batch_normalization runs on its
+//                                                               moving statistics (the script never switches tflearn's
+//                                                               training mode on), i.e. a per-feature affine map that
+//                                                               the host folds into the preceding linear layer
+//   OUNoise.__call__                    RL/MR_ddpg.py:69-73     x += theta (mu - x) dt + sigma sqrt(dt) N(0,1), mu = 0
+//   the loop's use of both              RL/MR_ddpg.py:277       action = actor.predict(state) + actor_noise()
+//
+// Mapping onto the hardware.  One wave = 64 environments (one per lane for the env step).  The two 64-wide layers are the
+// only dense contraction anywhere near this path and go to the matrix cores as f32-input MFMA (v_mfma_f32_32x32x2_f32:
+// exact f32 products, f32 accumulate, bit-for-bit a k-ordered fmaf chain), features on the M rows, environments on the N
+// columns: H[f][env] = sum_k W[f][k] X[k][env].  A wave's 64 envs are two column tiles (ct), the 64 features two row
+// tiles (rt).  The 32x32 result layout puts the COLUMN (env) on the lane and 16 ROWS (features) in the lane's registers --
+// exactly what the next layer's B operand wants (it sums over the feature index), so activations never leave the
+// registers between layers: at k-step s lane half h supplies the feature it holds in register s, and the weights are
+// stored pre-permuted to match (kperm below).  Only the 5-wide input and the 2-wide output cross lanes, with
+// v_permlane32_swap.  The 64 -> 2 output layer is 2 x 32 fmas per lane on the vector unit (an MFMA tile would be 94 % padding).
+//
+// Summation order (part of the definition; oracle/mrsim_oracle.c: orc_actor_forward follows it, so the two agree bitwise):
+//   kperm(q, h) = 32 (q / 16) + 8 ((q % 16) / 4) + 4 h + (q % 4),   q = 0..31, h = 0..1
+//   layer 1:  acc = b1[f];  for k = 0..4:              acc = fmaf(W1[f][k], x[k], acc)        (k = 5 is a zero pad)
+//   layer 2:  acc = b2[f];  for q = 0..31, h = 0..1:   acc = fmaf(W2[f][kperm(q,h)], relu(h1[kperm(q,h)]), acc)
+//   layer 3:  p_h = 0;      for q = 0..31:             p_h = fmaf(W3[o][kperm(q,h)], relu(h2[kperm(q,h)]), p_h)
+//             pre = (p_0 + p_1) + b3[o];   out[o] = tanh_spec(pre) * bound[o]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrsim {
+
+constexpr int kActHidden = 64;
+// packed parameter block (float offsets); the kernels copy it to LDS once per block
+constexpr int kActA1 = 0;                    // [rt 2][s 3][lane 64]      layer-1 A operands
+constexpr int kActA2 = kActA1 + 2 * 3 * 64;  // [rt 2][s4 8][lane 64][4]  layer-2 A operands, four k-steps per ds_read_b128
+constexpr int kActC1 = kActA2 + 64 * 64;     // [h 2][q 32]               b1 in accumulator layout
+constexpr int kActC2 = kActC1 + 64;          // [h 2][q 32]               b2 in accumulator layout
+constexpr int kActW3 = kActC2 + 64;          // [h 2][o 2][q 32]          output layer, per lane half
+constexpr int kActTail = kActW3 + 128;       // b3[2], bound[2]
+constexpr int kActBlobFloats = kActTail + 8; // padded to a multiple of 4 floats (copied as float4)
+static_assert(kActBlobFloats % 4 == 0, "blob is copied as float4");
+
+__host__ __device__ constexpr int act_kperm(int q, int h) { return 32 * (q / 16) + 8 * ((q % 16) / 4) + 4 * h + (q % 4); }
+
+typedef float act_f32x16 __attribute__((ext_vector_type(16)));
+typedef float act_f32x4 __attribute__((ext_vector_type(4)));
+
+// copy the parameter block HBM -> LDS (all threads of the block; caller synchronises)
+__device__ __forceinline__ void actor_stage_blob(const float* __restrict__ blob, float* __restrict__ s_blob, unsigned tid,
+                                                 unsigned nthreads) {
+    const act_f32x4* __restrict__ src = reinterpret_cast<const act_f32x4*>(blob);
+    act_f32x4* __restrict__ dst = reinterpret_cast<act_f32x4*>(s_blob);
+    for (unsigned k = tid; k < (unsigned)(kActBlobFloats / 4); k += nthreads) dst[k] = src[k];
+}
+
+// exp(x) for x in [-20, 20]: Cephes expf (Cody-Waite reduction by ln 2, degree-5 polynomial), explicit fmaf, exact ldexp.
+// The oracle has the same operations in the same order.
+__device__ __forceinline__ float spec_expf(float x) {
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
+    const float z = r * r;
+    const float e = __builtin_fmaf(p, z, r) + 1.0f;
+    return __builtin_ldexpf(e, (int)n);
+}
+
+// tanh in specified fp32 arithmetic (Cephes tanhf): odd polynomial below 0.625, 1 - 2 / (exp(2|x|) + 1) above,
+// +-1 from 9.0 on.  The division is IEEE (hipcc's default for `/` on float): same bits as the oracle's.
+__device__ __forceinline__ float spec_tanhf(float x) {
+    const float ax = __builtin_fabsf(x);
+    float r;
+    if (ax >= 9.0f) {
+        r = 1.0f;
+    } else if (ax >= 0.625f) {
+        const float e = spec_expf(ax + ax);
+        r = 1.0f - 2.0f / (e + 1.0f);
+    } else {
+        const float z = x * x;
+        float p = -5.70498872745E-3f;
+        p = __builtin_fmaf(p, z, 2.06390887954E-2f);
+        p = __builtin_fmaf(p, z, -5.37397155531E-2f);
+        p = __builtin_fmaf(p, z, 1.33314422036E-1f);
+        p = __builtin_fmaf(p, z, -3.33332819422E-1f);
+        return __builtin_fmaf(p * z, x, x);
+    }
+    return x < 0.0f ? -r : r;
+}
+
+__device__ __forceinline__ void lds_load16(const float* __restrict__ p, act_f32x16& v) {
+    const act_f32x4* __restrict__ q = reinterpret_cast<const act_f32x4*>(p);
+    const act_f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+    v = act_f32x16{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
+}
+
+// actor.predict for the 64 envs of this wave.  obs: this lane's env's observation (already scaled if the caller scales);
+// a[2]: scaled_out of this lane's env.  Must be called by ALL 64 lanes in uniform control flow (MFMA and
+// v_permlane32_swap are wave-wide operations); lanes without an env pass any finite values.
+__device__ __forceinline__ void actor_forward(const float* __restrict__ sA, const float (&obs)[5], float (&a)[2]) {
+    // layer-1 B operands: at k-step s lane (j, h) of column tile ct supplies obs[2 s + h] of env 32 ct + j.  One half swap
+    // per k-step pair turns "lane = env" registers into both tiles' operands: {x[2s].lo | x[2s+1].lo}, {x[2s].hi | x[2s+1].hi}.
+    float b1op[2][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const float va = obs[2 * s];
+        const float vb = (2 * s + 1 < 5) ? obs[2 * s + 1] : 0.0f;
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+        b1op[0][s] = __uint_as_float(r[0]);
+        b1op[1][s] = __uint_as_float(r[1]);
+    }
+    // The two column tiles one after the other, as a real loop: unrolled, the scheduler interleaves them and keeps all
+    // eight 16-register accumulators live (313 registers, one wave per SIMD); rolled, a tile needs four of them.
+    float part[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma nounroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const float bop[3] = {ct ? b1op[1][0] : b1op[0][0], ct ? b1op[1][1] : b1op[0][1], ct ? b1op[1][2] : b1op[0][2]};
+        // Every LDS address below derives from a lane id that is opaque per iteration.  Otherwise the parameter reads -- the
+        // same for both tiles and for every time step of a fused rollout -- are hoisted out of all loops and 260 registers
+        // of weights and bias tiles stay live across the env step (measured: 313 registers, one wave per SIMD, or spills).
+        unsigned lane = threadIdx.x & 63u;
+        asm volatile("" : "+v"(lane));
+        const unsigned h = lane >> 5;
+        act_f32x16 acc1[2], acc2[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            lds_load16(sA + kActC1 + h * 32 + rt * 16, acc1[rt]);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[kActA1 + (rt * 3 + s) * 64 + lane], bop[s], acc1[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) lds_load16(sA + kActC2 + h * 32 + rt * 16, acc2[rt]);
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const act_f32x4 a4 = *reinterpret_cast<const act_f32x4*>(sA + kActA2 + ((rt * 8 + s4) * 64 + lane) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = 4 * s4 + j;
+                    const float b = __builtin_fmaxf(acc1[q / 16][q % 16], 0.0f);  // ReLU of layer 1, in place
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b, acc2[rt], 0, 0, 0);
+                }
+            }
+        }
+        // output layer on the vector unit: this lane's 32 features of env (32 ct + j), two partial sums per output
+        float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+        for (int q4 = 0; q4 < 8; ++q4) {
+            const act_f32x4 w0 = *reinterpret_cast<const act_f32x4*>(sA + kActW3 + (h * 2 + 0) * 32 + q4 * 4);
+            const act_f32x4 w1 = *reinterpret_cast<const act_f32x4*>(sA + kActW3 + (h * 2 + 1) * 32 + q4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = 4 * q4 + j;
+                const float hq = __builtin_fmaxf(acc2[q / 16][q % 16], 0.0f);
+                p0 = __builtin_fmaf(w0[j], hq, p0);
+                p1 = __builtin_fmaf(w1[j], hq, p1);
+            }
+        }
+        if (ct == 0) { part[0][0] = p0; part[0][1] = p1; }
+        else { part[1][0] = p0; part[1][1] = p1; }
+    }
+    // lane (j, h) holds half h's partial sums of env j (ct 0) and env 32 + j (ct 1): one half swap per output puts
+    // {half 0's | half 1's} partial of env = lane into the two result registers
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0][o]), __float_as_uint(part[1][o]), false, false);
+        const float pre = (__uint_as_float(r[0]) + __uint_as_float(r[1])) + sA[kActTail + o];
+        a[o] = spec_tanhf(pre) * sA[kActTail + 2 + o];
+    }
+}
+
+// OUNoise.__call__ (RL/MR_ddpg.py:69-73) with mu = 0, in fp32:  x <- fma(sigma sqrt(dt), z, fma(-theta dt, x, x))
+struct OUParams {
+    float theta_dt, sigma_sqrt_dt;
+};
+__device__ __forceinline__ float ou_update(const OUParams& ou, float x, float z) {
+    return __builtin_fmaf(ou.sigma_sqrt_dt, z, __builtin_fmaf(-ou.theta_dt, x, x));
+}
+
+}  // namespace mrsim

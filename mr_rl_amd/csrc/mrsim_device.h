@@ -82,6 +82,9 @@ enum : uint32_t {
     kFOutTraj = 1u << 8, kFOutStatePrime = 1u << 9, kFOutObs = 1u << 10, kFOutRew = 1u << 11,
     kFOutDone = 1u << 12, kFOutActions = 1u << 13, kFOutFinalRet = 1u << 14, kFOutFinalLen = 1u << 15,
     kFOutFinalObs = 1u << 16, kFOutStatus = 1u << 17, kFRk4 = 1u << 18, kFCarry64 = 1u << 19, kFActions64 = 1u << 20,
+    // policy source = the in-kernel DDPG actor (mrsim_actor.h); + Ornstein-Uhlenbeck exploration noise; + OU state zeroed at
+    // the first step of every episode (the reference never resets the process, RL/MR_ddpg.py:270-311)
+    kFActor = 1u << 21, kFActorOU = 1u << 22, kFOUReset = 1u << 23,
 };
 __device__ __forceinline__ uint32_t live_flags(uint32_t f) {
     asm volatile("" : "+s"(f));
@@ -1186,9 +1189,11 @@ struct StepWords {
     uint32_t w[N][4];
 };
 
+// policy_words: slot 0's first two words are wanted even when no noise block is drawn (random policy, or the actor's
+// Ornstein-Uhlenbeck pair -- the exploration noise takes the place of the exploration policy's uniforms)
 template <bool RK45, int NZ, bool MIS>
 __device__ __forceinline__ void step_prologue(const KParams& P, const Rng& R, bool random_policy,
-                                              StepWords<RK45, NZ, MIS>& W, float& af, float& aa) {
+                                              StepWords<RK45, NZ, MIS>& W, float& af, float& aa, bool policy_words = false) {
     using SW = StepWords<RK45, NZ, MIS>;
     if constexpr (SW::NDYN > 0) {
         uint32_t c0s[SW::N];
@@ -1197,7 +1202,7 @@ __device__ __forceinline__ void step_prologue(const KParams& P, const Rng& R, bo
         philox_multi<SW::N>(R, c0s, W.w);
     } else {
         W.w[0][0] = W.w[0][1] = W.w[0][2] = W.w[0][3] = 0u;
-        if (random_policy) philox_call(R, policy_c0(RK45), W.w[0]);
+        if (random_policy || policy_words) philox_call(R, policy_c0(RK45), W.w[0]);
     }
     if (random_policy) action_from_words(P, W.w[0], af, aa);
 }

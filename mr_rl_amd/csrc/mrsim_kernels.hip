@@ -18,8 +18,47 @@
 
 #include "mrsim.h"
 #include "mrsim_device.h"
+#include "mrsim_actor.h"
 
 namespace mrsim {
+
+// the in-kernel policy source (include/mrsim.h: MrsimActor), as the kernels see it
+struct ActorArgs {
+    const float* blob;  // packed parameters, kActBlobFloats floats (mrsim_actor_pack_host)
+    float* ou_state;    // [n][2] Ornstein-Uhlenbeck state, or null: actor.predict without exploration noise
+    OUParams ou;
+};
+
+// Box-Muller flavour of the OU pair: the launch's own (fast / spec); sigma = 0 launches carry no noise code: spec
+template <int NZ>
+constexpr int ou_nz() { return NZ == kNoiseFast ? kNoiseFast : kNoiseSpec; }
+
+// current observation of an env from its state: what the last step / reset returned (same expressions: equal bits)
+__device__ __forceinline__ void obs_from_state(const KParams& P, uint32_t fl, const float* __restrict__ goal_table,
+                                               uint32_t env, const EnvRegs& e, float (&obs)[5]) {
+    double gx, gy;
+    goal_at(P, fl, goal_table, env, e.counter, gx, gy);
+    const double dx = gx - e.x, dy = gy - e.y;
+    pack_obs(e.x, e.y, gx, gy, __builtin_fma(dx, dx, dy * dy), obs);
+}
+
+// action = actor.predict(obs) + actor_noise()  (RL/MR_ddpg.py:277) for this lane's env; all 64 lanes call it
+template <int OUNZ>
+__device__ __forceinline__ void actor_policy(const KParams& P, uint32_t fl, const ActorArgs& ac, const float* __restrict__ s_actor,
+                                             const float (&obs)[5], int32_t counter, const uint32_t* w, float& ou0, float& ou1,
+                                             float& af, float& aa) {
+    float a[2];
+    actor_forward(s_actor, obs, a);
+    af = a[0]; aa = a[1];
+    if (fl & kFActorOU) {
+        if ((fl & kFOUReset) && counter == 0) ou0 = ou1 = 0.0f;
+        float z0, z1;
+        box_muller<OUNZ>(w[0], w[1], z0, z1);
+        ou0 = ou_update(ac.ou, ou0, z0);
+        ou1 = ou_update(ac.ou, ou1, z1);
+        af += ou0; aa += ou1;
+    }
+}
 
 struct StateArgs {
     double* pos;
@@ -45,49 +84,72 @@ struct IOArgs {
 // step
 // ---------------------------------------------------------------------------
 // FL != 0: flags word known at compile time (see mr_rollout_kernel); kFStepBase is not part of it (step_words reads it
-// from P).
-template <bool RK45, int NZ, bool MIS, bool AOS, uint32_t FL = 0>
-__global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const StateArgs st, const IOArgs io) {
+// from P).  ACT: the action comes from the in-kernel actor (+ OU noise) evaluated on the env's current observation;
+// every lane of a wave then runs the whole body (MFMA and the half swaps are wave-wide), lanes past n on a copy of
+// the last env, and only the stores are predicated.
+template <bool RK45, int NZ, bool MIS, bool AOS, uint32_t FL = 0, bool ACT = false>
+__global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const StateArgs st, const IOArgs io, const ActorArgs ac) {
     __shared__ __attribute__((aligned(16))) float s_obs[AOS ? kBlock * 5 : 4];
+    __shared__ __attribute__((aligned(16))) float s_actor[ACT ? kActBlobFloats : 4];
+    if constexpr (ACT) {
+        actor_stage_blob(ac.blob, s_actor, threadIdx.x, kBlock);
+        __syncthreads();
+    }
     const long long base = (long long)blockIdx.x * kBlock;
     const long long i = base + threadIdx.x;
     const bool active = i < P.n;
+    const long long il = (ACT && !active) ? P.n - 1 : i;
     StepOut o;
     const uint32_t fl = FL != 0 ? FL : P.flags;
-    if (active) {
+    if (active || ACT) {
         EnvRegs e;
-        load_env(st.pos, st.aux, st.ep_ret, i, P, e);
-        const Rng R = make_rng(P, i);
+        load_env(st.pos, st.aux, st.ep_ret, il, P, e);
+        const Rng R = make_rng(P, il);
         float af = 0.f, aa = 0.f;
         StepWords<RK45, NZ, MIS> W;
         if (fl & kFActions) {
-            const float2 a = reinterpret_cast<const float2*>(io.actions)[i];
+            const float2 a = reinterpret_cast<const float2*>(io.actions)[il];
             af = a.x; aa = a.y;
         }
-        step_prologue<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa);
+        step_prologue<RK45, NZ, MIS>(P, R, !ACT && !(fl & kFActions), W, af, aa, ACT && (fl & kFActorOU));
+        float ou0 = 0.f, ou1 = 0.f;
+        if constexpr (ACT) {
+            float obs_cur[5];
+            obs_from_state(P, fl, io.goal_table, R.env, e, obs_cur);
+            if (fl & kFActorOU) {
+                const float2 u = reinterpret_cast<const float2*>(ac.ou_state)[il];
+                ou0 = u.x; ou1 = u.y;
+            }
+            actor_policy<ou_nz<NZ>()>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
+        }
         int fail = 0;
         env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, (double)af, (double)aa, W, fl, o, fail,
                                 MRSIM_ROLLOUT_TABLE ? kSinCosTab : nullptr);  // same arithmetic as the rollout: equal bits
-        store_env(st.pos, st.aux, st.ep_ret, i, P, e);
-        io.rew[i] = o.rew;
-        io.done[i] = o.done;
-        if (fl & kFOutActions) reinterpret_cast<float2*>(io.actions_out)[i] = make_float2(af, aa);
-        if (fl & kFOutStatePrime) reinterpret_cast<float2*>(io.state_prime)[i] = make_float2(o.spx, o.spy);
-        if (o.has_final) {
-            if (fl & kFOutFinalObs) {
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    if constexpr (AOS) io.final_obs[i * 5 + j] = o.fobs[j];
-                    else io.final_obs[(long long)j * P.n + i] = o.fobs[j];
-                }
+        if (active) {
+            store_env(st.pos, st.aux, st.ep_ret, i, P, e);
+            if constexpr (ACT) {
+                if (fl & kFActorOU) reinterpret_cast<float2*>(ac.ou_state)[i] = make_float2(ou0, ou1);
             }
-            if (fl & kFOutFinalRet) io.final_ret[i] = o.fret;
-            if (fl & kFOutFinalLen) io.final_len[i] = o.flen;
-        }
-        if (fail && (fl & kFOutStatus)) atomicOr(io.status, fail);
-        if constexpr (!AOS) {
+            io.rew[i] = o.rew;
+            io.done[i] = o.done;
+            if (fl & kFOutActions) reinterpret_cast<float2*>(io.actions_out)[i] = make_float2(af, aa);
+            if (fl & kFOutStatePrime) reinterpret_cast<float2*>(io.state_prime)[i] = make_float2(o.spx, o.spy);
+            if (o.has_final) {
+                if (fl & kFOutFinalObs) {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) io.obs[(long long)j * P.n + i] = o.obs[j];
+                    for (int j = 0; j < 5; ++j) {
+                        if constexpr (AOS) io.final_obs[i * 5 + j] = o.fobs[j];
+                        else io.final_obs[(long long)j * P.n + i] = o.fobs[j];
+                    }
+                }
+                if (fl & kFOutFinalRet) io.final_ret[i] = o.fret;
+                if (fl & kFOutFinalLen) io.final_len[i] = o.flen;
+            }
+            if (fail && (fl & kFOutStatus)) atomicOr(io.status, fail);
+            if constexpr (!AOS) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) io.obs[(long long)j * P.n + i] = o.obs[j];
+            }
         }
     }
     if constexpr (AOS) {
@@ -141,7 +203,8 @@ __global__ __launch_bounds__(kBlock) void mr_reset_kernel(const KParams P, const
         double gx, gy;
         goal_at(P, P.flags, goal_table, R.env, 0, gx, gy);
         const double dx = gx - e.x, dy = gy - e.y;
-        const float v[5] = {(float)e.x, (float)e.y, (float)gx, (float)gy, __builtin_amdgcn_sqrtf((float)(dx * dx + dy * dy))};
+        float v[5];  // the packer of env_step (an in-kernel actor re-derives this observation from the state: equal bits)
+        pack_obs(e.x, e.y, gx, gy, __builtin_fma(dx, dx, dy * dy), v);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             if (obs_layout == MRSIM_OBS_AOS) obs[i * 5 + j] = v[j];
@@ -215,13 +278,21 @@ __device__ __forceinline__ void rotate_wave_priority(unsigned t, unsigned slot) 
 // FL != 0: the launch's flags word is known at compile time (the host picks such an instantiation when K.flags
 // matches one of the common configurations): every optional path below folds away, which frees the scalar
 // registers their pointers and constants would occupy.  FL == 0: generic kernel, flags read from P.
-template <bool RK45, int NZ, bool MIS, uint32_t FL = 0>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void mr_rollout_kernel(const KParams P, const StateArgs st, const RolloutArgs ra) {
+// ACT: the action of every step comes from the in-kernel actor (+ OU noise) evaluated on the observation the previous
+// step (or, for t = 0, the state) produced -- the DDPG collection loop of RL/MR_ddpg.py:270-311 without leaving the
+// registers.  All 64 lanes of a wave then run the whole loop (MFMA and the half swaps are wave-wide), lanes past n on a
+// copy of the last env, and only their stores are predicated.
+template <bool RK45, int NZ, bool MIS, uint32_t FL, bool ACT>
+__device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& st, const RolloutArgs& ra, const ActorArgs& ac) {
     // All per-step stores use a wave-uniform base (block start of row t, kept in SGPRs) plus a 32-bit
     // per-lane offset, so no 64-bit address arithmetic runs on the vector unit inside the time loop.
     const long long blk0 = (long long)blockIdx.x * kBlock;
     const unsigned tid = threadIdx.x;
-    const long long i = blk0 + tid;
+    const long long i_raw = blk0 + tid;
+    const bool active = i_raw < P.n;
+    const long long i = (ACT && !active) ? P.n - 1 : i_raw;
+    __shared__ __attribute__((aligned(16))) float s_actor[ACT ? kActBlobFloats : 4];
+    if constexpr (ACT) actor_stage_blob(ac.blob, s_actor, tid, kBlock);  // the barrier below (or its own) publishes it
 #if MRSIM_ROLLOUT_TABLE == 1
     // sin/cos table of the action heading (mrsim_device.h: sincos_tab): 16 KiB per block, read once from L2 per launch
     __shared__ __attribute__((aligned(16))) double2 s_sincos[MRSIM_SINCOS_N];
@@ -233,7 +304,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
 #else
     const double2* __restrict__ sincos_lds = nullptr;
 #endif
-    if (i >= P.n) return;
+#if MRSIM_ROLLOUT_TABLE != 1
+    if constexpr (ACT) __syncthreads();
+#endif
+    if constexpr (!ACT) { if (!active) return; }
     EnvRegs e;
 #ifdef MRSIM_WAVE_PROBE
     const unsigned long long clk0 = wall_clock64();
@@ -257,6 +331,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     if constexpr (kGoal0) {
         goal0 = goal_fetch(P, FL != 0 ? FL : P.flags, ra.goal_table, P.env_id0 + (uint32_t)i, 0);
         asm volatile("" : "+v"(goal0.x), "+v"(goal0.y));
+    }
+    float obs_cur[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float ou0 = 0.f, ou1 = 0.f;
+    if constexpr (ACT) {
+        obs_from_state(P, FL != 0 ? FL : P.flags, ra.goal_table, P.env_id0 + (uint32_t)i, e, obs_cur);
+        if ((FL != 0 ? FL : P.flags) & kFActorOU) {
+            const float2 u = reinterpret_cast<const float2*>(ac.ou_state)[i];
+            ou0 = u.x; ou1 = u.y;
+            asm volatile("" : "+v"(ou0), "+v"(ou1));  // consumed here, like the state above
+        }
     }
     for (int t = 0; t < ra.T; ++t) {
 #if MRSIM_PRIO_MODE == 1
@@ -285,10 +369,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
             const float2 a = (reinterpret_cast<const float2*>(ra.actions) + row)[tid];
             af = a.x; aa = a.y;
         }
-        step_prologue<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa);
+        step_prologue<RK45, NZ, MIS>(P, R, !ACT && !(fl & kFActions), W, af, aa, ACT && (fl & kFActorOU));
+        if constexpr (ACT) actor_policy<ou_nz<NZ>()>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
         if (!(fl & kFActions64)) { adf = (double)af; ada = (double)aa; }
         StepOut o;
         env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr);
+        if constexpr (ACT) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) obs_cur[j] = o.obs[j];  // what the policy sees next (the reset row after an auto-reset)
+        }
         // Goal of the NEXT step (row counter + 1 of this env's trajectory; counter is already 0 after an auto-reset), loaded
         // BEFORE this step's stores are issued: vmcnt counts loads and stores together in issue order, so a load issued
         // after the stores makes its s_waitcnt vmcnt(0) wait for every one of them; issued before, the wait is vmcnt(5)
@@ -302,6 +391,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         // The [T][N] outputs are write-once streams the kernel never reads back: non-temporal stores (+1 %)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef double f64x2 __attribute__((ext_vector_type(2)));
+        if (ACT && !active) continue;  // a lane past n: nothing to store
         if (fl & kFOutTraj) {
             const f64x2 v = {o.px, o.py};
             __builtin_nontemporal_store(v, &(reinterpret_cast<f64x2*>(ra.traj_xy) + row)[tid]);
@@ -342,7 +432,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
             if (fl & kFOutFinalLen) ra.final_len[i] = o.flen;
         }
     }
+    if (ACT && !active) return;
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
+    if constexpr (ACT) {
+        if (P.flags & kFActorOU) reinterpret_cast<float2*>(ac.ou_state)[i] = make_float2(ou0, ou1);
+    }
     if (fail && (P.flags & kFOutStatus)) atomicOr(ra.status, fail);
 #ifdef MRSIM_WAVE_PROBE
     // measurement build only (make CXXFLAGS+=-DMRSIM_WAVE_PROBE, tools/wave_time_probe.py): lane 0 of every wave
@@ -355,6 +449,60 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
         ra.final_len[i + 3] = (int)(clk0 & 0x7fffffff);
     }
 #endif
+}
+
+template <bool RK45, int NZ, bool MIS, uint32_t FL = 0>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void mr_rollout_kernel(const KParams P, const StateArgs st, const RolloutArgs ra) {
+    rollout_body<RK45, NZ, MIS, FL, false>(P, st, ra, ActorArgs{nullptr, nullptr, {0.f, 0.f}});
+}
+
+// The same loop with the actor as its policy source.  No occupancy floor: the two 32-register accumulator tiles of a layer
+// and the env state do not fit the 128 registers that four waves per SIMD leave, and the kernel is bound by the matrix
+// pipe (140 f32 MFMAs of 64 cycles per wave and step), which two waves per SIMD already keep busy.
+#ifndef MRSIM_ACTOR_WAVES
+#define MRSIM_ACTOR_WAVES 2
+#endif
+template <bool RK45, int NZ, bool MIS, uint32_t FL = 0>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES, 8))) void mr_rollout_actor_kernel(const KParams P, const StateArgs st, const RolloutArgs ra,
+                                                                  const ActorArgs ac) {
+    rollout_body<RK45, NZ, MIS, FL, true>(P, st, ra, ac);
+}
+
+// ---------------------------------------------------------------------------
+// the actor as a kernel of its own: actions[n][2] = actor.predict(obs) + actor_noise()   (RL/MR_ddpg.py:277)
+// ---------------------------------------------------------------------------
+// The gym-loop form (this kernel, then mrsim_step with its output) and the fused forms (mr_step_kernel / mr_rollout_actor_kernel
+// with ACT) evaluate the same device functions on the same bits: equal actions.  aux: the env state's {f0x, f0y, hq, counter}
+// records, read only for the episode-start reset of the OU state (kFOUReset).
+template <int OUNZ>
+__global__ __launch_bounds__(kBlock) void mr_actor_kernel(const KParams P, const ActorArgs ac, const float* __restrict__ obs,
+                                                          int obs_layout, const float* __restrict__ aux,
+                                                          float* __restrict__ actions) {
+    __shared__ __attribute__((aligned(16))) float s_actor[kActBlobFloats];
+    actor_stage_blob(ac.blob, s_actor, threadIdx.x, kBlock);
+    __syncthreads();
+    const long long i_raw = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = i_raw < P.n;
+    const long long i = active ? i_raw : P.n - 1;
+    float o[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) o[j] = obs_layout == MRSIM_OBS_AOS ? obs[i * 5 + j] : obs[(long long)j * P.n + i];
+    const uint32_t fl = P.flags;
+    float ou0 = 0.f, ou1 = 0.f;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    int32_t counter = 1;
+    if (fl & kFActorOU) {
+        const float2 u = reinterpret_cast<const float2*>(ac.ou_state)[i];
+        ou0 = u.x; ou1 = u.y;
+        const Rng R = make_rng(P, i);
+        philox_call(R, policy_c0(P.integrator == MRSIM_INT_RK45), w);
+        if (fl & kFOUReset) counter = __float_as_int(reinterpret_cast<const float4*>(aux)[i].w);
+    }
+    float af, aa;
+    actor_policy<OUNZ>(P, fl, ac, s_actor, o, counter, w, ou0, ou1, af, aa);
+    if (!active) return;
+    reinterpret_cast<float2*>(actions)[i] = make_float2(af, aa);
+    if (fl & kFActorOU) reinterpret_cast<float2*>(ac.ou_state)[i] = make_float2(ou0, ou1);
 }
 
 // ---------------------------------------------------------------------------
@@ -555,17 +703,46 @@ static int dispatch(bool rk45, int nz, bool mis, F&& f) {
 constexpr uint32_t kFlGym = kFAutoReset | kFSymBounds | kFObsAos | kFActions | kFOutFinalObs | kFOutFinalRet |
                             kFOutFinalLen | kFOutStatus;
 
-static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams& K, const StateArgs& S, const IOArgs& IO) {
+
+static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams& K, const StateArgs& S, const IOArgs& IO,
+                       const ActorArgs& AC) {
     const bool aos = p->obs_layout == MRSIM_OBS_AOS;
+    if (K.flags & kFActor) {  // policy source = in-kernel actor (RK45 only, checked by the caller)
+        return dispatch(true, noise_variant(p), p->mismatched != 0, [&](auto, auto NZ, auto MIS) {
+            constexpr bool mis = decltype(MIS)::value;
+            constexpr int nz = decltype(NZ)::value;
+            if (aos) return launch(lc, mr_step_kernel<true, nz, mis, true, 0, true>, K.n, K, S, IO, AC);
+            return launch(lc, mr_step_kernel<true, nz, mis, false, 0, true>, K.n, K, S, IO, AC);
+        });
+    }
     if ((K.flags & ~kFStepBase) == kFlGym && p->integrator == MRSIM_INT_RK45 && noise_variant(p) == kNoiseFast)
-        return p->mismatched ? launch(lc, mr_step_kernel<true, kNoiseFast, true, true, kFlGym>, K.n, K, S, IO)
-                             : launch(lc, mr_step_kernel<true, kNoiseFast, false, true, kFlGym>, K.n, K, S, IO);
+        return p->mismatched ? launch(lc, mr_step_kernel<true, kNoiseFast, true, true, kFlGym>, K.n, K, S, IO, AC)
+                             : launch(lc, mr_step_kernel<true, kNoiseFast, false, true, kFlGym>, K.n, K, S, IO, AC);
     return dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
         constexpr bool rk = decltype(RK)::value, mis = decltype(MIS)::value;
         constexpr int nz = decltype(NZ)::value;
-        if (aos) return launch(lc, mr_step_kernel<rk, nz, mis, true>, K.n, K, S, IO);
-        return launch(lc, mr_step_kernel<rk, nz, mis, false>, K.n, K, S, IO);
+        if (aos) return launch(lc, mr_step_kernel<rk, nz, mis, true>, K.n, K, S, IO, AC);
+        return launch(lc, mr_step_kernel<rk, nz, mis, false>, K.n, K, S, IO, AC);
     });
+}
+
+// MrsimActor -> kernel arguments + flag bits.  Returns MRSIM_OK with `on` = false when there is no actor.
+static int actor_args(const MrsimParams* p, const MrsimActor* a, bool have_actions, ActorArgs& AC, uint32_t& bits, bool& on) {
+    AC = ActorArgs{nullptr, nullptr, {0.f, 0.f}};
+    bits = 0u; on = false;
+    if (a == nullptr || a->blob == nullptr) return MRSIM_OK;
+    if (have_actions) return MRSIM_EINVAL;                      // one policy source per launch
+    if (p->integrator != MRSIM_INT_RK45) return MRSIM_EINVAL;   // the actor drives the reference integrator only
+    if (!aligned16(a->blob) || (a->ou_state && !aligned8(a->ou_state))) return MRSIM_EALIGN;
+    if (!(a->ou_dt >= 0.0f) || std::isnan(a->ou_theta) || std::isnan(a->ou_sigma)) return MRSIM_EINVAL;
+    AC.blob = a->blob;
+    AC.ou_state = a->ou_state;
+    // x += theta (mu - x) dt + sigma sqrt(dt) N(0,1), mu = 0: the two products, formed in double and rounded once
+    AC.ou.theta_dt = (float)((double)a->ou_theta * (double)a->ou_dt);
+    AC.ou.sigma_sqrt_dt = (float)((double)a->ou_sigma * std::sqrt((double)a->ou_dt));
+    bits = kFActor | (a->ou_state ? kFActorOU : 0u) | ((a->ou_state && a->ou_reset_on_done) ? kFOUReset : 0u);
+    on = true;
+    return MRSIM_OK;
 }
 
 // Flags words with a compile-time-specialised rollout kernel (mr_rollout_kernel<.., FL>): the DDPG rollout workload
@@ -577,6 +754,8 @@ constexpr uint32_t kFlDdpg = kFAutoReset | kFSymBounds | kFObsAos | kFOutObs | k
                              kFOutFinalRet | kFOutFinalLen | kFOutStatus;
 constexpr uint32_t kFlMixed = kFlDdpg | kFGoalTable | kFRewardGoal;
 constexpr uint32_t kFlDdpgSoa = kFlDdpg & ~kFObsAos;  // the same with [T][5][N] observations
+// the DDPG collection loop with the actor in the kernel (RolloutCollector(policy=actor)): actor + OU noise, fp64 carry
+constexpr uint32_t kFlDdpgActor = kFlDdpg | kFCarry64 | kFActor | kFActorOU;
 
 template <uint32_t FL>
 static int launch_rollout_fl(const LaunchCfg& lc, int nz, bool mis, const KParams& K, const StateArgs& S,
@@ -586,6 +765,17 @@ static int launch_rollout_fl(const LaunchCfg& lc, int nz, bool mis, const KParam
         return mis ? launch(lc, mr_rollout_kernel<true, kNoiseFast, true, FL>, K.n, K, S, ra)
                    : launch(lc, mr_rollout_kernel<true, kNoiseFast, false, FL>, K.n, K, S, ra);
     handled = false;  // sigma == 0 / noise_math = spec: generic kernel
+    return MRSIM_OK;
+}
+
+template <uint32_t FL>
+static int launch_rollout_actor_fl(const LaunchCfg& lc, int nz, bool mis, const KParams& K, const StateArgs& S,
+                                   const RolloutArgs& ra, const ActorArgs& AC, bool& handled) {
+    handled = true;
+    if (nz == kNoiseFast)
+        return mis ? launch(lc, mr_rollout_actor_kernel<true, kNoiseFast, true, FL>, K.n, K, S, ra, AC)
+                   : launch(lc, mr_rollout_actor_kernel<true, kNoiseFast, false, FL>, K.n, K, S, ra, AC);
+    handled = false;
     return MRSIM_OK;
 }
 
@@ -601,6 +791,10 @@ static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
     if (io == nullptr || io->obs == nullptr || io->rew == nullptr || io->done == nullptr) return MRSIM_EINVAL;
     if (!aligned16(io->obs) || (io->actions && !aligned16(io->actions))) return MRSIM_EALIGN;
     if (io->goal_table != nullptr && (p->goal_K < 1 || p->goal_T < 1)) return MRSIM_EINVAL;
+    ActorArgs AC;
+    uint32_t abits = 0u;
+    bool actor_on = false;
+    if ((rc = actor_args(p, io->actor, io->actions != nullptr, AC, abits, actor_on))) return rc;
     if ((rc = check_device())) return rc;
     const StateArgs S{st->pos, st->aux, st->ep_ret};
     const IOArgs IO{io->actions, io->actions_out, io->goal_table, io->obs, io->rew, io->done, io->state_prime,
@@ -608,12 +802,12 @@ static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
     K.flags |= (io->actions ? kFActions : 0u) | (io->goal_table ? kFGoalTable : 0u) |
                (io->actions_out ? kFOutActions : 0u) | (io->state_prime ? kFOutStatePrime : 0u) |
                (io->final_obs ? kFOutFinalObs : 0u) | (io->final_ret ? kFOutFinalRet : 0u) |
-               (io->final_len ? kFOutFinalLen : 0u) | (io->status ? kFOutStatus : 0u);
+               (io->final_len ? kFOutFinalLen : 0u) | (io->status ? kFOutStatus : 0u) | abits;
     LaunchCfg lc{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
-    if (kernel_ms == nullptr) return launch_step(lc, p, K, S, IO);
+    if (kernel_ms == nullptr) return launch_step(lc, p, K, S, IO, AC);
     // timed variant: events attached to this one dispatch (hipExtLaunchKernelGGL)
     if (hipEventCreate(&lc.start) != hipSuccess || hipEventCreate(&lc.stop) != hipSuccess) return MRSIM_ELAUNCH;
-    rc = launch_step(lc, p, K, S, IO);
+    rc = launch_step(lc, p, K, S, IO, AC);
     if (rc == MRSIM_OK) {
         if (hipEventSynchronize(lc.stop) != hipSuccess || hipEventElapsedTime(kernel_ms, lc.start, lc.stop) != hipSuccess)
             rc = MRSIM_ELAUNCH;
@@ -746,8 +940,13 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
         (io->state_prime_T && !aligned8(io->state_prime_T)))
         return MRSIM_EALIGN;
     if (io->goal_table != nullptr && (p->goal_K < 1 || p->goal_T < 1)) return MRSIM_EINVAL;
+    ActorArgs AC;
+    uint32_t abits = 0u;
+    bool actor_on = false;
+    if ((rc = actor_args(p, io->actor, io->actions != nullptr, AC, abits, actor_on))) return rc;
     if ((rc = check_device())) return rc;
     const StateArgs S{st->pos, st->aux, st->ep_ret};
+    K.flags |= abits;
     K.flags |= (io->actions ? kFActions : 0u) | (io->shared_actions ? kFSharedActions : 0u) |
                (io->goal_table ? kFGoalTable : 0u) | (io->traj_xy ? kFOutTraj : 0u) |
                (io->state_prime_T ? kFOutStatePrime : 0u) | (io->obs_T ? kFOutObs : 0u) | (io->rew_T ? kFOutRew : 0u) |
@@ -763,7 +962,16 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     if (kernel_ms != nullptr && (hipEventCreate(&lc.start) != hipSuccess || hipEventCreate(&lc.stop) != hipSuccess))
         return MRSIM_ELAUNCH;
     bool handled = false;
-    if (p->integrator == MRSIM_INT_RK45) {
+    if (actor_on) {
+        const int nz = noise_variant(p);
+        const bool mis = p->mismatched != 0;
+        if (K.flags == kFlDdpgActor) rc = launch_rollout_actor_fl<kFlDdpgActor>(lc, nz, mis, K, S, ra, AC, handled);
+        if (!handled)
+            rc = dispatch(true, nz, mis, [&](auto, auto NZ, auto MIS) {
+                return launch(lc, mr_rollout_actor_kernel<true, decltype(NZ)::value, decltype(MIS)::value>, K.n, K, S, ra, AC);
+            });
+        handled = true;
+    } else if (p->integrator == MRSIM_INT_RK45) {
         const int nz = noise_variant(p);
         const bool mis = p->mismatched != 0;
         switch (K.flags) {
@@ -836,6 +1044,74 @@ int mrsim_step_events(const MrsimParams* p, int64_t n, uint32_t env_id0, const M
                       uint64_t seed, uint64_t step_idx, void* stream, void* start_event, void* stop_event) {
     if (start_event == nullptr || stop_event == nullptr) return MRSIM_EINVAL;
     return step_impl(p, n, env_id0, st, io, seed, step_idx, stream, nullptr, start_event, stop_event);
+}
+
+int mrsim_actor_fold_bn_host(int32_t rows, int32_t cols, const float* w, const float* b, const float* gamma,
+                             const float* beta, const float* mean, const float* var, float eps, float* w_out,
+                             float* b_out) {
+    if (rows < 1 || cols < 1 || w == nullptr || b == nullptr || gamma == nullptr || beta == nullptr || mean == nullptr ||
+        var == nullptr || w_out == nullptr || b_out == nullptr)
+        return MRSIM_EINVAL;
+    for (int r = 0; r < rows; ++r) {
+        const double g = (double)gamma[r] / std::sqrt((double)var[r] + (double)eps);
+        for (int c = 0; c < cols; ++c) w_out[(size_t)r * cols + c] = (float)((double)w[(size_t)r * cols + c] * g);
+        b_out[r] = (float)(((double)b[r] - (double)mean[r]) * g + (double)beta[r]);
+    }
+    return MRSIM_OK;
+}
+
+int mrsim_actor_pack_host(const MrsimActorWeights* w, float* blob) {
+    static_assert(MRSIM_ACTOR_BLOB_FLOATS == kActBlobFloats && MRSIM_ACTOR_HIDDEN == kActHidden, "mrsim.h / mrsim_actor.h");
+    if (w == nullptr || blob == nullptr || w->w1 == nullptr || w->b1 == nullptr || w->w2 == nullptr || w->b2 == nullptr ||
+        w->w3 == nullptr || w->b3 == nullptr)
+        return MRSIM_EINVAL;
+    std::memset(blob, 0, sizeof(float) * kActBlobFloats);
+    constexpr int H = kActHidden;
+    for (int rt = 0; rt < 2; ++rt)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int f = 32 * rt + (lane & 31), h = lane >> 5;
+            for (int s = 0; s < 3; ++s) {  // layer 1: k = 2 s + h (k = 5: zero pad), input scaling folded in
+                const int k = 2 * s + h;
+                blob[kActA1 + (rt * 3 + s) * 64 + lane] = k < 5 ? w->w1[f * 5 + k] * w->obs_scale[k] : 0.0f;
+            }
+            for (int q = 0; q < 32; ++q)  // layer 2: k-step q of lane half h sums feature kperm(q, h)
+                blob[kActA2 + ((rt * 8 + q / 4) * 64 + lane) * 4 + (q % 4)] = w->w2[f * H + act_kperm(q, h)];
+        }
+    for (int h = 0; h < 2; ++h)
+        for (int q = 0; q < 32; ++q) {
+            blob[kActC1 + h * 32 + q] = w->b1[act_kperm(q, h)];  // accumulator register q of half h = feature kperm(q, h)
+            blob[kActC2 + h * 32 + q] = w->b2[act_kperm(q, h)];
+            for (int o = 0; o < 2; ++o) blob[kActW3 + (h * 2 + o) * 32 + q] = w->w3[o * H + act_kperm(q, h)];
+        }
+    for (int o = 0; o < 2; ++o) {
+        blob[kActTail + o] = w->b3[o];
+        blob[kActTail + 2 + o] = w->action_bound[o];
+    }
+    return MRSIM_OK;
+}
+
+int mrsim_actor_forward(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimActor* actor, const MrsimState* st,
+                        const float* obs, float* actions, uint64_t seed, uint64_t step_idx, void* stream) {
+    KParams K;
+    int rc = make_kparams(p, n, env_id0, seed, step_idx, K);
+    if (rc) return rc;
+    if (actor == nullptr || actor->blob == nullptr || obs == nullptr || actions == nullptr) return MRSIM_EINVAL;
+    if (!aligned8(actions)) return MRSIM_EALIGN;
+    ActorArgs AC;
+    uint32_t abits = 0u;
+    bool on = false;
+    if ((rc = actor_args(p, actor, false, AC, abits, on))) return rc;
+    const float* aux = nullptr;
+    if (abits & kFOUReset) {
+        if (st == nullptr || st->aux == nullptr) return MRSIM_EINVAL;
+        if (!aligned16(st->aux)) return MRSIM_EALIGN;
+        aux = st->aux;
+    }
+    if ((rc = check_device())) return rc;
+    K.flags |= abits;
+    const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
+    if (noise_variant(p) == kNoiseFast) return launch(lc, mr_actor_kernel<kNoiseFast>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
+    return launch(lc, mr_actor_kernel<kNoiseSpec>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
 }
 
 int mrsim_velocity(int64_t n, int32_t T, int32_t n_filter, const double* traj_xy, const double* time, double* v_xy,

@@ -202,17 +202,25 @@ class MRVecEnv:
         self.step_idx += 1
         return self.obs
 
-    def _step_io(self, act_t):
-        return _lib.MrsimStepIO(
+    def _step_io(self, act_t, actor=None):
+        io = _lib.MrsimStepIO(
             self._p(act_t), self._p(self._actions_out), self._p(self.goal_table), self._p(self._obs),
             self._p(self.rew), self._p(self._done_u8), self._p(self._state_prime), self._p(self._final_obs),
             self._p(self.final_ret), self._p(self.final_len), self._p(self.status))
+        if actor is not None:
+            self._actor_struct = actor.struct(self.num_envs)   # keeps the ctypes block alive through the call
+            io.actor = C.pointer(self._actor_struct)
+        return io
 
-    def step(self, actions=None):
-        """MR_Env.step for all envs.  actions: [N,2] float32 device tensor {f_t, alpha_t}, or None to
-        draw the uniform random policy in-kernel (cfg.policy_low/high)."""
+    def step(self, actions=None, actor=None):
+        """MR_Env.step for all envs.  actions: [N,2] float32 device tensor {f_t, alpha_t}; or actor=DeviceActor: the action
+        is actor.predict(obs) + actor_noise() evaluated inside the step kernel on the env's current observation
+        (RL/MR_ddpg.py:277-278 in one launch); or neither, to draw the uniform random policy in-kernel
+        (cfg.policy_low/high)."""
         torch = _torch()
         act_t = None
+        if actions is not None and actor is not None:
+            raise ValueError("step: pass actions or actor, not both")
         if actions is not None:
             act_t = actions if (torch.is_tensor(actions) and actions.dtype == torch.float32 and
                                 actions.device == self.device and actions.is_contiguous()) else \
@@ -222,7 +230,7 @@ class MRVecEnv:
             self.last_action = act_t
         elif self._actions_out is not None:
             self.last_action = self._actions_out
-        io = self._step_io(act_t)
+        io = self._step_io(act_t, actor)
         rc = self._L.mrsim_step(C.byref(self._params), self.num_envs, self.env_id0, C.byref(self._st), C.byref(io),
                                 self.seed_value, self.step_idx, self._stream())
         _lib.check(rc, "mrsim_step")
@@ -291,10 +299,12 @@ class MRVecEnv:
         return out
 
     def rollout(self, T, actions=None, shared_actions=False, want=("traj",), out=None, timed=False, events=None,
-                carry=None):
+                carry=None, actor=None):
         """T fused steps in one launch (batched utils.run_sim / DDPG rollout).  actions: [T,N,2], or [T,2]
         with shared_actions=True, or None for the on-device random policy; a float64 array / tensor is
         passed on as fp64 (the reference's action tables are float64, main.py:14-50), anything else as fp32.
+        actor: a DeviceActor instead of actions -- every step's action is actor.predict(obs) + actor_noise() on the
+        observation of the previous step, evaluated in-kernel (the collection loop of RL/MR_ddpg.py:270-311).
         want: any of "traj" (fp64 positions [T,N,2]), "state_prime", "obs", "rew", "done", "actions".
         `out` lets a caller reuse the [T,...] buffers of a previous call (the returned dict).
         carry: "f32" (default, cfg.rollout_carry) rounds the carried RK45 state to its HBM format after every
@@ -331,7 +341,7 @@ class MRVecEnv:
         acts_T = get("actions", (T, n, 2), torch.float32)
         self.launch_rollout(T, 0, n, act_t=act_t, shared_actions=shared_actions, act64=act64, traj=traj, sp_T=sp_T,
                             obs_T=obs_T, rew_T=rew_T, done_T=done_T, acts_T=acts_T, carry=carry, timed_into=buf if timed else None,
-                            events=events)
+                            events=events, actor=actor)
         self.step_idx += int(T)
         if traj is not None:
             buf["traj"] = traj
@@ -349,7 +359,7 @@ class MRVecEnv:
 
     def launch_rollout(self, T, first, n, act_t=None, shared_actions=False, act64=False, traj=None, sp_T=None, obs_T=None,
                        rew_T=None, done_T=None, acts_T=None, final_ret=None, final_len=None, carry="f32", step_idx=None,
-                       stream=None, timed_into=None, events=None, prepare_only=False):
+                       stream=None, timed_into=None, events=None, prepare_only=False, actor=None):
         """One mrsim_rollout launch over the envs [first, first + n) of this env set (a sub-shard when n < num_envs):
         state, final_* and every [T, N, ...] buffer are passed advanced to env `first`, the buffers keep their row
         length N (MrsimRolloutIO.row_stride), the RNG keys stay the GLOBAL env ids.  Does not advance step_idx (the
@@ -381,12 +391,19 @@ class MRVecEnv:
                                  self.goal_table.data_ptr(), P(traj), P(sp_T), P(obs_T, soa_obs=self._soa), P(rew_T),
                                  P(done_T), P(acts_T), P(fr, 1), P(fl, 1), self.status.data_ptr(),
                                  0 if n == N else N, int(carry == "f64"), int(act64))
+        actor_struct = None
+        if actor is not None:
+            if act_t is not None:
+                raise ValueError("launch_rollout: pass actions or actor, not both")
+            actor_struct = actor.struct(N, first, n)   # OU state advanced to env `first`; kept alive by the closure
+            io.actor = C.pointer(actor_struct)
         strm = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
         head = (C.byref(self._params), n, self.env_id0 + first, C.byref(st), C.byref(io), self.seed_value)
         L = self._L
 
         def launch(step_idx, events=None, timed_into=None):
             """the prepared launch; the ctypes structures above stay alive in this closure"""
+            _keep = actor_struct  # noqa: F841
             if timed_into is not None:
                 ms = C.c_float(0.0)
                 _lib.check(L.mrsim_rollout_timed(*head, int(step_idx), strm, C.byref(ms)), "mrsim_rollout_timed")

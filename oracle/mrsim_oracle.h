@@ -126,6 +126,35 @@ int orc_vec_step(const OrcParams* p, int64_t n, uint32_t env_id0, OrcEnv* envs, 
                  double* final_obs /* [n][5] or NULL */, double* final_ret, int32_t* final_len, int threads);
 int orc_vec_random_policy(int integrator, int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx,
                           const double lo[2], const double hi[2], float* actions, int threads);
+/* ---- DDPG actor + OU noise as the policy (RL/MR_ddpg.py:80-160 ActorNetwork.predict, :59-78 OUNoise, :277).
+ * Inference form: 5 -> 64 (+ folded batch norm) -> relu -> 64 (+ folded batch norm) -> relu -> 2 tanh, * bound.
+ * Parity status: UNPINNED against the reference (TensorFlow 1.x / tflearn are absent); tests pin this restatement
+ * against the PyTorch twin's fp32 forward (mr_rl_amd/ddpg.py: Actor, eval mode).  The fp32 summation order is part of
+ * the definition (mr_rl_amd/csrc/mrsim_actor.h), so the HIP kernels agree with this function bit for bit. */
+typedef struct {
+    float w1[64 * 5];      /* [64][5]  (obs scaling already folded in)                   */
+    float b1[64];
+    float w2[64 * 64];     /* [64][64]                                                   */
+    float b2[64];
+    float w3[2 * 64];      /* [2][64]                                                    */
+    float b3[2];
+    float bound[2];        /* action_bound                                               */
+    float ou_theta_dt;     /* theta * dt           (products formed in double, rounded)  */
+    float ou_sigma_sqrt_dt;/* sigma * sqrt(dt)                                           */
+    int32_t ou_enabled;    /* 0: actor.predict alone                                     */
+    int32_t ou_reset_on_done; /* 1: x_prev := 0 at the first step of an episode (counter == 0) */
+} OrcActor;
+float orc_spec_tanhf(float x);
+void orc_actor_forward(const OrcActor* a, const float obs[5], float act[2]);
+/* action = actor.predict(obs) + actor_noise(); ou[2] is OUNoise.x_prev, updated in place.  The OU pair's normals are
+ * words 0,1 of DYN(0,0) (RK45) / POLICY(0,0) (fixed-step) of (seed, env_id, step_idx), spec Box-Muller. */
+void orc_actor_policy(const OrcActor* a, int integrator, const float obs[5], int32_t counter, float ou[2], uint64_t seed,
+                      uint32_t env_id, uint64_t step_idx, float act[2]);
+int orc_vec_actor_policy(const OrcActor* a, int integrator, int64_t n, uint32_t env_id0, const float* obs /* [n][5] */,
+                         const int32_t* counter /* [n] or NULL */, float* ou /* [n][2] or NULL */, uint64_t seed,
+                         uint64_t step_idx, float* actions /* [n][2] */, int threads);
+int orc_sizeof_actor(void);
+
 int orc_num_threads(void);
 int orc_sizeof_env(void);
 int orc_sizeof_params(void);

@@ -44,6 +44,15 @@ ENV_DTYPE = np.dtype([
 ])
 
 
+class OrcActor(C.Structure):
+    _fields_ = [
+        ("w1", C.c_float * 320), ("b1", C.c_float * 64), ("w2", C.c_float * 4096), ("b2", C.c_float * 64),
+        ("w3", C.c_float * 128), ("b3", C.c_float * 2), ("bound", C.c_float * 2),
+        ("ou_theta_dt", C.c_float), ("ou_sigma_sqrt_dt", C.c_float), ("ou_enabled", C.c_int32),
+        ("ou_reset_on_done", C.c_int32),
+    ]
+
+
 class OrcNoise(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("seed", C.c_uint64), ("step_idx", C.c_uint64),
@@ -97,6 +106,12 @@ def lib():
         L.orc_vec_step.restype = C.c_int
         L.orc_vec_random_policy.argtypes = [C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_uint64, dp, dp,
                                             C.c_void_p, C.c_int]
+        assert L.orc_sizeof_actor() == C.sizeof(OrcActor), "OrcActor layout mismatch"
+        L.orc_spec_tanhf.argtypes = [C.c_float]
+        L.orc_spec_tanhf.restype = C.c_float
+        L.orc_actor_forward.argtypes = [C.POINTER(OrcActor), fp, fp]
+        L.orc_vec_actor_policy.argtypes = [C.POINTER(OrcActor), C.c_int, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -116,6 +131,48 @@ def default_params(**kw):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_actor(w, ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False):
+    """OrcActor from the inference-form weights dict {w1 [64,5], b1, w2 [64,64], b2, w3 [2,64], b3, obs_scale [5],
+    action_bound [2]} (mr_rl_amd.actor.fold_actor's output): the obs scaling is folded into w1 exactly as
+    mrsim_actor_pack_host does (float32 product)."""
+    lib()
+    a = OrcActor()
+    w1 = (np.asarray(w["w1"], np.float32) * np.asarray(w.get("obs_scale", np.ones(5)), np.float32)[None, :]).astype(np.float32)
+    for name, arr in (("w1", w1), ("b1", w["b1"]), ("w2", w["w2"]), ("b2", w["b2"]), ("w3", w["w3"]), ("b3", w["b3"]),
+                      ("bound", w["action_bound"])):
+        flat = np.ascontiguousarray(arr, dtype=np.float32).ravel()
+        dst = getattr(a, name)
+        assert len(flat) == len(dst), name
+        C.memmove(dst, flat.ctypes.data, flat.nbytes)
+    a.ou_theta_dt = np.float32(np.float64(np.float32(theta)) * np.float64(np.float32(dt)))
+    a.ou_sigma_sqrt_dt = np.float32(np.float64(np.float32(sigma)) * np.sqrt(np.float64(np.float32(dt))))
+    a.ou_enabled, a.ou_reset_on_done = int(bool(ou)), int(bool(reset_on_done))
+    return a
+
+
+def actor_forward(actor, obs):
+    """[n,5] float32 -> [n,2] float32: ActorNetwork.predict, no noise."""
+    obs = np.ascontiguousarray(obs, dtype=np.float32)
+    out = np.zeros((obs.shape[0], 2), dtype=np.float32)
+    a0 = OrcActor.from_buffer_copy(actor)
+    a0.ou_enabled = 0
+    lib().orc_vec_actor_policy(C.byref(a0), INT_RK45, obs.shape[0], 0, _ptr(obs), None, None, 0, 0, _ptr(out), 1)
+    return out
+
+
+def actor_policy(actor, obs, ou, seed, step_idx, env_id0=0, counter=None, integrator=INT_RK45, threads=1):
+    """actions [n,2] = actor.predict(obs) + actor_noise(); `ou` [n,2] float32 is updated in place."""
+    obs = np.ascontiguousarray(obs, dtype=np.float32)
+    n = obs.shape[0]
+    out = np.zeros((n, 2), dtype=np.float32)
+    if ou is not None:
+        assert ou.dtype == np.float32 and ou.shape == (n, 2) and ou.flags.c_contiguous
+    cnt = None if counter is None else np.ascontiguousarray(counter, dtype=np.int32)
+    lib().orc_vec_actor_policy(C.byref(actor), integrator, n, env_id0, _ptr(obs), _ptr(cnt), _ptr(ou), seed, step_idx,
+                               _ptr(out), threads)
+    return out
 
 
 # ---------------------------------------------------------------------------

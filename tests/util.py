@@ -46,3 +46,28 @@ def actions_ramp(T=1000, freq=4.0):
     a[800:, 1] = np.linspace(np.pi / 8, -np.pi, 200)
     a[:, 0] = freq
     return a[:T]
+
+
+def random_actor(seed=0, bn_stats=True, out_scale=None):
+    """An mr_rl_amd.ddpg.Actor (the PyTorch twin of RL/MR_ddpg.py's ActorNetwork) in eval mode with random weights; bn_stats:
+    non-trivial running statistics and affine terms, as after training; out_scale: widen the U[-3e-3, 3e-3] output layer
+    so that tanh leaves its linear range."""
+    import torch
+    from mr_rl_amd.ddpg import Actor
+    g = torch.Generator().manual_seed(seed)
+    m = Actor()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * (1.0 / max(1, p.shape[-1])) ** 0.5)
+        if out_scale is None:
+            m.out.weight.copy_((torch.rand(m.out.weight.shape, generator=g) * 2 - 1) * 3e-3)
+            m.out.bias.copy_((torch.rand(m.out.bias.shape, generator=g) * 2 - 1) * 3e-3)
+        else:
+            m.out.weight.mul_(out_scale)
+        if bn_stats:
+            for bn in (m.bn1, m.bn2):
+                bn.running_mean.copy_(torch.randn(64, generator=g) * 0.3)
+                bn.running_var.copy_(torch.rand(64, generator=g) * 2 + 0.25)
+                bn.weight.copy_(torch.rand(64, generator=g) + 0.5)
+                bn.bias.copy_(torch.randn(64, generator=g) * 0.2)
+    return m.eval()
