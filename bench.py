@@ -109,6 +109,7 @@ def parse(argv=None):
     ap.add_argument("--no-step-path", action="store_true", help="skip the extra one-launch-per-step measurement")
     ap.add_argument("--no-mixed-set", action="store_true", help="skip the extra mixed-trajectory-set measurement")
     ap.add_argument("--no-power", action="store_true", help="skip the 1.5 s package-power leg (hwmon sysfs)")
+    ap.add_argument("--no-actor-leg", action="store_true", help="skip the actor-in-the-loop collection measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--master-port", type=int, default=0, help="--gpus N launcher: rendezvous port (0 = pick a free one)")
@@ -505,6 +506,68 @@ def measure_mixed_set(args, n_local, env_id0, world, dev, seed, streams, steps=1
             "streams": reg.col.S, "ms_per_step": el / k * 1e3, "mean_episode_return": reg.g.last_mean()}
 
 
+ACTOR_FLOP_PER_ENV_STEP = 2 * (5 * 64 + 64 * 64 + 64 * 2)   # RL/MR_ddpg.py:120-137: 5 -> 64 -> 64 -> 2
+MFMA_F32_PEAK_TFLOPS = 157.3                                # MI355X_MICROARCH.md: f32-input MFMA, dense
+
+
+def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event_episodes=60):
+    """The DDPG collection loop with an OBSERVATION-DEPENDENT policy (RL/MR_ddpg.py:270-311: action = actor.predict(state)
+    + actor_noise(); env.step(action)): the reference's actor architecture, random-initialised, evaluated inside the
+    fused rollout kernel (mr_rl_amd.actor.DeviceActor as the collector's policy), OU noise on, every transition written.
+    Wall-clock rate over `episodes` episodes after a pre-roll, then the same on ONE stream with a HIP event pair on every
+    dispatch: the kernel durations behind the `mfma` roofline object (the two 64-wide layers are f32-input MFMA)."""
+    import torch
+    from mr_rl_amd import MRConfig
+    from mr_rl_amd._lib import EventPair
+    from mr_rl_amd.actor import DeviceActor
+    from mr_rl_amd.collector import RolloutCollector
+    from mr_rl_amd.ddpg import Actor
+    torch.manual_seed(seed)
+    actor = DeviceActor.from_module(Actor().eval(), obs_scale=[0.01] * 5, device=dev)
+    cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math, seed=seed,
+                   is_mismatched=args.mismatched)
+    ep = cfg.max_timesteps + 1
+
+    def run(S, n, events=None):
+        col = RolloutCollector(n_local, cfg=cfg, device=dev, seed=seed, streams=S, carry=args.carry, policy=actor)
+        col.reset()
+        for _ in range(40):
+            col.collect(); col.ready(); col.release()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(n):
+            col.collect(events=None if events is None else [events[k]]); col.ready(); col.release()
+        col.join()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        col.check_status()
+        return el
+    el = run(streams, episodes)
+    pool = [EventPair() for _ in range(event_episodes)]
+    el1 = run(1, event_episodes, pool)
+    ms = [p.elapsed_ms() for p in pool]
+    for p in pool:
+        p.close()
+    avg_us, med_us = stats_us(ms)
+    tflops = n_local * ep * ACTOR_FLOP_PER_ENV_STEP / (avg_us * 1e-6) / 1e12
+    return {"what": "BASELINE config 4 with the reference's DDPG actor (5-64-64-2, eval-mode batch norm folded, tanh x bound) "
+                    "+ OU noise as the policy, evaluated INSIDE the fused rollout kernel on each step's observation "
+                    "(RL/MR_ddpg.py:277-278 without leaving the registers); random-initialised weights, every transition written",
+            "value": n_local * ep * episodes / el, "unit": "env-steps/s", "episodes": episodes, "streams": streams,
+            "ms_per_step": el / (episodes * ep) * 1e3,
+            "one_stream_with_events": {"value": n_local * ep * event_episodes / el1, "avg_kernel_us": round(avg_us, 2),
+                                       "median_kernel_us": round(med_us, 2)},
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                         "flop_per_env_step": ACTOR_FLOP_PER_ENV_STEP,
+                         "kernel": "mr_rollout_actor_fl_kernel<RK45,%s,%s,DDPG|carry64|actor|OU>" %
+                                   ("nonoise" if args.sigma == 0 else args.noise_math, "mismatched" if args.mismatched else "nominal"),
+                         "note": "algorithmic flops of the actor (2 x 4544 multiply-adds per env-step) / the kernel's average "
+                                 "duration (HIP events on the dispatches) against the dense f32-input MFMA peak; 97 % of the "
+                                 "flops (layers 1, 2) run on v_mfma_f32_32x32x2_f32, the env step runs on the vector unit "
+                                 "beside them"}}
+
+
 def trajectory_rmse(dev, carry):
     """Second half of BASELINE's metric: trajectory RMSE vs the CPU reference, on the committed golden trajectories
     the reference itself produced (tests/golden/ref_sim.npz, sigma = 0, 1000-2000 steps each), through the same
@@ -809,6 +872,11 @@ def main():
             step_path = measure_step_path(cfg, n_local, dev, seed)
         trace("step path done")
 
+    actor_leg = None
+    if rank == 0 and world == 1 and args.mode == "rollout" and args.workload == "ddpg" and not args.no_actor_leg:
+        actor_leg = measure_actor_in_loop(args, n_local, dev, seed, streams)
+        trace("actor-in-the-loop leg done")
+
     power = None
     if rank == 0 and world == 1 and args.mode == "rollout" and not args.no_power and not pmc:
         power = measure_power(reg, dev, total)
@@ -849,6 +917,8 @@ def main():
             out["step_path"] = step_path
         if mixed is not None:
             out["mixed_trajectory_set"] = mixed
+        if actor_leg is not None:
+            out["actor_in_loop"] = actor_leg
         if power is not None:
             out["power"] = power
         if pmc:

@@ -76,6 +76,14 @@ typedef struct MrsimParams {
     int32_t goal_T;        /*   = MR_Env.init_goal, MR_env.py:57                                */
     int32_t obs_layout;    /* MRSIM_OBS_*                                                       */
     int32_t noise_math;    /* MRSIM_NOISE_*: how Box-Muller is evaluated (same uniforms either way)    */
+    int32_t auto_reset_fresh_env; /* which env object an auto-reset stands for (ABI 3).  0 (default): the SAME   */
+                           /*   MR_Env re-used, `state = env.reset(...)` at the top of every episode             */
+                           /*   (RL/MR_ddpg.py:270): reset_start_pos builds the RK45 object BEFORE reset() sets  */
+                           /*   is_mismatched (MR_env.py:181-183), i.e. under the law the previous episode left  */
+                           /*   behind = params.mismatched.  1: a fresh MR_Env per episode (utils.run_sim,       */
+                           /*   utils.py:46): the constructor runs under the nominal law.  Same thing unless     */
+                           /*   mismatched != 0.                                                                 */
+    int32_t reserved0;     /* 0                                                                                  */
     const uint64_t* step_base; /* optional DEVICE word added to every step_idx argument.  Kernel      */
                            /*   arguments are frozen inside a captured hipGraph; keeping the base in */
                            /*   HBM (advanced by mrsim_advance_step_base) lets each replay draw new  */

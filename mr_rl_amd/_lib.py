@@ -34,6 +34,7 @@ class MrsimParams(C.Structure):
         ("mismatched", C.c_int32), ("integrator", C.c_int32), ("substeps", C.c_int32),
         ("reward_mode", C.c_int32), ("max_timesteps", C.c_int32), ("auto_reset", C.c_int32),
         ("goal_K", C.c_int32), ("goal_T", C.c_int32), ("obs_layout", C.c_int32), ("noise_math", C.c_int32),
+        ("auto_reset_fresh_env", C.c_int32), ("reserved0", C.c_int32),
         ("step_base", C.c_void_p),
     ]
 
@@ -124,7 +125,7 @@ def load(path):
             getattr(L, name).restype = C.c_int
     if L.mrsim_abi_version() != ABI_VERSION:
         raise ImportError(f"{path}: ABI {L.mrsim_abi_version()} != binding ABI {ABI_VERSION}")
-    assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 10 + 8
+    assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 12 + 8
     assert C.sizeof(MrsimRolloutIO) == 8 + 8 * 11 + 8 + 4 + 4 + 8
     assert C.sizeof(MrsimActor) == 32 and C.sizeof(MrsimActorWeights) == 48 + 28 + 4
     return L

@@ -64,8 +64,11 @@ class RolloutCollector:
 
     # ------------------------------------------------------------------------------------------------------------
     def reset(self, **kw):
-        """MR_Env.reset of every env (current stream); the sub-shard streams start behind it."""
+        """MR_Env.reset of every env (current stream); the sub-shard streams start behind it.  Launches still in flight on
+        the sub-shard streams read and write the state the reset kernel is about to overwrite: the current stream waits for
+        them first (join), so reset() may follow collect() directly."""
         import torch
+        self.join()
         obs = self.env.reset(**kw)
         self._start_ev.record(torch.cuda.current_stream(self.env.device))
         for st in self.streams:

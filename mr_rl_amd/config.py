@@ -38,6 +38,10 @@ class MRConfig:
     substeps: int = 1
     reward_mode: str = "constant10"       # constant10 (MR_env.py:89) | goal (calculate_reward, :118-134)
     auto_reset: bool = False
+    auto_reset_env: str = "reused"        # what an auto-reset stands for: "reused" = the same MR_Env object reset at the top of
+                                          # every episode (RL/MR_ddpg.py:270): the RK45 constructor inside reset runs under the
+                                          # law the previous episode left behind (MR_env.py:181-183); "fresh" = a new MR_Env
+                                          # per episode (utils.run_sim): nominal-law constructor.  Differs only if is_mismatched.
     obs_layout: str = "aos"               # storage of obs: [N,5] rows or [5,N] planes (returned view is [N,5])
     noise_math: str = "fast"              # Box-Muller on hardware transcendentals | "spec": bit-identical to the oracle
     rollout_carry: str = "f32"            # fused rollout: "f32" = carried RK45 state rounded per step (bit-identical to
@@ -66,6 +70,9 @@ class MRConfig:
         p.reward_mode = REWARD_MODES[self.reward_mode]
         p.max_timesteps = int(self.max_timesteps)
         p.auto_reset = int(bool(self.auto_reset))
+        if self.auto_reset_env not in ("reused", "fresh"):
+            raise ValueError("auto_reset_env must be 'reused' or 'fresh'")
+        p.auto_reset_fresh_env = int(self.auto_reset_env == "fresh")
         p.goal_K, p.goal_T = int(goal_K), int(goal_T)
         p.obs_layout = OBS_LAYOUTS[self.obs_layout]
         p.noise_math = NOISE_MATH[self.noise_math]

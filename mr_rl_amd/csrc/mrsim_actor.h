@@ -101,10 +101,37 @@ __device__ __forceinline__ void lds_load16(const float* __restrict__ p, act_f32x
     v = act_f32x16{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
 }
 
+// ReLU as ONE instruction: v_med3_f32(x, 0, +inf) = max(x, 0) for every non-NaN x.  (__builtin_fmaxf canonicalises its
+// operand first: two v_max per activation.  An inline-asm v_max_f32 is NOT an option: the hazard recogniser cannot see
+// into asm, does not pad the MFMA-result -> VALU-read wait states, and the read returns the accumulator's old value --
+// measured: actions off by 5e-4 in one kernel instantiation and right in another.)
+__device__ __forceinline__ float act_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+
+// The layer-2 A operands of this lane (its 2 x 32 weights W2[32 rt + (lane & 31)][kperm(q, lane >> 5)]) as registers:
+// a fused rollout loads them once per launch instead of once per tile and step (16 ds_read_b128 per tile pass whose
+// latency a wave alone on its SIMD cannot hide).
+struct ActorRegs {
+    float a2[2][32];
+};
+__device__ __forceinline__ void actor_load_regs(const float* __restrict__ sA, ActorRegs& R) {
+    const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const act_f32x4 a4 = *reinterpret_cast<const act_f32x4*>(sA + kActA2 + ((rt * 8 + s4) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) R.a2[rt][4 * s4 + j] = a4[j];
+        }
+}
+
 // actor.predict for the 64 envs of this wave.  obs: this lane's env's observation (already scaled if the caller scales);
 // a[2]: scaled_out of this lane's env.  Must be called by ALL 64 lanes in uniform control flow (MFMA and
 // v_permlane32_swap are wave-wide operations); lanes without an env pass any finite values.
-__device__ __forceinline__ void actor_forward(const float* __restrict__ sA, const float (&obs)[5], float (&a)[2]) {
+// REGS: layer-2 weights come from `R` (actor_load_regs) instead of LDS.
+template <bool REGS>
+__device__ __forceinline__ void actor_forward(const float* __restrict__ sA, const ActorRegs& R, const float (&obs)[5],
+                                              float (&a)[2]) {
     // layer-1 B operands: at k-step s lane (j, h) of column tile ct supplies obs[2 s + h] of env 32 ct + j.  One half swap
     // per k-step pair turns "lane = env" registers into both tiles' operands: {x[2s].lo | x[2s+1].lo}, {x[2s].hi | x[2s+1].hi}.
     float b1op[2][3];
@@ -140,15 +167,18 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
         for (int rt = 0; rt < 2; ++rt) lds_load16(sA + kActC2 + h * 32 + rt * 16, acc2[rt]);
 #pragma unroll
         for (int s4 = 0; s4 < 8; ++s4) {
+            act_f32x4 a4[2];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const act_f32x4 a4 = *reinterpret_cast<const act_f32x4*>(sA + kActA2 + ((rt * 8 + s4) * 64 + lane) * 4);
+                if constexpr (REGS) a4[rt] = act_f32x4{R.a2[rt][4 * s4], R.a2[rt][4 * s4 + 1], R.a2[rt][4 * s4 + 2], R.a2[rt][4 * s4 + 3]};
+                else a4[rt] = *reinterpret_cast<const act_f32x4*>(sA + kActA2 + ((rt * 8 + s4) * 64 + lane) * 4);
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int q = 4 * s4 + j;
-                    const float b = __builtin_fmaxf(acc1[q / 16][q % 16], 0.0f);  // ReLU of layer 1, in place
-                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b, acc2[rt], 0, 0, 0);
-                }
+            for (int j = 0; j < 4; ++j) {
+                const int q = 4 * s4 + j;
+                const float b = act_relu(acc1[q / 16][q % 16]);  // ReLU of layer 1
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt][j], b, acc2[rt], 0, 0, 0);
             }
         }
         // output layer on the vector unit: this lane's 32 features of env (32 ct + j), two partial sums per output
@@ -160,7 +190,7 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int q = 4 * q4 + j;
-                const float hq = __builtin_fmaxf(acc2[q / 16][q % 16], 0.0f);
+                const float hq = act_relu(acc2[q / 16][q % 16]);
                 p0 = __builtin_fmaf(w0[j], hq, p0);
                 p1 = __builtin_fmaf(w1[j], hq, p1);
             }

@@ -56,7 +56,7 @@ struct KParams {
     float act_lo_f[2], act_span_f[2];
     double h1_thresh;  // 0.01 / dt^5 : select_initial_step's h1 >= dt  <=>  max(d1,d2) <= h1_thresh
     double h1_thresh_m;    // h1_thresh / 1.05                  (first-level tests, 5 % margins)
-    double k_h0;           // 105 * dt: |y| >= k_h0 * F  =>  0.01 * d0/d1 >= dt, i.e. h0 == dt
+    double k_h0;           // max(105 * dt, 1): |y| >= k_h0 * F  =>  0.01 * d0/d1 >= dt, i.e. h0 == dt, and |y| >= 2e-5 max(scale)
     double gmax_dt;        // 2 * Zmax * sigma / dt: worst case of |f1 - f0| / dt under the nominal law
     double reset_fmin;     // >= 0: over the whole init box construct_level0 of a nominal reset constructor reduces to
                            // max|f0| >= reset_fmin (make_kparams certifies the other three conditions); < 0: not certified
@@ -85,6 +85,7 @@ enum : uint32_t {
     // policy source = the in-kernel DDPG actor (mrsim_actor.h); + Ornstein-Uhlenbeck exploration noise; + OU state zeroed at
     // the first step of every episode (the reference never resets the process, RL/MR_ddpg.py:270-311)
     kFActor = 1u << 21, kFActorOU = 1u << 22, kFOUReset = 1u << 23,
+    kFResetFresh = 1u << 24,  // auto-reset = a fresh MR_Env (nominal-law constructor) instead of the re-used one
 };
 __device__ __forceinline__ uint32_t live_flags(uint32_t f) {
     asm volatile("" : "+s"(f));
@@ -1290,8 +1291,17 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         // different steps, so some lane of almost every wave resets at almost every step.  With the constant goal all
         // episodes of the DDPG workload end together every max_timesteps + 1 steps, and its flag-specialised kernel keeps
         // the code (and the register allocation of its time loop) it had.
-        reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry, wr, (fl & kFOutStatePrime) != 0,
-                                   /*in_init_box=*/(fl & kFGoalTable) != 0);
+        // Which law the RK45 constructor inside reset runs under (MR_env.py:181-183 sets is_mismatched AFTER
+        // reset_start_pos): the re-used env object of an episode loop (RL/MR_ddpg.py:270) still carries the previous
+        // episode's law -- under is_mismatched the stale first stage of the new episode is the drift (0.2, -0.1) (+ noise) --
+        // a fresh env (kFResetFresh) the nominal one.
+        const bool need_sp = (fl & kFOutStatePrime) != 0;
+        if constexpr (MIS) {
+            if (fl & kFResetFresh) reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry, wr, need_sp, (fl & kFGoalTable) != 0);
+            else reset_env<RK45, NZ, true>(P, R, x0, y0, e, rx, ry, wr, need_sp, false);
+        } else {
+            reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry, wr, need_sp, /*in_init_box=*/(fl & kFGoalTable) != 0);
+        }
         if constexpr (RK45) { o.spx = (float)rx; o.spy = (float)ry; }  // state_prime = last RHS value
         if (goal0_pre != nullptr) { gx = (double)goal0_pre->x; gy = (double)goal0_pre->y; }  // row 0: loaded once per launch
         else goal_at(P, fl, goal_table, R.env, 0, gx, gy);

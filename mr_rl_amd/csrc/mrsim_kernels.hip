@@ -43,12 +43,13 @@ __device__ __forceinline__ void obs_from_state(const KParams& P, uint32_t fl, co
 }
 
 // action = actor.predict(obs) + actor_noise()  (RL/MR_ddpg.py:277) for this lane's env; all 64 lanes call it
-template <int OUNZ>
+template <int OUNZ, bool REGS = false>
 __device__ __forceinline__ void actor_policy(const KParams& P, uint32_t fl, const ActorArgs& ac, const float* __restrict__ s_actor,
                                              const float (&obs)[5], int32_t counter, const uint32_t* w, float& ou0, float& ou1,
-                                             float& af, float& aa) {
+                                             float& af, float& aa, const ActorRegs* regs = nullptr) {
     float a[2];
-    actor_forward(s_actor, obs, a);
+    if constexpr (REGS) actor_forward<true>(s_actor, *regs, obs, a);
+    else { ActorRegs none; actor_forward<false>(s_actor, none, obs, a); }
     af = a[0]; aa = a[1];
     if (fl & kFActorOU) {
         if ((fl & kFOUReset) && counter == 0) ou0 = ou1 = 0.0f;
@@ -334,6 +335,11 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     }
     float obs_cur[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float ou0 = 0.f, ou1 = 0.f;
+#ifndef MRSIM_ACTOR_A2REG   // 1: the fused rollout keeps the lane's 64 layer-2 weights in registers for the whole launch (measured:
+#define MRSIM_ACTOR_A2REG 0 // 1081 us at two waves per SIMD against 1055 us with the weights re-read from LDS; four waves: 1014 us)
+#endif
+    ActorRegs aregs;
+    if constexpr (ACT && MRSIM_ACTOR_A2REG) actor_load_regs(s_actor, aregs);
     if constexpr (ACT) {
         obs_from_state(P, FL != 0 ? FL : P.flags, ra.goal_table, P.env_id0 + (uint32_t)i, e, obs_cur);
         if ((FL != 0 ? FL : P.flags) & kFActorOU) {
@@ -370,7 +376,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
             af = a.x; aa = a.y;
         }
         step_prologue<RK45, NZ, MIS>(P, R, !ACT && !(fl & kFActions), W, af, aa, ACT && (fl & kFActorOU));
-        if constexpr (ACT) actor_policy<ou_nz<NZ>()>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
+        if constexpr (ACT) actor_policy<ou_nz<NZ>(), MRSIM_ACTOR_A2REG != 0>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa, &aregs);
         if (!(fl & kFActions64)) { adf = (double)af; ada = (double)aa; }
         StepOut o;
         env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr);
@@ -456,15 +462,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     rollout_body<RK45, NZ, MIS, FL, false>(P, st, ra, ActorArgs{nullptr, nullptr, {0.f, 0.f}});
 }
 
-// The same loop with the actor as its policy source.  No occupancy floor: the two 32-register accumulator tiles of a layer
-// and the env state do not fit the 128 registers that four waves per SIMD leave, and the kernel is bound by the matrix
-// pipe (140 f32 MFMAs of 64 cycles per wave and step), which two waves per SIMD already keep busy.
+// The same loop with the actor as its policy source.  Register budget: two 32-register accumulator tiles of the layer
+// being computed + the env state.  The flag-specialised DDPG collection kernel fits four waves per SIMD with 7 - 8 spilled
+// dwords (measured faster than three waves without spills, 1014 vs 1096 us per 51-step launch at N = 262 144: that launch
+// is exactly four waves per SIMD, so three resident waves leave a fourth to run alone); the generic instantiations
+// (test-oriented modes) take three.  The kernel is bound by the matrix pipe: 140 f32 MFMAs of 64 cycles per wave and step.
 #ifndef MRSIM_ACTOR_WAVES
-#define MRSIM_ACTOR_WAVES 2
+#define MRSIM_ACTOR_WAVES 4
+#endif
+#ifndef MRSIM_ACTOR_WAVES_GENERIC
+#define MRSIM_ACTOR_WAVES_GENERIC 3
 #endif
 template <bool RK45, int NZ, bool MIS, uint32_t FL = 0>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES, 8))) void mr_rollout_actor_kernel(const KParams P, const StateArgs st, const RolloutArgs ra,
-                                                                  const ActorArgs ac) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES_GENERIC, 8))) void mr_rollout_actor_kernel(
+    const KParams P, const StateArgs st, const RolloutArgs ra, const ActorArgs ac) {
+    rollout_body<RK45, NZ, MIS, FL, true>(P, st, ra, ac);
+}
+template <bool RK45, int NZ, bool MIS, uint32_t FL>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES, 8))) void mr_rollout_actor_fl_kernel(
+    const KParams P, const StateArgs st, const RolloutArgs ra, const ActorArgs ac) {
     rollout_body<RK45, NZ, MIS, FL, true>(P, st, ra, ac);
 }
 
@@ -609,14 +625,18 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
         if (!(p->obs_high[j] == K.sym_bound && p->obs_low[j] == -K.sym_bound)) sym = false;
     K.flags = (sym ? kFSymBounds : 0u) | (p->auto_reset ? kFAutoReset : 0u) |
               (p->reward_mode == MRSIM_REW_GOAL ? kFRewardGoal : 0u) | (p->step_base ? kFStepBase : 0u) |
-              (p->obs_layout == MRSIM_OBS_AOS ? kFObsAos : 0u) | (p->integrator == MRSIM_INT_RK4 ? kFRk4 : 0u);
+              (p->obs_layout == MRSIM_OBS_AOS ? kFObsAos : 0u) | (p->integrator == MRSIM_INT_RK4 ? kFRk4 : 0u) |
+              ((p->auto_reset_fresh_env && p->mismatched) ? kFResetFresh : 0u);  // only ever read by the mismatched kernels
     for (int j = 0; j < 2; ++j) {
         K.init_lo[j] = p->init_low[j]; K.init_span[j] = p->init_high[j] - p->init_low[j];
         K.act_lo_f[j] = (float)p->act_low[j]; K.act_span_f[j] = (float)(p->act_high[j] - p->act_low[j]);
     }
     K.h1_thresh = 0.01 / std::pow(p->time_span, 5.0);
     K.h1_thresh_m = K.h1_thresh / 1.05;
-    K.k_h0 = 105.0 * p->time_span;
+    // |coordinate| >= k_h0 F certifies h0 == dt (needs >= 105 dt) AND, with F >= c = 2e-5 max(scale), that the coordinate
+    // itself is >= c, which rules out select_initial_step's d0 < 1e-5 branch (needs k_h0 >= 1): for time_span < 0.0095
+    // the second requirement is the stronger one.  A larger constant only makes the one-sided test harder to pass.
+    K.k_h0 = std::fmax(105.0 * p->time_span, 1.0);
     K.gmax_dt = 2.0 * 6.78 * p->sigma / p->time_span;
     K.zmax2_dt = 2.0 * 6.78 / p->time_span;
     {   // nominal reset constructor on a position sampled from the init box (float32 of lo + span u: within 1e-6 relative
@@ -773,8 +793,8 @@ static int launch_rollout_actor_fl(const LaunchCfg& lc, int nz, bool mis, const 
                                    const RolloutArgs& ra, const ActorArgs& AC, bool& handled) {
     handled = true;
     if (nz == kNoiseFast)
-        return mis ? launch(lc, mr_rollout_actor_kernel<true, kNoiseFast, true, FL>, K.n, K, S, ra, AC)
-                   : launch(lc, mr_rollout_actor_kernel<true, kNoiseFast, false, FL>, K.n, K, S, ra, AC);
+        return mis ? launch(lc, mr_rollout_actor_fl_kernel<true, kNoiseFast, true, FL>, K.n, K, S, ra, AC)
+                   : launch(lc, mr_rollout_actor_fl_kernel<true, kNoiseFast, false, FL>, K.n, K, S, ra, AC);
     handled = false;
     return MRSIM_OK;
 }
@@ -861,6 +881,8 @@ int mrsim_default_params(MrsimParams* p) {
     p->goal_K = 1; p->goal_T = 1;
     p->obs_layout = MRSIM_OBS_AOS;
     p->noise_math = MRSIM_NOISE_FAST;
+    p->auto_reset_fresh_env = 0;            // auto-reset = the same env object re-used (RL/MR_ddpg.py:270)
+    p->reserved0 = 0;
     p->step_base = nullptr;
     return MRSIM_OK;
 }

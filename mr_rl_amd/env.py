@@ -6,6 +6,7 @@ the GPU and is meant for plumbing / parity, not speed -- use MRVecEnv for throug
 """
 import numpy as np
 
+from . import recorder
 from .config import MRConfig
 from .vec_env import MRVecEnv
 
@@ -47,8 +48,11 @@ class MR_Env:
         self.state_prime = None
 
     def seed(self, seed=None):
-        self.init_space.seed(seed) if hasattr(self.init_space, "seed") else None
-        return self._v.seed(seed)
+        """old/MR_dqn_keras_rl.py:19 calls env.seed(n): reseeds the noise stream and the init_space sampler (the
+        constructor's seed= argument does the same, so MR_Env(seed=s).reset() is reproducible without this call)."""
+        out = self._v.seed(seed)
+        self.init_space = self._v.init_space
+        return out
 
     def reset(self, init=None, noise_var=1, a0=1, is_mismatched=False):
         """MR_env.py:164-201 (without its two print() calls)."""
@@ -58,7 +62,12 @@ class MR_Env:
         obs = self._v.reset(init=init[None, :], noise_var=noise_var, a0=a0, is_mismatched=is_mismatched)
         self.last_pos = init
         self.counter = 0
-        return obs[0].double().cpu().numpy()
+        obs = obs[0].double().cpu().numpy()
+        if self.MR_data is not None:                                   # MR_env.py:189-198
+            if self.MR_data.iterations > 0:
+                self.MR_data.save_experiment(self.name_experiment)
+            self.MR_data.new_iter(np.array(init, dtype=np.float64), obs, np.zeros(len(self.last_action)), np.array([0]))
+        return obs
 
     def step(self, action):
         """MR_env.py:70-98: returns (obs[5], rew, done, {})."""
@@ -70,7 +79,16 @@ class MR_Env:
         self.last_action = np.array([f_t, alpha_t])
         self.state_prime = self._v.state_prime[0].double().cpu().numpy()
         r = float(rew[0].item())
-        return obs[0].double().cpu().numpy(), (int(r) if r == int(r) else r), bool(done[0].item()), dict()
+        r = int(r) if r == int(r) else r
+        obs, done = obs[0].double().cpu().numpy(), bool(done[0].item())
+        if self.MR_data is not None:
+            # MR_env.py:145-147: `end` saves the experiment when an episode dies on the bounds or the step limit (the goal
+            # branch does not); :94-95: every transition is recorded -- end() runs before new_transition in step()
+            if done and self.MR_data.iterations > 0 and (self.counter > self.max_timesteps or
+                                                         not self.observation_space.contains(obs.astype(np.float32))):
+                self.MR_data.save_experiment(self.name_experiment)
+            self.MR_data.new_transition(np.array(self.last_pos, dtype=np.float64), obs, self.last_action, r)
+        return obs, r, done, dict()
 
     def render(self, mode="human"):
         return None
@@ -86,8 +104,11 @@ class MR_Env:
         return self.init_goal
 
     def set_save_experice(self, name="experiment_ssn_ddpg_10iter"):
+        """MR_env.py:223-226: from now on reset() / step() record into an MRExperiment-layout recorder and save it to
+        ./_experiments/<date-hour><name> at the reference's trigger points."""
         assert isinstance(name, str), "name must be a string"
-        self.name_experiment = name  # the MRExperiment recorder (MR_data.py) is out of scope
+        self.MR_data = recorder.ExperimentRecorder()
+        self.name_experiment = name
 
     def set_test_performace(self):
         self.test_performance = True

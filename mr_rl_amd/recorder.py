@@ -27,6 +27,51 @@ def _empty():
                 scream=None, obs_states_str={}, time_step=10)
 
 
+class ExperimentRecorder:
+    """The recording half of MR_data.MRExperiment (MR_data.py:9-74) behind MR_Env.set_save_experice: `new_iter` at every
+    reset, `new_transition` at every step, `save_experiment` = pickle (protocol 2) of the same dictionary layout into
+    ./_experiments/<YYYY-mm-dd-HH><name>.  Rows are appended to lists and stacked when read (the reference re-stacks every
+    array on every step); `to_dict()` / the attributes give exactly MRExperiment.__dict__'s content."""
+
+    def __init__(self, info=None):
+        self.iterations, self.info = -1, info
+        self._rows = {}   # it -> {"states": [...], "observations": [...], "actions": [...], "rewards": [...]}
+
+    def new_iter(self, s0, obs0, a0, r0):
+        self.iterations += 1
+        self._rows[self.iterations] = {"states": [np.asarray(s0)], "observations": [np.asarray(obs0)],
+                                       "actions": [np.asarray(a0)], "rewards": [np.asarray(r0)]}
+
+    def new_transition(self, s, obs, a, r):
+        row = self._rows[self.iterations]
+        for key, v in (("states", s), ("observations", obs), ("actions", a), ("rewards", r)):
+            row[key].append(np.asarray(v))
+
+    def _stack(self, key):
+        # one row: the array itself (MRExperiment.new_iter stores s0 unstacked); more: np.vstack, as new_transition does
+        return {it: (rows[key][0] if len(rows[key]) == 1 else np.vstack(rows[key])) for it, rows in self._rows.items()}
+
+    states = property(lambda self: self._stack("states"))
+    observations = property(lambda self: self._stack("observations"))
+    actions = property(lambda self: self._stack("actions"))
+    rewards = property(lambda self: self._stack("rewards"))
+    steps = property(lambda self: {it: len(rows["states"]) - 1 for it, rows in self._rows.items()})
+
+    def to_dict(self):
+        d = _empty()
+        d.update(iterations=self.iterations, states=self.states, observations=self.observations, actions=self.actions,
+                 rewards=self.rewards, steps=self.steps, info=self.info)
+        return d
+
+    def save_experiment(self, descr="_experiment"):
+        import datetime
+        import os
+        os.makedirs("_experiments", exist_ok=True)
+        path = os.path.join("_experiments", datetime.datetime.now().strftime("%Y-%m-%d-%H") + descr)
+        save_experiment(self.to_dict(), path)
+        return path
+
+
 def _rewards_column(rew, integer):
     r = np.asarray(rew, np.float64)
     col = np.vstack([np.array([0.0]), r[:, None]]) if len(r) else np.array([[0.0]])

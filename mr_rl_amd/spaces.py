@@ -28,11 +28,19 @@ class Box:
         return f"Box({self.low}, {self.high}, {self.shape}, {self.dtype})"
 
 
-def make_box(low, high):
+def make_box(low, high, seed=None):
+    """seed: seeds the space's own sampler (MR_Env.reset(init=None) draws init_space.sample(), MR_env.py:172-173), so two
+    envs built with the same seed start in the same places without a separate env.seed() call."""
+    box = None
     for mod in ("gymnasium", "gym"):
         try:
             spaces = __import__(mod + ".spaces", fromlist=["Box"])
-            return spaces.Box(low=np.asarray(low, dtype=np.float32), high=np.asarray(high, dtype=np.float32))
+            box = spaces.Box(low=np.asarray(low, dtype=np.float32), high=np.asarray(high, dtype=np.float32))
+            break
         except Exception:
             continue
-    return Box(low, high)
+    if box is None:
+        box = Box(low, high)
+    if seed is not None:
+        box.seed(int(seed))
+    return box

@@ -66,7 +66,7 @@ class MRVecEnv:
         # spaces (MR_env.py:34-45)
         self.action_space = make_box(self.cfg.action_low, self.cfg.action_high)
         self.observation_space = make_box(self.cfg.obs_low, self.cfg.obs_high)
-        self.init_space = make_box(self.cfg.init_low, self.cfg.init_high)
+        self.init_space = make_box(self.cfg.init_low, self.cfg.init_high, seed=self.seed_value)
         self.max_timesteps = self.cfg.max_timesteps
         self.min_dist2goal = self.cfg.min_dist2goal
 
@@ -168,6 +168,7 @@ class MRVecEnv:
         """keras-rl era callers use env.seed(n) (old/MR_dqn_keras_rl.py:19)."""
         if seed is not None:
             self.seed_value = int(seed)
+            self.init_space.seed(self.seed_value)   # MR_Env.reset(init=None) samples from it (MR_env.py:172-173)
         return [self.seed_value]
 
     # ------------------------------------------------------------------ gym API
@@ -532,7 +533,7 @@ class MRVecEnv:
     def set_init_space(self, low, high):
         """MR_env.py:154-155."""
         self.cfg.init_low, self.cfg.init_high = tuple(float(x) for x in low), tuple(float(x) for x in high)
-        self.init_space = make_box(self.cfg.init_low, self.cfg.init_high)
+        self.init_space = make_box(self.cfg.init_low, self.cfg.init_high, seed=self.seed_value)
         self._refresh_params()
 
     def set_goal(self, init=None):
@@ -543,12 +544,15 @@ class MRVecEnv:
     _CFG_STATE = ("noise_var", "a0", "is_mismatched", "init_low", "init_high")  # what reset() / set_init_space change
 
     def state_dict(self):
-        """Everything a resumed env needs to continue bit for bit: the per-env state, the RNG position -- host
+        """Everything a resumed env needs to continue bit for bit: the per-env state, the outputs of the latest step /
+        reset that a gym-style loop reads before its next action (obs, rew, done, final_*, status), the RNG position -- host
         step_idx plus, once capture_steps() / enable_device_step_base() moved the counter into HBM, the device word
         it lives in -- and the cfg fields reset() kwargs and set_init_space() may have changed."""
         sb = getattr(self, "_step_base", None)
         return {"pos": self.pos.clone(), "aux": self.aux.clone(), "ep_ret": self.ep_ret.clone(),
                 "final_ret": self.final_ret.clone(), "final_len": self.final_len.clone(),
+                "obs": self._obs.clone(), "final_obs": self._final_obs.clone(), "rew": self.rew.clone(),
+                "done": self._done_u8.clone(), "status": self.status.clone(), "obs_layout": self.cfg.obs_layout,
                 "step_idx": self.step_idx, "step_base": None if sb is None else int(sb.item()),
                 "seed": self.seed_value, "env_id0": self.env_id0, "prev_mismatched": self._prev_mismatched,
                 "cfg": {k: getattr(self.cfg, k) for k in self._CFG_STATE}}
@@ -557,11 +561,14 @@ class MRVecEnv:
         self.pos.copy_(sd["pos"]); self.aux.copy_(sd["aux"]); self.ep_ret.copy_(sd["ep_ret"])
         if "final_ret" in sd:
             self.final_ret.copy_(sd["final_ret"]); self.final_len.copy_(sd["final_len"])
+        if "obs" in sd and sd.get("obs_layout") == self.cfg.obs_layout:
+            self._obs.copy_(sd["obs"]); self._final_obs.copy_(sd["final_obs"]); self.rew.copy_(sd["rew"])
+            self._done_u8.copy_(sd["done"]); self.status.copy_(sd["status"])
         self.seed_value, self.env_id0 = int(sd["seed"]), int(sd["env_id0"])
         self._prev_mismatched = bool(sd["prev_mismatched"])
-        for k, v in sd.get("cfg", {}).items():
-            setattr(self.cfg, k, v)
-        self.init_space = make_box(self.cfg.init_low, self.cfg.init_high)
+        import dataclasses
+        self.cfg = dataclasses.replace(self.cfg, **sd.get("cfg", {}))   # the caller's MRConfig object is left alone
+        self.init_space = make_box(self.cfg.init_low, self.cfg.init_high, seed=self.seed_value)
         # RNG position = step_base (device word, if this env keeps one) + step_idx; restore it in whichever form THIS
         # env uses, so a checkpoint taken behind a captured graph resumes on an eager env and vice versa
         total = int(sd["step_idx"]) + int(sd.get("step_base") or 0)

@@ -600,15 +600,17 @@ int orc_env_step(const OrcParams* p, OrcEnv* e, const float* goal_table, double 
     *rew = r; *done = (uint8_t)d;
     if (d && p->auto_reset) {
         /* build extension: same-step auto-reset.  Terminal obs/return/length go to the
-         * final_* outputs, the env restarts as MR_Env.reset(init=None) would on a fresh
-         * env (nominal law in the constructor, MR_env.py:181-183) and the RETURNED obs is
+         * final_* outputs, the env restarts as MR_Env.reset(init=None) would on the re-used
+         * env object (auto_reset_fresh_env = 0) or on a fresh one (= 1; MR_env.py:181-183) and the RETURNED obs is
          * the reset observation. */
         if (final_obs) memcpy(final_obs, obs, 5 * sizeof(double));
         if (final_ret) *final_ret = e->ep_ret;
         if (final_len) *final_len = e->counter;
         double xy[2];
         orc_sample_init(p, nz->seed, env_id, nz->step_idx, xy);
-        orc_env_reset(p, e, goal_table, xy[0], xy[1], 0, nz, env_id, obs);
+        /* MR_env.py:181-183: reset_start_pos runs BEFORE is_mismatched is assigned, so the env object an episode loop
+         * re-uses builds its RK45 under the previous episode's law; a fresh object under the nominal one */
+        orc_env_reset(p, e, goal_table, xy[0], xy[1], (p->mismatched && !p->auto_reset_fresh_env) ? 1 : 0, nz, env_id, obs);
     }
     return 0;
 }

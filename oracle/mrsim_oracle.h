@@ -55,6 +55,10 @@ typedef struct {
     int32_t auto_reset;    /* build extension: re-draw init and reset in the same step  */
     int32_t goal_K;        /* goal table [K][T][2] (float); K = T = 1, (0,0) = reference */
     int32_t goal_T;
+    int32_t auto_reset_fresh_env; /* 0: an auto-reset is reset() on the SAME env object (RL/MR_ddpg.py:270): the RK45   */
+                           /*    constructor runs under the law the previous episode left (MR_env.py:181-183);     */
+                           /*    1: a fresh MR_Env per episode (nominal-law constructor)                           */
+    int32_t reserved0;
 } OrcParams;
 
 /* One environment = one MR_Env + its Simulator + its live RK45 object. */

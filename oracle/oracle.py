@@ -26,7 +26,7 @@ class OrcParams(C.Structure):
         ("init_low", C.c_double * 2), ("init_high", C.c_double * 2),
         ("mismatched", C.c_int32), ("integrator", C.c_int32), ("substeps", C.c_int32),
         ("reward_mode", C.c_int32), ("max_timesteps", C.c_int32), ("auto_reset", C.c_int32),
-        ("goal_K", C.c_int32), ("goal_T", C.c_int32),
+        ("goal_K", C.c_int32), ("goal_T", C.c_int32), ("auto_reset_fresh_env", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

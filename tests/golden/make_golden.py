@@ -21,6 +21,9 @@ them is copied.  What is committed is data: inputs and the reference's outputs.
                 out-of-bounds termination is therefore documented as
                 "parity unpinned (gym absent)" in DESIGN.md.     (G6, G7)
 
+  ref_reused.npz  ONE MR_Env object driven through three consecutive episodes with reset(is_mismatched=True) each time
+                (the loop shape of RL/MR_ddpg.py:270-311): from the second episode on reset_start_pos builds the RK45
+                object under the law the PREVIOUS episode left behind (MR_env.py:181-183), sigma = 0 and one taped sigma > 0 run.
   ref_sim_f64.npz  the ref_sim scenarios with the reference's own float64 action tables (not rounded to float32).
   ref_experiment.npz  MR_data.MRExperiment's dictionaries after three recorded MR_Env episodes (8f-3).
 
@@ -363,11 +366,61 @@ def gen_experiment():
           "keys", sorted(d.keys()))
 
 
+def gen_reused():
+    """One env object, several episodes (`state = env.reset(...)` at the top of every episode, RL/MR_ddpg.py:270).  Every
+    episode starts at the same float32-representable point, so a vec env whose init box is that single point replays it
+    through its in-kernel auto-reset."""
+    _install_standins()
+    import contextlib
+    import io
+    import MR_env  # noqa: E402 (reference, unmodified)
+    rng = np.random.default_rng(909)
+    flat = {}
+    init = np.array([110.5, 104.25])
+    n_ep, max_steps = 3, 60
+    for name, sigma, mis, a0 in (("reused_mis_s0", 0.0, True, 1.5), ("reused_mis_s05", 0.5, True, 1.0),
+                                 ("reused_nom_s0", 0.0, False, 1.0)):
+        actions = f32(actions_random(n_ep * max_steps, rng, idle_frac=0.05))
+        env = MR_env.MR_Env()
+        np.random.seed(4321)
+        rows = dict(pos=[], obs=[], done=[], counter=[], episode=[], reset_f=[], reset_h_abs=[], f=[], h_abs=[])
+        used = []
+        with _Tape() as tape:
+            k = 0
+            for ep in range(n_ep):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    env.reset(init=init.copy(), noise_var=sigma, a0=a0, is_mismatched=mis)
+                rows["reset_f"].append(np.array(env.simulator.integrator.f, dtype=np.float64))
+                rows["reset_h_abs"].append(float(env.simulator.integrator.h_abs))
+                for j in range(max_steps):
+                    a = actions[k]; k += 1
+                    used.append(a)
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        o, r, d, _ = env.step(a)
+                    rows["pos"].append(np.array(env.last_pos, dtype=np.float64)); rows["obs"].append(np.array(o, dtype=np.float64))
+                    rows["done"].append(int(d)); rows["counter"].append(env.counter); rows["episode"].append(ep)
+                    rows["f"].append(np.array(env.simulator.integrator.f, dtype=np.float64))
+                    rows["h_abs"].append(float(env.simulator.integrator.h_abs))
+                    if d:
+                        break
+        d = dict(init=init, a0=a0, sigma=sigma, mismatched=int(mis), actions=np.asarray(used), tape=np.asarray(tape.vals),
+                 **{k2: np.asarray(v) for k2, v in rows.items()})
+        for key, v in d.items():
+            flat[f"{name}/{key}"] = np.asarray(v)
+        print(f"  {name}: {len(used)} steps over {n_ep} episodes, {len(tape.vals)} draws, reset f = {rows['reset_f']}")
+    np.savez_compressed(os.path.join(HERE, "ref_reused.npz"), **flat)
+    print("ref_reused.npz written")
+
+
 if __name__ == "__main__":
     import scipy
     print(f"numpy {np.__version__}, scipy {scipy.__version__}, reference at {REF}")
+    if len(sys.argv) > 1 and sys.argv[1] == "reused":
+        gen_reused()
+        sys.exit(0)
     gen_sim()
     gen_sim(round_f32=False)
     gen_noise()
     gen_env()
     gen_experiment()
+    gen_reused()

@@ -638,6 +638,26 @@ def test_collector_prime_only_warms_the_launch_cache():
 # law x sigma x init box x reward mode x episode length x layout x launch form)
 # ----------------------------------------------------------------------------------------------------------------------
 def _random_case(k):
+    """k < 16: spec noise (normals bit-identical to the oracle's).  16 <= k < 24: the first eight again with the default
+    noise_math="fast" (the straight-line fast step and its fallback to the general path are only compiled for it).
+    24 <= k < 28: time_span 1 - 8 ms with a coordinate near zero: the first-level constructor test must not certify
+    h_abs = dt where select_initial_step takes its d0 < 1e-5 branch (h0 = 1e-6)."""
+    if k >= 24:
+        rng = np.random.default_rng(5000 + k)
+        ts = [0.002, 0.004, 0.001, 0.008][k - 24]
+        lo, hi = [((-2e-5, 40.0), (2e-5, 60.0)), ((-50.0, -1e-4), (-30.0, 1e-4)), ((-1e-6, -1e-6), (1e-6, 1e-6)),
+                  ((-3e-4, 100.0), (3e-4, 120.0))][k - 24]
+        return dict(noise_var=float([0.0, 0.3, 1.0, 0.05][k - 24]), a0=1.0, is_mismatched=bool(k & 1), init_low=lo,
+                    init_high=hi, time_span=ts, max_timesteps=20, auto_reset=True, noise_math="spec"), 30, rng
+    fast = k >= 16
+    k = k - 16 if fast else k
+    kw, T, rng = _random_case_spec(k)
+    if fast:
+        kw["noise_math"] = "fast"
+    return kw, T, rng
+
+
+def _random_case_spec(k):
     rng = np.random.default_rng(1000 + k)
     boxes = [((100.0, 100.0), (120.0, 120.0)),        # the reference's init space
              ((-40.0, -40.0), (40.0, 40.0)),          # crosses both axes: step-size control splits steps, goal reach (d < 30)
@@ -652,7 +672,7 @@ def _random_case(k):
                 obs_layout=("soa" if rng.integers(3) == 0 else "aos"), noise_math="spec"), T, rng
 
 
-@pytest.mark.parametrize("k", range(16))
+@pytest.mark.parametrize("k", range(28))
 def test_randomised_config_vs_oracle(k):
     """16 seeded configurations, 600 envs each (not a multiple of the wave or block size), spec noise (normals bit-identical
     to the oracle's): odd cases are driven through step() -- explicit actions and the in-kernel policy alternating -- even
@@ -664,8 +684,11 @@ def test_randomised_config_vs_oracle(k):
     kw, T, rng = _random_case(k)
     n = 600
     cfg = MRConfig(**kw)
-    env = MRVecEnv(n, cfg=cfg, seed=77 + k, env_id0=1000 * k)
-    orc = O.VecOracle(n, orc_params_from_cfg(cfg), seed=77 + k, env_id0=1000 * k)
+    pos_tol = 5e-6 if cfg.noise_math == "fast" else 1e-6     # POS_TOL_FAST / POS_TOL of test_gpu_parity.py
+    margin_tol = 1e-5 if cfg.noise_math == "fast" else 1e-6  # fast normals move error_norm by ~1e-6 relative
+    k_orig, k = k, (k - 16 if 16 <= k < 24 else k)
+    env = MRVecEnv(n, cfg=cfg, seed=77 + k_orig, env_id0=1000 * k)
+    orc = O.VecOracle(n, orc_params_from_cfg(cfg), seed=77 + k_orig, env_id0=1000 * k)
     og = env.reset(); oo = orc.reset(0)
     og = og.cpu().numpy()   # [N, 5] whatever the layout in HBM (a transposed view for "soa")
     np.testing.assert_array_equal(env.pos.cpu().numpy(), orc.envs["y"])
@@ -676,18 +699,19 @@ def test_randomised_config_vs_oracle(k):
 
     ndone = [0]
 
-    def check(t, pos, obs, rew, done):
+    def check(t, pos, obs, rew, done, ref_pos=None):
         ndone[0] += int(orc.done.sum())
-        bad = alive & ~(np.abs(pos - orc.envs["y"]).max(axis=1) <= 1e-6)
+        ref_pos = orc.envs["y"] if ref_pos is None else ref_pos
+        bad = alive & ~(np.abs(pos - ref_pos).max(axis=1) <= pos_tol)
         for i in np.nonzero(bad)[0]:
-            if not (orc.envs["err_margin"][i] < 1e-6):
+            if not (orc.envs["err_margin"][i] < margin_tol):
                 unexplained.append((t, int(i), float(orc.envs["err_margin"][i])))
         alive[bad] = False
         a = alive
         np.testing.assert_array_equal(done[a].astype(np.uint8), orc.done[a], err_msg=f"done, step {t}")
         np.testing.assert_array_equal(rew[a], orc.rew[a].astype(np.float32), err_msg=f"rew, step {t}")
         want = orc.obs[a].astype(np.float32)
-        tol = 2 * np.spacing(np.abs(want)) + 1e-6
+        tol = 2 * np.spacing(np.abs(want)) + pos_tol
         tol[:, 4] += 1e-3 * (np.abs(want[:, 4]) > 1000)   # sqrt of ~5e7 in fp32 hardware sqrt: 1 ulp of 7000 = 5e-4
         assert (np.abs(obs[a].astype(np.float64) - want) <= tol).all(), f"obs, step {t}"
 
@@ -716,10 +740,17 @@ def test_randomised_config_vs_oracle(k):
                 orc.step(a_o, step_idx=t + j + 1)
                 obs = r["obs"][j].cpu().numpy()
                 pos = r["traj"][j].cpu().numpy()
-                if cfg.auto_reset:   # traj holds the position BEFORE the auto-reset; the oracle's y the one after it
+                ref = None
+                if cfg.auto_reset:   # traj holds the position BEFORE the auto-reset: the oracle's terminal observation
                     d = orc.done.astype(bool)
-                    pos = np.where(d[:, None], orc.envs["y"], pos) if j < m - 1 else env.pos.cpu().numpy()
-                check(t + j, pos, obs, r["rew"][j].cpu().numpy(), r["done"][j].cpu().numpy())
+                    ref = np.where(d[:, None], orc.final_obs[:, :2], orc.envs["y"])
+                check(t + j, pos, obs, r["rew"][j].cpu().numpy(), r["done"][j].cpu().numpy(), ref_pos=ref)
+                if cfg.auto_reset and j == m - 1:   # ... and the state the launch leaves behind is the one AFTER it
+                    post_bad = alive & ~(np.abs(env.pos.cpu().numpy() - orc.envs["y"]).max(axis=1) <= pos_tol)
+                    for i in np.nonzero(post_bad)[0]:
+                        if not (orc.envs["err_margin"][i] < margin_tol):
+                            unexplained.append((t + j, int(i), "state after the launch"))
+                    alive[post_bad] = False
             t += m
             np.testing.assert_array_equal(env.counter.cpu().numpy()[alive], orc.envs["counter"][alive])
     assert not unexplained, (kw, unexplained[:6])

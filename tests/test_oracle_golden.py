@@ -122,3 +122,63 @@ def test_run_sim_tuple(name):
     np.testing.assert_allclose(np.linspace(0, (T - 1) / 30.0, T), G["time"], rtol=0, atol=0)
     np.testing.assert_array_equal(G["alpha"], G["actions"][:, 1])
     np.testing.assert_array_equal(G["freq"], G["actions"][:, 0])
+
+
+REUSED = load_cases("ref_reused.npz")
+
+
+def _replay_reused(G, fresh_env):
+    """Three consecutive episodes of ONE reference MR_Env (reset(is_mismatched=...) at the top of each, RL/MR_ddpg.py:270)
+    through the oracle's same-step auto-reset: the init box is the single point the golden episodes start from."""
+    import ctypes as C
+    sigma = float(G["sigma"])
+    init = [float(v) for v in G["init"]]
+    p = O.default_params(a0=float(G["a0"]), sigma=sigma, mismatched=int(G["mismatched"]), auto_reset=1,
+                         init_low=init, init_high=init, auto_reset_fresh_env=int(fresh_env))
+    e, nz = O.OrcEnv(), O.OrcNoise()
+    tape = np.ascontiguousarray(G["tape"], dtype=np.float64)
+    if sigma > 0:
+        nz.kind, nz.tape, nz.tape_len, nz.tape_pos = O.NOISE_TAPE, tape.ctypes.data_as(C.POINTER(C.c_double)), len(tape), 0
+    else:
+        nz.kind = O.NOISE_NONE
+    L = O.lib()
+    obs = (C.c_double * 5)(); fobs = (C.c_double * 5)()
+    rew, done, fret, flen = C.c_double(), C.c_uint8(), C.c_double(), C.c_int32()
+    L.orc_env_reset(C.byref(p), C.byref(e), None, init[0], init[1], 0, C.byref(nz), 0, obs)   # a fresh env: nominal ctor
+    worst, ep, resets = 0.0, 0, [(np.array(e.f[:]), e.h_abs)]
+    for k, (f, a) in enumerate(G["actions"]):
+        nz.step_idx = k + 1
+        assert L.orc_env_step(C.byref(p), C.byref(e), None, float(f), float(a), C.byref(nz), 0, obs, C.byref(rew),
+                              C.byref(done), fobs, C.byref(fret), C.byref(flen)) == 0
+        assert done.value == G["done"][k], k
+        pos = np.array(fobs[:2]) if done.value else np.array(e.y[:])
+        worst = max(worst, float(np.abs(pos - G["pos"][k]).max()))
+        if done.value:
+            ep += 1
+            resets.append((np.array(e.f[:]), e.h_abs))
+        else:
+            assert e.counter == G["counter"][k]
+    return worst, resets, (nz.tape_pos, len(tape))
+
+
+@pytest.mark.parametrize("name", sorted(REUSED))
+def test_auto_reset_is_the_reused_env_object(name):
+    """MR_env.py:181-183 assigns is_mismatched AFTER reset_start_pos has built the RK45 object: from the second episode on
+    a re-used mismatched env starts with the drift (0.2, -0.1) as its stale first stage and a full-dt first step."""
+    G = REUSED[name]
+    worst, resets, (used, total) = _replay_reused(G, fresh_env=False)
+    assert worst < TOL, worst
+    for (f, h), gf, gh in zip(resets, G["reset_f"], G["reset_h_abs"]):
+        np.testing.assert_allclose(f, gf, rtol=0, atol=1e-12)
+        assert abs(h - gh) <= 1e-12 * max(1.0, gh)
+    if float(G["sigma"]) > 0:
+        # every draw of the reference consumed, in order, the reset constructors' included; the auto-reset behind the LAST
+        # episode (the reference loop stopped there) asks for one more constructor's worth: 2 RHS evaluations x 2 or 3 draws
+        assert used == total + 2 * (3 if int(G["mismatched"]) else 2)
+    if int(G["mismatched"]) and float(G["sigma"]) == 0:
+        assert np.allclose(G["reset_f"][1], [0.2, -0.1]) and np.allclose(G["reset_f"][0], [0.0, 0.0])
+        # the other meaning of an auto-reset (a fresh env per episode) is a different trajectory: its first step after a
+        # reset takes a 1e-6 sub-step with K0 = 0 instead of one full step that blends b1 = 9 % of the drift into the action's
+        # velocity (up to ~100 under this law): dt b1 |drift - v| ~ 0.1 per episode
+        worst_fresh, _, _ = _replay_reused(G, fresh_env=True)
+        assert 1e-4 < worst_fresh < 0.5, worst_fresh

@@ -47,7 +47,7 @@ for r in range(a.rounds):
     for v, e, b, ms in order:
         for k in range(a.launches):
             e.rollout(T, want=WANT, out=b, events=pool[k])
-        ms.extend([p.elapsed_ms() for p in pool][a.discard:])
+        ms.extend([p.elapsed_ms() for p in pool][min(a.discard, a.launches - 1):])
 ref = envs[0][1].pos.clone()
 print(f"# N={a.envs} T={T} workload={a.workload} mismatched={a.mismatched} rounds={a.rounds} x launches={a.launches} "
       f"(first {a.discard} of each block discarded; blocks interleaved in one process)")

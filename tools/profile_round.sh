@@ -18,7 +18,7 @@ pass() {  # pass <name> <cmd...>: run, record the exit code
   "$@" > $O/$name.out 2> $O/$name.log
   echo "$name $?" >> $O/status.txt
 }
-PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
+PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --no-actor-leg --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
 pass kt rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-power
 pass kt_s1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1 -- python3 $R/bench.py --no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set
 pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --no-power --mode step
