@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_PER_ENV_STEP = 97   # fp64 positions -> reads 40 + writes 57 per env-step
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0    # same table: 6.29 TB/s measured (float4 copy, 79 %)
 SIMDS = 1024                   # 256 CUs x 4 SIMDs
 PREROLL_EPISODES = 300         # untimed episodes issued right in front of every secondary timed region: after ANY host-side
                                # pause of a millisecond or more (allocating buffers, creating or reading a thousand events)
@@ -113,6 +114,8 @@ def parse(argv=None):
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--master-port", type=int, default=0, help="--gpus N launcher: rendezvous port (0 = pick a free one)")
+    ap.add_argument("--rendezvous-timeout", type=float, default=180.0,
+                    help="seconds init_process_group may wait for the other ranks before this rank gives up (exit code 3)")
     return ap.parse_args(argv)
 
 
@@ -223,9 +226,21 @@ def cpu_baseline(cfg, seed, target_seconds):
         el = time.perf_counter() - t0
         if el >= target_seconds or steps >= 2000:
             break
-    return {"value": n * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} envs x {steps} steps ({el:.1f} s) of the same workload, oracle/mrsim_oracle.c "
-                      f"with OpenMP over {threads} host threads"}
+    out = {"value": n * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
+           "sample": f"{n} envs x {steps} steps ({el:.1f} s) of the same workload, oracle/mrsim_oracle.c "
+                     f"with OpenMP over {threads} host threads"}
+    # the reference's OWN Python path beside every GPU number.  The reference's files never
+    # travel to the GPU box, so this is a QUOTED record: measured in the build container by tools/ref_python_baseline.py and
+    # committed under profiles/ (hardware, versions and command inside); nothing of it is executed here.
+    f = newest_profile("ref_python_baseline.json")
+    if f is not None:
+        try:
+            ref = json.load(open(f))
+            ref["quoted_from"] = os.path.relpath(f, ROOT)
+            out["reference_python"] = ref
+        except Exception:
+            pass
+    return out
 
 
 def newest_profile(name):
@@ -269,7 +284,8 @@ def committed_valu(args, n_local, T):
     try:
         d = json.load(open(f))
         k = d["kernels"]["rollout_" + args.carry]
-        return {"valu_issue_frac": k["valu_issue_frac"], "insts_valu_per_wave_step": k["insts_valu_per_wave_step"],
+        return {"valu_issue_frac": k["valu_issue_frac"], "valu_issue_frac_at_spec_rates": k.get("valu_issue_frac_at_spec_rates"),
+                "insts_valu_per_wave_step": k["insts_valu_per_wave_step"],
                 "issue_floor_cycles_per_wave_step": k["issue_floor_cycles_per_wave_step"],
                 "wave_cycles_per_wave_step": k["wave_cycles_per_wave_step"], "waves_per_simd": d["waves_per_simd"],
                 "floor_us_per_launch_at_burst_clock": k["floor_us_per_launch_at_burst_clock"],
@@ -405,10 +421,15 @@ class RolloutRegion:
         # the GPU, closing barrier -- a region of one short launch group is mostly the first and the last
         self.last_phases_us = {"enqueue": round((t1 - t0) * 1e6, 1), "wait_gpu": round((t2 - t1) * 1e6, 1),
                                "closing_barrier": round((t0 + el - t2) * 1e6, 1)}
+        self.last_per_rank_s = [el]
         if self.world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cdev = self.dev if self.backend == "nccl" else "cpu"
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            every = torch.zeros(self.world, dtype=torch.float64, device=cdev)
+            dist.all_gather_into_tensor(every, t)      # each rank's own clock around the region ...
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)   # ... and the contract's figure: the slowest rank
             el = float(t.item())
+            self.last_per_rank_s = [float(x) for x in every.tolist()]
         return el, self.launches - l0
 
 
@@ -633,10 +654,22 @@ def main():
             raise SystemExit("bench.py: rank %d needs cuda:%d but only %d device(s) are visible (--share-gpu only "
                              "for rehearsals)" % (rank, local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.dist_backend)
+        import datetime
+        try:
+            kw = {"timeout": datetime.timedelta(seconds=args.rendezvous_timeout)}
+            if args.dist_backend == "nccl":
+                kw["device_id"] = torch.device("cuda", local_rank)
+            dist.init_process_group(args.dist_backend, **kw)
+        except Exception as exc:  # a missing rank, a busy port, an unreachable MASTER_ADDR: say which and stop
+            sys.stderr.write("bench.py: rank %d/%d could not join the %s process group at %s:%s within %.0f s: %s: %s\n"
+                             % (rank, world, args.dist_backend, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"),
+                                args.rendezvous_timeout, type(exc).__name__, exc))
+            sys.exit(3)
+        if dist.get_world_size() != world or (args.gpus > 1 and dist.get_world_size() != args.gpus):
+            sys.stderr.write("bench.py: process group has %d ranks, WORLD_SIZE=%d, --gpus %d: they must agree\n"
+                             % (dist.get_world_size(), world, args.gpus))
+            dist.destroy_process_group()
+            sys.exit(4)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     if world == 1 and os.environ.get("MRSIM_BENCH_FORCE_DIST"):
         # rehearsal of the per-episode collective's HOST cost on a one-GPU box: a one-rank RCCL group, same call path
@@ -733,6 +766,7 @@ def main():
     if args.mode == "rollout":
         el, launches = reg.timed(K, ev_pool, ev_used)
         region_phases = reg.last_phases_us
+        per_rank_s = reg.last_per_rank_s
     else:
         l0 = n_launches[0]
         t0 = time.perf_counter()
@@ -742,10 +776,15 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         launches = n_launches[0] - l0
+        per_rank_s = [el]
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            cdev = dev if args.dist_backend == "nccl" else "cpu"
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            every = torch.zeros(world, dtype=torch.float64, device=cdev)
+            dist.all_gather_into_tensor(every, t)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+            per_rank_s = [float(x) for x in every.tolist()]
     trace("timed region done")
 
     # ---- sustained legs (every rank takes part): the same workload over its own >= 10 200-step region, (a) as
@@ -828,13 +867,23 @@ def main():
                     "unit": "G env-steps/s in-kernel; peak = achieved / frac, frac = VALU issue cycles the kernel's measured "
                             "instruction mix needs at the per-instruction issue costs of tools/instbench (4 waves per SIMD) / "
                             "the kernel's SQ_WAVE_CYCLES, both from the committed rocprofv3 --pmc passes (cycles over cycles)",
-                    "frac": frac, "valu": valu,
+                    "frac": frac,
+                    # the same instruction counts priced at architectural issue rates (2 cycles per fp32 / int32 wave
+                    # instruction, 4 for fp64, transcendentals and v_mad_u64_u32) instead of the measured ones
+                    "frac_at_spec_issue_rates": valu.get("valu_issue_frac_at_spec_rates") if valu else None,
+                    "valu": valu,
                     "in_kernel_clock_GHz": round(clock, 3) if clock else None,
                     "frac_of_burst_clock_floor": round(valu["floor_us_per_launch_at_burst_clock"] / avg_us, 4) if valu else None,
                     "traffic": traffic, "traffic_source": traffic_src,
                     "hbm_achieved_GBs": round(traffic / (avg_us * 1e-6) / 1e9, 1) if traffic else None,
                     "hbm_peak_GBs": HBM_PEAK_GBS,
                     "hbm_frac": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "hbm_achievable_GBs": HBM_ACHIEVABLE_GBS,
+                    "hbm_frac_of_achievable": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_ACHIEVABLE_GBS, 4) if traffic else None,
+                    # north_star asks for >= 60 % of the HBM roofline; on the bytes the fused kernel really moves it is not
+                    # met (the kernel is bound by vector issue at the package power cap)
+                    "north_star_hbm_target": 0.60,
+                    "north_star_hbm_target_met": bool(traffic and traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS >= 0.60),
                     "algorithmic_equiv": {
                         "what": "SURVEY 8(d)'s algorithmic bytes (state round-trips HBM every step) / kernel time; the "
                                 "fused kernel keeps the state in registers and does NOT move these bytes: an "
@@ -907,6 +956,9 @@ def main():
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": el / max(K, 1) * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
                "data": "synthetic", "launches": launches, "config": config, "roofline": roof, "cpu_baseline": cpu}
+        # every rank's own rate over the timed region (its envs x K / its own clock between the two barriers); `value` is
+        # total envs x K / the slowest rank's clock
+        out["per_rank_value"] = [n_local * K / max(s_, 1e-12) for s_ in per_rank_s]
         if region_phases is not None:
             out["timed_region_phases_us"] = region_phases  # rank 0's wall time of the K-step region, by phase
         if sustained is not None:

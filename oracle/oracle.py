@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmrsim_oracle.so")
+# MRSIM_ORACLE_LIB: load another build of the same source instead (tests/test_oracle_sanitizers.py: the ASan / UBSan build)
+_LIB_PATH = os.environ.get("MRSIM_ORACLE_LIB") or os.path.join(_HERE, "libmrsim_oracle.so")
 
 INT_RK45, INT_EULER, INT_RK4 = 0, 1, 2
 REW_CONSTANT10, REW_GOAL = 0, 1
@@ -61,6 +62,8 @@ class OrcNoise(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("MRSIM_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or (
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
                                               for f in ("mrsim_oracle.c", "mrsim_oracle.h"))):

@@ -177,3 +177,66 @@ def test_state_dict_carries_the_step_outputs_and_leaves_the_callers_cfg_alone():
         ob, rb, db, _ = b.step(None)
         assert torch.equal(oa, ob) and torch.equal(da, db)
     assert torch.equal(a.pos, b.pos)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 on one GPU: eight shards one after another == the unsharded 2 097 152-env run
+# ----------------------------------------------------------------------------------------------------------------------
+def test_config5_eight_shards_equal_one_unsharded_run():
+    """2 097 152 envs of the mixed trajectory set (goal reward, auto-reset) as ONE collector run, then as the eight
+    262 144-env shards of BASELINE config 5 (env_id0 = r x 262 144), each through its own RolloutCollector and
+    BlockReturnGatherer: the assembled [world, E, n_local] returns -- what one all_gather_into_tensor over eight ranks
+    delivers -- and a sampled set of transitions must agree bitwise with the unsharded run, episode lengths included."""
+    import bench
+    from mr_rl_amd import MRConfig
+    from mr_rl_amd.collector import BlockReturnGatherer, RolloutCollector
+    world, n_local, E, seed = 8, 262144, 4, 7
+    N = world * n_local
+    cfg = MRConfig(noise_var=1.0, auto_reset=True, seed=seed)
+    tab = bench.mixed_goal_table(cfg, seed)              # sets reward_mode="goal", min_dist2goal=1
+    rng = np.random.default_rng(1)
+    # sampled envs: the first and last env of every shard + 512 random ones per shard
+    sample = np.unique(np.concatenate([[r * n_local, (r + 1) * n_local - 1] for r in range(world)] +
+                                      [r * n_local + rng.integers(0, n_local, 512) for r in range(world)]))
+    sample_t = torch.from_numpy(sample).cuda()
+    keys = ("obs", "rew", "done", "actions")
+
+    col = RolloutCollector(N, cfg=cfg, seed=seed, goal_table=tab, streams=2, returns_interval=E)
+    g = BlockReturnGatherer(col, world_size=1)
+    col.reset()
+    full = []
+    for k in range(E):
+        col.collect(); g.gather()
+        out = col.ready(k)
+        full.append({q: out[q].index_select(1, sample_t).clone() for q in keys})
+        col.release(k)
+    col.join()
+    ret_full = g.latest().clone().view(E, N)             # [1, E, N] single process
+    len_full = col.len_blocks[0].clone()
+    col.check_status()
+    assert int((len_full > 0).sum()) > 0.9 * E * N       # episodes ended in (almost) every launch group
+    del col, g, out
+    torch.cuda.empty_cache()
+
+    gathered, lens = [], []
+    for r in range(world):
+        c = RolloutCollector(n_local, cfg=cfg, seed=seed, env_id0=r * n_local, goal_table=tab, streams=2, returns_interval=E)
+        gr = BlockReturnGatherer(c, world_size=1)
+        c.reset()
+        loc = torch.from_numpy(sample[(sample >= r * n_local) & (sample < (r + 1) * n_local)] - r * n_local).cuda()
+        cols = np.nonzero((sample >= r * n_local) & (sample < (r + 1) * n_local))[0]
+        for k in range(E):
+            c.collect(); gr.gather()
+            o = c.ready(k)
+            for q in keys:
+                assert torch.equal(o[q].index_select(1, loc), full[k][q][:, cols]), (r, k, q)
+            c.release(k)
+        c.join()
+        gathered.append(gr.latest().clone())             # [1, E, n_local]: this rank's slab of the all-gather
+        lens.append(c.len_blocks[0].clone())
+        c.check_status()
+        del c, gr
+    allg = torch.cat(gathered, dim=0)                    # [world, E, n_local], rank-major = global env order per episode
+    assert allg.shape == (world, E, n_local)
+    assert torch.equal(allg.permute(1, 0, 2).reshape(E, N), ret_full)
+    assert torch.equal(torch.stack(lens).permute(1, 0, 2).reshape(E, N), len_full)

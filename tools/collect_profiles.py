@@ -161,6 +161,14 @@ CLASS_OP = {  # PMC class -> the instbench instruction that prices it
     "SQ_INSTS_VALU_MUL_F64": "v_mul_f64", "SQ_INSTS_VALU_ADD_F64": "v_add_f64", "SQ_INSTS_VALU_CVT": "v_cvt_f64_f32",
     "SQ_INSTS_VALU_FMA_F32": "v_fma_f32", "SQ_INSTS_VALU_MUL_F32": "v_mul_f32", "SQ_INSTS_VALU_ADD_F32": "v_add_f32",
     "SQ_INSTS_VALU_INT32": "v_add_u32"}
+# The same counts priced at ARCHITECTURAL issue rates instead of measured ones (MI355X_MICROARCH.md: a wave64 VALU instruction
+# issues over 2 cycles on the 32-lane SIMD -- the 157.3 TFLOP/s fp32 vector peak; fp64 runs at half that rate (78.6 TFLOP/s);
+# transcendentals and the 32x32->64-bit multiplier take twice the cycles of an fp32 fma in the guide's issue-cost row (8 vs 4
+# cycles for one wave alone); conversions and everything unclassified at the fp32 rate): what fraction of the kernel's cycles
+# the mix would need if every instruction issued at its data-sheet rate.
+SPEC_CYCLES = {"SQ_INSTS_VALU_INT64": 4.0, "SQ_INSTS_VALU_TRANS_F32": 4.0, "SQ_INSTS_VALU_FMA_F64": 4.0, "SQ_INSTS_VALU_MUL_F64": 4.0,
+               "SQ_INSTS_VALU_ADD_F64": 4.0, "SQ_INSTS_VALU_CVT": 2.0, "SQ_INSTS_VALU_FMA_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0,
+               "SQ_INSTS_VALU_ADD_F32": 2.0, "SQ_INSTS_VALU_INT32": 2.0, "other": 2.0}
 WPS = WAVES // 1024  # waves per SIMD of the launch (N / 64 / 1024 = 4)
 valu = {"what": "rocprofv3 --pmc SQ counters of the fused rollout kernel per wave and env step (value / (grid/64) / T), and the VALU "
                 "issue floor they imply.  floor = sum over instruction classes of count x issue cost of that class (tools/instbench at "
@@ -173,7 +181,7 @@ valu = {"what": "rocprofv3 --pmc SQ counters of the fused rollout kernel per wav
                 "conversion: the floor is a lower bound, the fraction an under-estimate.  The ns figures of the same instbench run "
                 "(taken at the burst clock of a 0.1 ms launch) give floor_us_at_burst_clock, what the mix would take if the chip "
                 "held that clock.",
-        **stamp, "N": N, "T": T, "waves_per_simd": WPS,
+        **stamp, "N": N, "T": T, "waves_per_simd": WPS, "spec_issue_cycles": SPEC_CYCLES,
         "issue_costs": {"source": f"profiles/{tag}/instbench.json",
                         "w4": {op: {"cycles": cost[op][4]["cycles"], "ns": cost[op][4]["ns"]}
                                for op in sorted(set(CLASS_OP.values()) | {"v_xor_b32"})}},
@@ -191,7 +199,10 @@ for carry in ("f64", "f32"):
     for unit in ("cycles", "ns"):
         fl[unit] = sum(per[k] * cost[op][4][unit] for k, op in CLASS_OP.items()) + other * cost["v_xor_b32"][4][unit]
     wave_cycles = 4.0 * per["SQ_WAVE_CYCLES"]
+    spec_floor = sum(per[k] * SPEC_CYCLES[k] for k in CLASS_OP) + other * SPEC_CYCLES["other"]
     valu["kernels"]["rollout_" + carry] = {
+        "issue_floor_cycles_per_wave_step_at_spec_rates": round(spec_floor, 1),
+        "valu_issue_frac_at_spec_rates": round(WPS * spec_floor / wave_cycles, 4),
         "kernel": f"mr_rollout_kernel<RK45,fast,nominal,carry={carry}>", "per_wave_step": {k: round(v, 2) for k, v in sorted(per.items())},
         "insts_valu_per_wave_step": round(per["SQ_INSTS_VALU"], 2), "other_valu_per_wave_step": round(other, 2),
         "issue_floor_cycles_per_wave_step": round(fl["cycles"], 1), "wave_cycles_per_wave_step": round(wave_cycles, 1),
