@@ -595,7 +595,7 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
             // make_kparams) and the fourth, F >= 2e-5 max(scale), is implied by F >= reset_fmin.  Same outcome
             // (h_abs = dt) as the full test whenever this passes; anything else goes on to the full test.
             if (!have1 && in_init_box && P.reset_fmin >= 0.0 &&
-                fmax(__builtin_fabs(f0x), __builtin_fabs(f0y)) >= P.reset_fmin) {
+                ((__builtin_fabs(f0x) >= P.reset_fmin) | (__builtin_fabs(f0y) >= P.reset_fmin))) {  // max|f0| >= fmin, two compares
                 spx = C.vx; spy = C.vy;
                 h_abs = P.dt;
                 return;
@@ -1208,6 +1208,27 @@ __device__ __forceinline__ void step_prologue(const KParams& P, const Rng& R, bo
     if (random_policy) action_from_words(P, W.w[0], af, aa);
 }
 
+// The same prologue with the step's auto-reset call RESET_POS(0,0) drawn in the SAME interleaved batch (same counter, same
+// key: same words as reset_words()).  For launches on a goal table, where some lane of almost every wave terminates at
+// almost every step: the reset block then starts with its words in hand instead of running a lone ten-round Philox chain
+// (ILP 2) with one or two lanes active.
+template <bool RK45, int NZ, bool MIS>
+__device__ __forceinline__ void step_prologue_with_reset(const KParams& P, const Rng& R, bool random_policy,
+                                                         StepWords<RK45, NZ, MIS>& W, float& af, float& aa,
+                                                         uint32_t (&wr)[4]) {
+    using SW = StepWords<RK45, NZ, MIS>;
+    static_assert(SW::NDYN > 0, "only for the noisy RK45 kernels");
+    uint32_t c0s[SW::NDYN + 1], w[SW::NDYN + 1][4];
+#pragma unroll
+    for (int j = 0; j < SW::NDYN; ++j) c0s[j] = c0_of(kStreamDyn, 0, (uint32_t)j);
+    c0s[SW::NDYN] = c0_of(kStreamResetPos, 0, 0);
+    philox_multi<SW::NDYN + 1>(R, c0s, w);
+#pragma unroll
+    for (int j = 0; j < SW::NDYN; ++j) { W.w[j][0] = w[j][0]; W.w[j][1] = w[j][1]; W.w[j][2] = w[j][2]; W.w[j][3] = w[j][3]; }
+    wr[0] = w[SW::NDYN][0]; wr[1] = w[SW::NDYN][1]; wr[2] = w[SW::NDYN][2]; wr[3] = w[SW::NDYN][3];
+    if (random_policy) action_from_words(P, W.w[0], af, aa);
+}
+
 __device__ __forceinline__ void pack_obs(double x, double y, double gx, double gy, double d2, float (&obs)[5]) {
     // convert_state (MR_env.py:100-116); dist emitted as the fp32 sqrt of the fp64 squared distance
     obs[0] = (float)x; obs[1] = (float)y; obs[2] = (float)gx; obs[3] = (float)gy;
@@ -1219,7 +1240,8 @@ template <bool RK45, int NZ, bool MIS>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
                                          EnvRegs& e, double act_f, double act_a, const StepWords<RK45, NZ, MIS>& W,
                                          uint32_t fl, StepOut& o, int& fail, const double2* __restrict__ sincos_lds = nullptr,
-                                         const float2* goal_pre = nullptr, const float2* goal0_pre = nullptr) {
+                                         const float2* goal_pre = nullptr, const float2* goal0_pre = nullptr,
+                                         const uint32_t* wr_pre = nullptr) {
     e.counter += 1;  // :80
     // the goal of this step only depends on the counter: the one-launch-per-step kernel fetches it now, so that the table
     // read (an L1/L2 hit, but hundreds of cycles) completes behind the integrator instead of stalling the termination
@@ -1285,7 +1307,8 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         o.flen = e.counter;
         double x0, y0, rx, ry;
         uint32_t wr[4];
-        reset_words(R, wr);
+        if (wr_pre != nullptr) { wr[0] = wr_pre[0]; wr[1] = wr_pre[1]; wr[2] = wr_pre[2]; wr[3] = wr_pre[3]; }  // drawn with the step's batch
+        else reset_words(R, wr);
         sample_init(P, wr, x0, y0);
         // The host-certified shortcut of the constructor test only where resets are hot: on a goal table episodes end at
         // different steps, so some lane of almost every wave resets at almost every step.  With the constant goal all

@@ -375,11 +375,20 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
             const float2 a = (reinterpret_cast<const float2*>(ra.actions) + row)[tid];
             af = a.x; aa = a.y;
         }
-        step_prologue<RK45, NZ, MIS>(P, R, !ACT && !(fl & kFActions), W, af, aa, ACT && (fl & kFActorOU));
+#ifndef MRSIM_PRE_RESET   // A/B switch (off): 1 = on goal-table launches the auto-reset's Philox call rides in the step's batch
+#define MRSIM_PRE_RESET 0 // (step_prologue_with_reset).  Measured SLOWER on the mixed trajectory set, 145.8 vs 140.8 us per launch,
+#endif                    // same bits (profiles/r03/ab_pre_reset_mixed.txt): 27 more vector instructions in EVERY wave-step cost
+                          // more than the 34 they save in the 0.9 reset blocks per wave-step.
+        constexpr bool kPreReset = MRSIM_PRE_RESET != 0 && !ACT && RK45 && NZ == kNoiseFast && FL != 0 && (FL & kFGoalTable) != 0 &&
+                                   (FL & kFAutoReset) != 0;
+        uint32_t wr_pre[4] = {0u, 0u, 0u, 0u};
+        if constexpr (kPreReset) step_prologue_with_reset<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa, wr_pre);
+        else step_prologue<RK45, NZ, MIS>(P, R, !ACT && !(fl & kFActions), W, af, aa, ACT && (fl & kFActorOU));
         if constexpr (ACT) actor_policy<ou_nz<NZ>(), MRSIM_ACTOR_A2REG != 0>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa, &aregs);
         if (!(fl & kFActions64)) { adf = (double)af; ada = (double)aa; }
         StepOut o;
-        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr);
+        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr,
+                                kPreReset ? wr_pre : nullptr);
         if constexpr (ACT) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) obs_cur[j] = o.obs[j];  // what the policy sees next (the reset row after an auto-reset)

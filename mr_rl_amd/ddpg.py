@@ -132,7 +132,10 @@ class DDPG:
     """The training loop of RL/MR_ddpg.py:251-323 for N envs in lockstep."""
 
     def __init__(self, env, gamma=0.99, tau=0.001, actor_lr=1e-3, critic_lr=1e-2, min_batch=64, buffer_size=10000,
-                 seed=0, obs_scale=None):
+                 seed=0, obs_scale=None, device_actor=False, refresh_every=1):
+        """device_actor=True: the behaviour policy of train() is evaluated INSIDE the env's step kernel
+        (mr_rl_amd.actor.DeviceActor: folded eval-mode network + OU noise in libmrsim.so) instead of as eager PyTorch
+        between two launches; its parameters are re-uploaded from the learner's actor every `refresh_every` updates."""
         self.env, self.gamma, self.tau, self.min_batch = env, gamma, tau, min_batch
         dev = env.device
         torch.manual_seed(seed)
@@ -147,6 +150,14 @@ class DDPG:
         self.noise = OUNoise((env.num_envs, 2), device=dev, seed=seed)
         # optional fixed observation scaling (the reference feeds raw observations; obs are O(100))
         self.obs_scale = None if obs_scale is None else torch.as_tensor(obs_scale, dtype=torch.float32, device=dev)
+        self.device_actor, self.refresh_every, self._updates = None, max(1, int(refresh_every)), 0
+        if device_actor:
+            from .actor import DeviceActor
+            self.actor.eval()
+            self.device_actor = DeviceActor.from_module(self.actor, obs_scale=obs_scale, device=dev, ou=True,
+                                                        theta=self.noise.theta, sigma=self.noise.sigma, dt=self.noise.dt,
+                                                        reset_on_done=True)   # as train() does with its own OUNoise
+            self.actor.train()
 
     def _prep(self, obs):
         return obs if self.obs_scale is None else obs * self.obs_scale
@@ -170,6 +181,11 @@ class DDPG:
         self.opt_a.zero_grad(set_to_none=True); loss_a.backward(); self.opt_a.step()
         soft_update(self.actor_t, self.actor, self.tau)
         soft_update(self.critic_t, self.critic, self.tau)
+        self._updates += 1
+        if self.device_actor is not None and self._updates % self.refresh_every == 0:
+            self.actor.eval()
+            self.device_actor.load_module(self.actor)    # fold batch norm, pack, upload (19 KB)
+            self.actor.train()
         return float(loss_c.detach()), float(loss_a.detach())
 
     def train(self, total_steps, updates_per_step=1, log_every=0):
@@ -177,15 +193,22 @@ class DDPG:
         env = self.env
         obs = env.reset().clone()
         returns = []
+        if self.device_actor is not None and env._actions_out is None:
+            raise ValueError("DDPG(device_actor=True) needs MRVecEnv(track_actions=True): the replay ring stores the applied actions")
         for k in range(total_steps):
-            a = self.act(obs).float().contiguous()
-            obs2, rew, done, info = env.step(a)
+            if self.device_actor is not None:   # policy + exploration noise + MR_Env.step in ONE kernel
+                obs2, rew, done, info = env.step(actor=self.device_actor)
+                a = env._actions_out.clone()
+            else:
+                a = self.act(obs).float().contiguous()
+                obs2, rew, done, info = env.step(a)
             # with auto_reset the returned obs of a done env is the reset obs; the transition's s2 is final_obs
             s2 = torch.where(done[:, None], info["final_obs"], obs2) if env.cfg.auto_reset else obs2
             self.buffer.add(self._prep(obs), a, rew, done.float(), self._prep(s2))
             if env.cfg.auto_reset and bool(done.any()):
                 returns.append(float(info["final_ret"][done].mean()))
-                self.noise.reset(done)
+                if self.device_actor is None:
+                    self.noise.reset(done)      # (the device actor zeroes its OU state in-kernel: reset_on_done)
             obs = obs2.clone()
             for _ in range(updates_per_step):
                 self.update()

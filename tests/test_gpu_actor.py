@@ -297,3 +297,30 @@ def test_actor_argument_errors():
     rc = env._L.mrsim_actor_forward(C.byref(env._params), 256, 0, C.byref(rst), None, env._p(env._obs), env._p(out), 0, 0,
                                     env._stream())
     assert rc == _lib.EINVAL                               # ou_reset_on_done needs the env state (MR_Env.counter)
+
+
+def test_ddpg_twin_trains_with_the_device_actor():
+    """mr_rl_amd.ddpg.DDPG(device_actor=True): the behaviour policy runs inside the env's step kernel and follows the
+    learner (parameters re-uploaded after every update): after training, the device actor's noise-free output equals the
+    PyTorch actor's eval-mode forward on the same observations to ACTOR_TOL of the bound."""
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.actor import DeviceActor
+    from mr_rl_amd.ddpg import DDPG
+    cfg = MRConfig(noise_var=0.1, reward_mode="goal", auto_reset=True, init_low=(20.0, 20.0), init_high=(30.0, 30.0),
+                   min_dist2goal=25.0)
+    env = MRVecEnv(256, cfg=cfg, seed=0, track_actions=True)
+    agent = DDPG(env, seed=0, obs_scale=SCALE, device_actor=True)
+    w0 = agent.device_actor.blob.clone()
+    rets = agent.train(120)
+    assert agent.buffer.size() == 10000 and len(rets) > 0 and all(np.isfinite(rets))
+    assert not torch.equal(w0, agent.device_actor.blob)            # the learner's updates reached the device policy
+    env.check_status()
+    agent.actor.eval()
+    quiet = DeviceActor.from_module(agent.actor, obs_scale=SCALE, device="cuda", ou=False)
+    got = quiet.forward(env)
+    with torch.no_grad():
+        want = agent.actor(env.obs * torch.tensor(SCALE, device="cuda"))
+    bound = agent.actor.action_bound
+    assert ((got - want).abs() / bound).max().item() < ACTOR_TOL
+    follow = DeviceActor(agent.device_actor.weights, device="cuda", ou=False)   # what train() uploaded last
+    assert torch.equal(follow.forward(env), got)

@@ -35,7 +35,8 @@ def sha16(path):
 
 EXPECTED = ["kt", "kt_s1", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
                                              for p in ("pmc_f64", "pmc_f32", "pmc_step", "cal", "cal262k")] + \
-           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")]
+           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")] + \
+           ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed"]
 if not os.path.exists(f"{src}/status.txt"):
     die(f"{src}/status.txt not found (did tools/profile_round.sh {tag} run?)")
 status = dict(l.split() for l in open(f"{src}/status.txt").read().splitlines() if l.strip())
@@ -210,6 +211,50 @@ for carry in ("f64", "f32"):
         "issue_floor_ns_per_wave_step_at_burst_clock": round(fl["ns"], 2),
         "floor_us_per_launch_at_burst_clock": round(fl["ns"] * WPS * T * 1e-3, 2), "source": srcs}
 files["pmc_valu.json"] = json.dumps(valu, indent=1) + "\n"
+
+# ---- the fused rollout with the actor as its policy source: f32-MFMA roofline from counters + trace
+ACT = "mr_rollout_actor_fl_kernel<true, 2, false"
+files["kernel_stats_actor_rollout.csv"] = open(the_csv("kt_actor", "kernel_stats.csv")).read()
+kta = the_csv("kt_actor", "kernel_trace.csv")
+adur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kta)) if ACT in r["Kernel_Name"]]
+if len(adur) < 100:
+    die(f"{kta}: {len(adur)} dispatches of the actor rollout kernel")
+adur = adur[50:]
+ca, _, grid_a, fa = counters("pmc_actor_a", ACT, 0.0)
+cb, _, _, fb = counters("pmc_actor_b", ACT, 0.0)
+fr, _, _, f1 = counters("pmc_actor_FETCH_SIZE", ACT, 0.0)
+wr, _, _, f2 = counters("pmc_actor_WRITE_SIZE", ACT, 0.0)
+waves_a = grid_a / 64
+avg_us = sum(adur) / len(adur)
+FLOP = 2 * (5 * 64 + 64 * 64 + 64 * 2)
+mfma_per_ws = ca["SQ_INSTS_MFMA"] / waves_a / T
+busy_per_simd = ca["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0          # the counter sums the SIMDs' busy cycles (= 64 x MFMA count)
+files["pmc_actor.json"] = json.dumps({
+    "what": "the fused rollout with the DDPG actor (+ OU noise) as its policy source, tools/actor_probe.py (262 144 envs, 51 steps "
+            "per launch, fp64 carry, every transition written): rocprofv3 kernel trace (durations) and --pmc passes (counters per "
+            "dispatch).  mfma_pipe_frac = matrix-pipe busy cycles per SIMD / (kernel duration x in-kernel clock); the clock "
+            "is GRBM_GUI_ACTIVE / duration of the SAME counter pass (counter passes serialise dispatches: durations of the "
+            "trace pass are the ones quoted); tflops = algorithmic actor flops / trace duration against the 157.3 TFLOP/s "
+            "f32-input MFMA peak (MI355X_MICROARCH.md)",
+    **stamp, "kernel": "mr_rollout_actor_fl_kernel<RK45,fast,nominal,DDPG|carry64|actor|OU>", "N": N, "T": T,
+    "avg_kernel_us": round(avg_us, 2), "median_kernel_us": round(sorted(adur)[len(adur) // 2], 2), "dispatches_timed": len(adur),
+    "in_kernel_env_steps_per_s": round(N * T / (avg_us * 1e-6), 1),
+    "actor_flop_per_env_step": FLOP, "tflops": round(N * T * FLOP / (avg_us * 1e-6) / 1e12, 2), "mfma_f32_peak_tflops": 157.3,
+    "mfma_frac_of_peak": round(N * T * FLOP / (avg_us * 1e-6) / 1e12 / 157.3, 4),
+    "per_wave_step": {"mfma_insts": round(mfma_per_ws, 2), "valu_insts_incl_mfma": round(ca["SQ_INSTS_VALU"] / waves_a / T, 2),
+                      "salu_insts": round(cb["SQ_INSTS_SALU"] / waves_a / T, 2), "lds_insts": round(ca["SQ_INSTS_LDS"] / waves_a / T, 2),
+                      "mfma_busy_cycles": round(ca["SQ_VALU_MFMA_BUSY_CYCLES"] / waves_a / T, 1)},
+    "mfma_busy_cycles_per_simd_per_launch": round(busy_per_simd, 1),
+    "GRBM_GUI_ACTIVE_per_launch": cb.get("GRBM_GUI_ACTIVE"),
+    "hbm_bytes_per_launch": (2 * fr["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024,
+    "hbm_bytes_per_env_step": (2 * fr["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024 / (N * T),
+    "raw": {"a": ca, "b": cb}, "source": [prov(kta), prov(fa), prov(fb), prov(f1), prov(f2)]}, indent=1) + "\n"
+# ---- mixed trajectory set: VALU instructions per wave-step of the goal-table kernel
+cm, _, grid_m, fm = counters("valu_a_mixed", "mr_rollout_kernel<true, 2, false")
+files["pmc_mixed_set.json"] = json.dumps({
+    "what": "SQ counters of the rollout kernel on BASELINE config 5's mixed trajectory set (bench.py --workload mixed, goal table, "
+            "goal reward), per wave and env step",
+    **stamp, "per_wave_step": {k: round(v / (grid_m / 64) / T, 2) for k, v in sorted(cm.items())}, "source": prov(fm)}, indent=1) + "\n"
 
 os.makedirs(dst, exist_ok=True)
 for name, text in files.items():

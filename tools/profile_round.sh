@@ -35,6 +35,15 @@ for carry in f64 f32; do
   pass valu_b_$carry rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VMEM_WR --output-format csv -d $O/valu_b_$carry -- python3 $R/bench.py $PMCARGS --carry $carry
   pass valu_c_$carry rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD --output-format csv -d $O/valu_c_$carry -- python3 $R/bench.py $PMCARGS --carry $carry
 done
+# ---- the fused rollout with the DDPG actor as its policy source (tools/actor_probe.py: 262 144 envs, 51 steps per launch)
+pass kt_actor rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_actor -- python3 $R/tools/actor_probe.py --launches 200
+pass pmc_actor_a rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/pmc_actor_a -- python3 $R/tools/actor_probe.py --launches 6 --discard 0
+pass pmc_actor_b rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc_actor_b -- python3 $R/tools/actor_probe.py --launches 6 --discard 0
+for c in FETCH_SIZE WRITE_SIZE; do
+  pass pmc_actor_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_actor_$c -- python3 $R/tools/actor_probe.py --launches 6 --discard 0
+done
+# ---- the mixed trajectory set (BASELINE config 5's workload): instruction count per wave-step
+pass valu_a_mixed rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/valu_a_mixed -- python3 $R/bench.py $PMCARGS --workload mixed --carry f64
 pass instbench $R/tools/instbench --json
 sha256sum $R/bench.py $R/mr_rl_amd/libmrsim.so > $O/sha.txt
 (cd $O && find . -type f ! -name manifest.txt | sed 's|^\./||' | sort) > $O/manifest.txt   # what THIS round wrote
