@@ -348,7 +348,16 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
             asm volatile("" : "+v"(ou0), "+v"(ou1));  // consumed here, like the state above
         }
     }
+#ifndef MRSIM_ACTOR_PRIO   // issue priority of the actor-in-the-loop kernel (A/B, tools/actor_probe.py): 0 none, 1 rotate per step
+#define MRSIM_ACTOR_PRIO 1 // like the plain rollout, 2 fixed by wave slot, 3 high in the MFMA phase, 4 high in the VALU phase
+#endif
+    if constexpr (ACT && MRSIM_ACTOR_PRIO == 2) rotate_wave_priority(0u, slot);
     for (int t = 0; t < ra.T; ++t) {
+        if constexpr (ACT) {
+            if constexpr (MRSIM_ACTOR_PRIO == 1) rotate_wave_priority((unsigned)t, slot);
+            if constexpr (MRSIM_ACTOR_PRIO == 3) __builtin_amdgcn_s_setprio(3);
+            if constexpr (MRSIM_ACTOR_PRIO == 4) __builtin_amdgcn_s_setprio(0);
+        } else {
 #if MRSIM_PRIO_MODE == 1
         rotate_wave_priority((unsigned)t, slot);
 #elif MRSIM_PRIO_MODE == 2
@@ -356,6 +365,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
 #elif MRSIM_PRIO_MODE == 4
         if ((t & 3) == 0) rotate_wave_priority((unsigned)t >> 2, slot);
 #endif
+        }
         const uint32_t fl = FL != 0 ? FL : live_flags(P.flags);  // one SGPR; every uniform yes/no below is a bit test
         const Rng R = make_rng(P, i, (unsigned long long)t);
         const long long row = (long long)t * ra.row_stride + blk0;  // uniform
@@ -384,7 +394,11 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         uint32_t wr_pre[4] = {0u, 0u, 0u, 0u};
         if constexpr (kPreReset) step_prologue_with_reset<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa, wr_pre);
         else step_prologue<RK45, NZ, MIS>(P, R, !ACT && !(fl & kFActions), W, af, aa, ACT && (fl & kFActorOU));
-        if constexpr (ACT) actor_policy<ou_nz<NZ>(), MRSIM_ACTOR_A2REG != 0>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa, &aregs);
+        if constexpr (ACT) {
+            actor_policy<ou_nz<NZ>(), MRSIM_ACTOR_A2REG != 0>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa, &aregs);
+            if constexpr (MRSIM_ACTOR_PRIO == 3) __builtin_amdgcn_s_setprio(0);
+            if constexpr (MRSIM_ACTOR_PRIO == 4) __builtin_amdgcn_s_setprio(3);
+        }
         if (!(fl & kFActions64)) { adf = (double)af; ada = (double)aa; }
         StepOut o;
         env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr,
