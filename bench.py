@@ -529,6 +529,7 @@ def measure_mixed_set(args, n_local, env_id0, world, dev, seed, streams, steps=1
 
 ACTOR_FLOP_PER_ENV_STEP = 2 * (5 * 64 + 64 * 64 + 64 * 2)   # RL/MR_ddpg.py:120-137: 5 -> 64 -> 64 -> 2
 MFMA_F32_PEAK_TFLOPS = 157.3                                # MI355X_MICROARCH.md: f32-input MFMA, dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0                              # same table: bf16 MFMA, dense
 
 
 def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event_episodes=60):
@@ -544,12 +545,14 @@ def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event
     from mr_rl_amd.collector import RolloutCollector
     from mr_rl_amd.ddpg import Actor
     torch.manual_seed(seed)
-    actor = DeviceActor.from_module(Actor().eval(), obs_scale=[0.01] * 5, device=dev)
+    module = Actor().eval()
+    actor = DeviceActor.from_module(module, obs_scale=[0.01] * 5, device=dev)
+    actor_bf = DeviceActor.from_module(module, obs_scale=[0.01] * 5, device=dev, math="bf16x3")
     cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math, seed=seed,
                    is_mismatched=args.mismatched)
     ep = cfg.max_timesteps + 1
 
-    def run(S, n, events=None):
+    def run(S, n, events=None, actor=actor):
         col = RolloutCollector(n_local, cfg=cfg, device=dev, seed=seed, streams=S, carry=args.carry, policy=actor)
         col.reset()
         for _ in range(40):
@@ -571,7 +574,31 @@ def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event
         p.close()
     avg_us, med_us = stats_us(ms)
     tflops = n_local * ep * ACTOR_FLOP_PER_ENV_STEP / (avg_us * 1e-6) / 1e12
-    return {"what": "BASELINE config 4 with the reference's DDPG actor (5-64-64-2, eval-mode batch norm folded, tanh x bound) "
+    # the same with the 64 x 64 layer in bf16 x 3 arithmetic (three bf16 terms per f32 operand, six bf16 MFMAs, f32 accumulate)
+    el_bf = run(streams, episodes, actor=actor_bf)
+    pool = [EventPair() for _ in range(event_episodes)]
+    el1_bf = run(1, event_episodes, pool, actor=actor_bf)
+    ms_bf = [p.elapsed_ms() for p in pool]
+    for p in pool:
+        p.close()
+    avg_bf, med_bf = stats_us(ms_bf)
+    waves = (n_local + 63) // 64
+    exec_flops = waves * ep * (96 * 32 * 32 * 16 * 2 + 12 * 32 * 32 * 2 * 2)   # executed MFMA flops: 96 bf16 + 12 f32 per wave-step
+    bf16x3 = {"what": "the same with MrsimActor.math = BF16X3: every f32 operand of the 64 x 64 layer as three bf16 terms, the six "
+                      "products above 2^-24 on v_mfma_f32_32x32x16_bf16 with f32 accumulation (within 2e-6 of the action bound of the "
+                      "f32 result; tests/test_gpu_actor.py) -- the matrix cores proper, which run beside the vector unit",
+              "value": n_local * ep * episodes / el_bf, "unit": "env-steps/s", "ms_per_step": el_bf / (episodes * ep) * 1e3,
+              "one_stream_with_events": {"value": n_local * ep * event_episodes / el1_bf, "avg_kernel_us": round(avg_bf, 2),
+                                         "median_kernel_us": round(med_bf, 2)},
+              "roofline": {"bound": "mfma", "achieved": round(exec_flops / (avg_bf * 1e-6) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(exec_flops / (avg_bf * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                           "traffic": None,
+                           "note": "EXECUTED matrix flops (96 bf16 MFMAs of 32x32x16 + 12 f32 MFMAs per wave and step) / kernel "
+                                   "duration against the dense bf16 MFMA peak; the kernel is bound by vector-instruction issue "
+                                   "(operand splitting, ReLU, the output layer, the env step: ~1050 per wave and step), not by the "
+                                   "matrix pipe",
+                           "algorithmic_actor_TFLOPs": round(n_local * ep * ACTOR_FLOP_PER_ENV_STEP / (avg_bf * 1e-6) / 1e12, 1)}}
+    return {"bf16x3": bf16x3, "what": "BASELINE config 4 with the reference's DDPG actor (5-64-64-2, eval-mode batch norm folded, tanh x bound) "
                     "+ OU noise as the policy, evaluated INSIDE the fused rollout kernel on each step's observation "
                     "(RL/MR_ddpg.py:277-278 without leaving the registers); random-initialised weights, every transition written",
             "value": n_local * ep * episodes / el, "unit": "env-steps/s", "episodes": episodes, "streams": streams,

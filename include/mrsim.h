@@ -127,7 +127,12 @@ typedef struct MrsimState {
  * words the uniform exploration policy would use (mrsim_random_policy): the two policy sources are alternatives.
  * --------------------------------------------------------------------------------------------------------- */
 #define MRSIM_ACTOR_HIDDEN 64
-#define MRSIM_ACTOR_BLOB_FLOATS 4744   /* size of the packed parameter block */
+#define MRSIM_ACTOR_BLOB_FLOATS 10888  /* size of the packed parameter block (f32 section 4744 + bf16x3 section 6144) */
+/* Arithmetic of the 64 x 64 layer (MrsimActor.math).  F32: exact f32 products on v_mfma_f32_32x32x2_f32, bit-for-bit an
+ * fmaf chain in the documented order.  BF16X3: every f32 operand as the sum of three bf16 terms, the six products above
+ * 2^-24 on v_mfma_f32_32x32x16_bf16 with f32 accumulation -- f32-class accuracy (within 2e-6 of the action bound of the F32
+ * result in the tests) on the matrix cores proper, which run beside the vector unit; about twice the collection rate. */
+enum { MRSIM_ACTOR_F32 = 0, MRSIM_ACTOR_BF16X3 = 1 };
 
 typedef struct MrsimActorWeights {   /* HOST pointers, row-major float32: the network in inference form */
     const float* w1;        /* [64][5]   first fully_connected (+ folded batch norm)   RL/MR_ddpg.py:122-123 */
@@ -158,6 +163,8 @@ typedef struct MrsimActor {
     float ou_dt;              /* 1e-2                                                                         */
     int32_t ou_reset_on_done; /* 0 = the reference (the process is never reset, :270-311); 1 = x_prev := 0 at  */
                               /*   the first step of every episode (MR_Env.counter == 0)                      */
+    int32_t math;             /* MRSIM_ACTOR_F32 (default) | MRSIM_ACTOR_BF16X3                               */
+    int32_t reserved0;        /* 0                                                                            */
 } MrsimActor;
 
 /* Inputs / outputs of one step.  Optional pointers may be NULL. */

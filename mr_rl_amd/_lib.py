@@ -12,7 +12,8 @@ REW_CONSTANT10, REW_GOAL = 0, 1
 OBS_AOS, OBS_SOA = 0, 1
 NOISE_FAST, NOISE_SPEC = 0, 1
 ABI_VERSION = 3
-ACTOR_HIDDEN, ACTOR_BLOB_FLOATS = 64, 4744
+ACTOR_HIDDEN, ACTOR_BLOB_FLOATS = 64, 10888
+ACTOR_F32, ACTOR_BF16X3 = 0, 1
 
 # every symbol include/mrsim.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
@@ -50,7 +51,7 @@ class MrsimActorWeights(C.Structure):
 
 class MrsimActor(C.Structure):
     _fields_ = [("blob", C.c_void_p), ("ou_state", C.c_void_p), ("ou_theta", C.c_float), ("ou_sigma", C.c_float),
-                ("ou_dt", C.c_float), ("ou_reset_on_done", C.c_int32)]
+                ("ou_dt", C.c_float), ("ou_reset_on_done", C.c_int32), ("math", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class MrsimStepIO(C.Structure):
@@ -127,7 +128,7 @@ def load(path):
         raise ImportError(f"{path}: ABI {L.mrsim_abi_version()} != binding ABI {ABI_VERSION}")
     assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 12 + 8
     assert C.sizeof(MrsimRolloutIO) == 8 + 8 * 11 + 8 + 4 + 4 + 8
-    assert C.sizeof(MrsimActor) == 32 and C.sizeof(MrsimActorWeights) == 48 + 28 + 4
+    assert C.sizeof(MrsimActor) == 40 and C.sizeof(MrsimActorWeights) == 48 + 28 + 4
     return L
 
 

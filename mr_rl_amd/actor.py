@@ -76,8 +76,16 @@ class DeviceActor:
     every episode (what mr_rl_amd.ddpg.DDPG.train does with its own OUNoise).
     The OU state tensor [num_envs, 2] is created on first use for the env count it is used with."""
 
-    def __init__(self, weights, device="cuda", ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False):
+    MATH = {"f32": _lib.ACTOR_F32, "bf16x3": _lib.ACTOR_BF16X3}
+
+    def __init__(self, weights, device="cuda", ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False, math="f32"):
+        """math: arithmetic of the 64 x 64 layer.  "f32" (default) = exact f32 MFMA, bit-for-bit the documented fmaf chain;
+        "bf16x3" = every f32 operand as three bf16 terms, six bf16 MFMAs with f32 accumulation: f32-class accuracy (within
+        2e-6 of the action bound of the f32 result), about twice the collection rate."""
         import torch
+        if math not in self.MATH:
+            raise ValueError("math must be 'f32' or 'bf16x3'")
+        self.math = math
         self.device = torch.device(device)
         self.ou, self.theta, self.sigma, self.dt = bool(ou), float(theta), float(sigma), float(dt)
         self.reset_on_done = bool(reset_on_done)
@@ -115,7 +123,7 @@ class DeviceActor:
         """MrsimActor for the envs [first, first + count) of an n-env set (the OU state pointer advanced to `first`)."""
         ou = self.ou_tensor(n)
         return _lib.MrsimActor(self.blob.data_ptr(), None if ou is None else ou.data_ptr() + first * 8, self.theta,
-                               self.sigma, self.dt, int(self.reset_on_done))
+                               self.sigma, self.dt, int(self.reset_on_done), self.MATH[self.math], 0)
 
     def forward(self, env, obs=None, out=None):
         """actions[N,2] = actor.predict(obs) + actor_noise() as a kernel of its own, for env's NEXT step (same RNG words

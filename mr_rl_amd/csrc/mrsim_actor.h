@@ -33,15 +33,45 @@
 namespace mrsim {
 
 constexpr int kActHidden = 64;
-// packed parameter block (float offsets); the kernels copy it to LDS once per block
+// Arithmetic of the 64 x 64 layer (MrsimActor.math):
+//   kActF32     exact f32 on v_mfma_f32_32x32x2_f32 (the definition above; bitwise against the oracle).  On gfx950 this
+//               instruction runs at the f32 VECTOR rate and -- measured -- does not overlap the vector unit's own work: the
+//               fused rollout takes (MFMA cycles + VALU cycles).
+//   kActBf16x3  every f32 operand split into three bf16 terms x = x1 + x2 + x3 (round-to-nearest, 24 mantissa bits in all)
+//               and the six products a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 run on v_mfma_f32_32x32x16_bf16 with f32
+//               accumulation: bf16 x bf16 products are exact in f32, the dropped terms are below 2^-24 |a||b|, so the layer
+//               keeps f32-class accuracy (tests: <= 2e-6 of the action bound against the oracle's emulation of the same
+//               splits, <= 1e-5 against PyTorch fp32) at 6/16 of the f32-MFMA cycles, on the matrix cores proper, which
+//               DO run beside the vector unit.
+enum : int { kActOff = 0, kActF32 = 1, kActBf16x3 = 2 };
+// packed parameter block (float offsets); the kernels copy the part their arithmetic needs to LDS once per block
 constexpr int kActA1 = 0;                    // [rt 2][s 3][lane 64]      layer-1 A operands
 constexpr int kActA2 = kActA1 + 2 * 3 * 64;  // [rt 2][s4 8][lane 64][4]  layer-2 A operands, four k-steps per ds_read_b128
 constexpr int kActC1 = kActA2 + 64 * 64;     // [h 2][q 32]               b1 in accumulator layout
 constexpr int kActC2 = kActC1 + 64;          // [h 2][q 32]               b2 in accumulator layout
 constexpr int kActW3 = kActC2 + 64;          // [h 2][o 2][q 32]          output layer, per lane half
 constexpr int kActTail = kActW3 + 128;       // b3[2], bound[2]
-constexpr int kActBlobFloats = kActTail + 8; // padded to a multiple of 4 floats (copied as float4)
-static_assert(kActBlobFloats % 4 == 0, "blob is copied as float4");
+constexpr int kActF32Floats = kActTail + 8;  // end of the f32 section, padded to a multiple of 4 floats (copied as float4)
+// bf16x3 section: layer-2 A operands [rt 2][s 4][part 3][lane 64][8 bf16]: one ds_read_b128 per (row tile, k-step, part)
+constexpr int kActA2bf = kActF32Floats;
+constexpr int kActA2bfFloats = 2 * 4 * 3 * 64 * 4;
+constexpr int kActBlobFloats = kActF32Floats + kActA2bfFloats;
+static_assert(kActF32Floats % 4 == 0 && kActBlobFloats % 4 == 0, "blob is copied as float4");
+
+// LDS image per arithmetic (float offsets).  f32: the f32 section as it is.  bf16x3: the f32 section WITHOUT its 16 KiB of
+// layer-2 operands, then the bf16 section (27 KiB instead of 43).
+template <int MODE> struct ActLds;
+template <> struct ActLds<kActF32> {
+    static constexpr int A1 = kActA1, A2 = kActA2, C1 = kActC1, C2 = kActC2, W3 = kActW3, Tail = kActTail, A2bf = 0,
+                         Floats = kActF32Floats;
+};
+template <> struct ActLds<kActBf16x3> {
+    static constexpr int A1 = 0, A2 = 0, C1 = kActA2, C2 = C1 + 64, W3 = C2 + 64, Tail = W3 + 128, A2bf = Tail + 8,
+                         Floats = A2bf + kActA2bfFloats;
+};
+template <> struct ActLds<kActOff> {
+    static constexpr int A1 = 0, A2 = 0, C1 = 0, C2 = 0, W3 = 0, Tail = 0, A2bf = 0, Floats = 4;
+};
 
 __host__ __device__ constexpr int act_kperm(int q, int h) { return 32 * (q / 16) + 8 * ((q % 16) / 4) + 4 * h + (q % 4); }
 
@@ -49,11 +79,23 @@ typedef float act_f32x16 __attribute__((ext_vector_type(16)));
 typedef float act_f32x4 __attribute__((ext_vector_type(4)));
 
 // copy the parameter block HBM -> LDS (all threads of the block; caller synchronises)
+__device__ __forceinline__ void act_copy4(const float* __restrict__ src, float* __restrict__ dst, int nfloats, unsigned tid,
+                                          unsigned nthreads) {
+    const act_f32x4* __restrict__ s4 = reinterpret_cast<const act_f32x4*>(src);
+    act_f32x4* __restrict__ d4 = reinterpret_cast<act_f32x4*>(dst);
+    for (unsigned k = tid; k < (unsigned)(nfloats / 4); k += nthreads) d4[k] = s4[k];
+}
+template <int MODE>
 __device__ __forceinline__ void actor_stage_blob(const float* __restrict__ blob, float* __restrict__ s_blob, unsigned tid,
                                                  unsigned nthreads) {
-    const act_f32x4* __restrict__ src = reinterpret_cast<const act_f32x4*>(blob);
-    act_f32x4* __restrict__ dst = reinterpret_cast<act_f32x4*>(s_blob);
-    for (unsigned k = tid; k < (unsigned)(kActBlobFloats / 4); k += nthreads) dst[k] = src[k];
+    using L = ActLds<MODE>;
+    if constexpr (MODE == kActF32) {
+        act_copy4(blob, s_blob, kActF32Floats, tid, nthreads);
+    } else if constexpr (MODE == kActBf16x3) {
+        act_copy4(blob + kActA1, s_blob + L::A1, kActA2 - kActA1, tid, nthreads);             // layer-1 operands
+        act_copy4(blob + kActC1, s_blob + L::C1, kActF32Floats - kActC1, tid, nthreads);      // biases, output layer, tail
+        act_copy4(blob + kActA2bf, s_blob + L::A2bf, kActA2bfFloats, tid, nthreads);          // layer-2 bf16 terms
+    }
 }
 
 // exp(x) for x in [-20, 20]: Cephes expf (Cody-Waite reduction by ln 2, degree-5 polynomial), explicit fmaf, exact ldexp.
@@ -107,31 +149,27 @@ __device__ __forceinline__ void lds_load16(const float* __restrict__ p, act_f32x
 // measured: actions off by 5e-4 in one kernel instantiation and right in another.)
 __device__ __forceinline__ float act_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 
-// The layer-2 A operands of this lane (its 2 x 32 weights W2[32 rt + (lane & 31)][kperm(q, lane >> 5)]) as registers:
-// a fused rollout loads them once per launch instead of once per tile and step (16 ds_read_b128 per tile pass whose
-// latency a wave alone on its SIMD cannot hide).
-struct ActorRegs {
-    float a2[2][32];
-};
-__device__ __forceinline__ void actor_load_regs(const float* __restrict__ sA, ActorRegs& R) {
-    const unsigned lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int s4 = 0; s4 < 8; ++s4) {
-            const act_f32x4 a4 = *reinterpret_cast<const act_f32x4*>(sA + kActA2 + ((rt * 8 + s4) * 64 + lane) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) R.a2[rt][4 * s4 + j] = a4[j];
-        }
+typedef __bf16 act_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 act_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float act_f32x2 __attribute__((ext_vector_type(2)));
+
+// x = x1 + x2 + x3, each term a bf16 (v_cvt_pk_bf16_f32: round to nearest even), two values at a time.  The residuals are
+// exact in f32 (x1 keeps x's leading 8 bits: x - x1 has at most 16 significant bits left).
+__device__ __forceinline__ void act_split3(float x0, float x1, act_bf16x2 (&t)[3]) {
+    const act_f32x2 v = {x0, x1};
+    t[0] = __builtin_convertvector(v, act_bf16x2);
+    const act_f32x2 r1 = v - __builtin_convertvector(t[0], act_f32x2);
+    t[1] = __builtin_convertvector(r1, act_bf16x2);
+    const act_f32x2 r2 = r1 - __builtin_convertvector(t[1], act_f32x2);
+    t[2] = __builtin_convertvector(r2, act_bf16x2);
 }
 
-// actor.predict for the 64 envs of this wave.  obs: this lane's env's observation (already scaled if the caller scales);
-// a[2]: scaled_out of this lane's env.  Must be called by ALL 64 lanes in uniform control flow (MFMA and
-// v_permlane32_swap are wave-wide operations); lanes without an env pass any finite values.
-// REGS: layer-2 weights come from `R` (actor_load_regs) instead of LDS.
-template <bool REGS>
-__device__ __forceinline__ void actor_forward(const float* __restrict__ sA, const ActorRegs& R, const float (&obs)[5],
-                                              float (&a)[2]) {
+// actor.predict for the 64 envs of this wave.  obs: this lane's env's observation; a[2]: scaled_out of this lane's env.
+// sA: the LDS image of the parameter block for this arithmetic (actor_stage_blob<MODE>).  Must be called by ALL 64 lanes in
+// uniform control flow (MFMA and v_permlane32_swap are wave-wide operations); lanes without an env pass any finite values.
+template <int MODE>
+__device__ __forceinline__ void actor_forward(const float* __restrict__ sA, const float (&obs)[5], float (&a)[2]) {
+    using L = ActLds<MODE>;
     // layer-1 B operands: at k-step s lane (j, h) of column tile ct supplies obs[2 s + h] of env 32 ct + j.  One half swap
     // per k-step pair turns "lane = env" registers into both tiles' operands: {x[2s].lo | x[2s+1].lo}, {x[2s].hi | x[2s+1].hi}.
     float b1op[2][3];
@@ -158,35 +196,66 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
         act_f32x16 acc1[2], acc2[2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            lds_load16(sA + kActC1 + h * 32 + rt * 16, acc1[rt]);
+            lds_load16(sA + L::C1 + h * 32 + rt * 16, acc1[rt]);
 #pragma unroll
             for (int s = 0; s < 3; ++s)
-                acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[kActA1 + (rt * 3 + s) * 64 + lane], bop[s], acc1[rt], 0, 0, 0);
+                acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[L::A1 + (rt * 3 + s) * 64 + lane], bop[s], acc1[rt], 0, 0, 0);
         }
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) lds_load16(sA + kActC2 + h * 32 + rt * 16, acc2[rt]);
+        for (int rt = 0; rt < 2; ++rt) lds_load16(sA + L::C2 + h * 32 + rt * 16, acc2[rt]);
+        if constexpr (MODE == kActF32) {
 #pragma unroll
-        for (int s4 = 0; s4 < 8; ++s4) {
-            act_f32x4 a4[2];
+            for (int s4 = 0; s4 < 8; ++s4) {
+                act_f32x4 a4[2];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                if constexpr (REGS) a4[rt] = act_f32x4{R.a2[rt][4 * s4], R.a2[rt][4 * s4 + 1], R.a2[rt][4 * s4 + 2], R.a2[rt][4 * s4 + 3]};
-                else a4[rt] = *reinterpret_cast<const act_f32x4*>(sA + kActA2 + ((rt * 8 + s4) * 64 + lane) * 4);
+                for (int rt = 0; rt < 2; ++rt)
+                    a4[rt] = *reinterpret_cast<const act_f32x4*>(sA + L::A2 + ((rt * 8 + s4) * 64 + lane) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = 4 * s4 + j;
+                    const float b = act_relu(acc1[q / 16][q % 16]);  // ReLU of layer 1
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt][j], b, acc2[rt], 0, 0, 0);
+                }
             }
+        } else {
+            // bf16 x 3: k-step s of the 32x32x16 instruction sums 16 features -- lane half h supplies its registers 8 s .. 8 s + 7,
+            // i.e. features kperm(8 s + jj, h), and the weights are stored pre-permuted and pre-split to match.
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = 4 * s4 + j;
-                const float b = act_relu(acc1[q / 16][q % 16]);  // ReLU of layer 1
+            for (int s = 0; s < 4; ++s) {
+                // the three bf16 terms of this k-step's eight activations, split right before their MFMAs (12 registers live
+                // instead of 48 for the whole tile)
+                act_bf16x8 bp[3];
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt][j], b, acc2[rt], 0, 0, 0);
+                for (int jj = 0; jj < 8; jj += 2) {
+                    const int q = 8 * s + jj;
+                    act_bf16x2 t[3];
+                    act_split3(act_relu(acc1[q / 16][q % 16]), act_relu(acc1[(q + 1) / 16][(q + 1) % 16]), t);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) { bp[p][jj] = t[p][0]; bp[p][jj + 1] = t[p][1]; }
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    act_bf16x8 ap[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        ap[p] = *reinterpret_cast<const act_bf16x8*>(sA + L::A2bf + (((rt * 4 + s) * 3 + p) * 64 + lane) * 4);
+                    // smallest terms first: a3 b1, a2 b2, a1 b3 (2^-16), a2 b1, a1 b2 (2^-8), a1 b1
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], bp[0], acc2[rt], 0, 0, 0);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bp[1], acc2[rt], 0, 0, 0);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[2], acc2[rt], 0, 0, 0);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bp[0], acc2[rt], 0, 0, 0);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[1], acc2[rt], 0, 0, 0);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[0], acc2[rt], 0, 0, 0);
+                }
             }
         }
         // output layer on the vector unit: this lane's 32 features of env (32 ct + j), two partial sums per output
         float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
         for (int q4 = 0; q4 < 8; ++q4) {
-            const act_f32x4 w0 = *reinterpret_cast<const act_f32x4*>(sA + kActW3 + (h * 2 + 0) * 32 + q4 * 4);
-            const act_f32x4 w1 = *reinterpret_cast<const act_f32x4*>(sA + kActW3 + (h * 2 + 1) * 32 + q4 * 4);
+            const act_f32x4 w0 = *reinterpret_cast<const act_f32x4*>(sA + L::W3 + (h * 2 + 0) * 32 + q4 * 4);
+            const act_f32x4 w1 = *reinterpret_cast<const act_f32x4*>(sA + L::W3 + (h * 2 + 1) * 32 + q4 * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int q = 4 * q4 + j;
@@ -203,8 +272,8 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0][o]), __float_as_uint(part[1][o]), false, false);
-        const float pre = (__uint_as_float(r[0]) + __uint_as_float(r[1])) + sA[kActTail + o];
-        a[o] = spec_tanhf(pre) * sA[kActTail + 2 + o];
+        const float pre = (__uint_as_float(r[0]) + __uint_as_float(r[1])) + sA[L::Tail + o];
+        a[o] = spec_tanhf(pre) * sA[L::Tail + 2 + o];
     }
 }
 

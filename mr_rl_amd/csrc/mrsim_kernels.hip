@@ -43,13 +43,12 @@ __device__ __forceinline__ void obs_from_state(const KParams& P, uint32_t fl, co
 }
 
 // action = actor.predict(obs) + actor_noise()  (RL/MR_ddpg.py:277) for this lane's env; all 64 lanes call it
-template <int OUNZ, bool REGS = false>
+template <int OUNZ, int MODE>
 __device__ __forceinline__ void actor_policy(const KParams& P, uint32_t fl, const ActorArgs& ac, const float* __restrict__ s_actor,
                                              const float (&obs)[5], int32_t counter, const uint32_t* w, float& ou0, float& ou1,
-                                             float& af, float& aa, const ActorRegs* regs = nullptr) {
+                                             float& af, float& aa) {
     float a[2];
-    if constexpr (REGS) actor_forward<true>(s_actor, *regs, obs, a);
-    else { ActorRegs none; actor_forward<false>(s_actor, none, obs, a); }
+    actor_forward<MODE>(s_actor, obs, a);
     af = a[0]; aa = a[1];
     if (fl & kFActorOU) {
         if ((fl & kFOUReset) && counter == 0) ou0 = ou1 = 0.0f;
@@ -88,21 +87,23 @@ struct IOArgs {
 // from P).  ACT: the action comes from the in-kernel actor (+ OU noise) evaluated on the env's current observation;
 // every lane of a wave then runs the whole body (MFMA and the half swaps are wave-wide), lanes past n on a copy of
 // the last env, and only the stores are predicated.
-template <bool RK45, int NZ, bool MIS, bool AOS, uint32_t FL = 0, bool ACT = false>
+// (ACT = kActOff / kActF32 / kActBf16x3: the arithmetic of the actor's 64 x 64 layer, mrsim_actor.h)
+template <bool RK45, int NZ, bool MIS, bool AOS, uint32_t FL = 0, int ACT = kActOff>
 __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const StateArgs st, const IOArgs io, const ActorArgs ac) {
+    constexpr bool HAS_ACT = ACT != kActOff;
     __shared__ __attribute__((aligned(16))) float s_obs[AOS ? kBlock * 5 : 4];
-    __shared__ __attribute__((aligned(16))) float s_actor[ACT ? kActBlobFloats : 4];
-    if constexpr (ACT) {
-        actor_stage_blob(ac.blob, s_actor, threadIdx.x, kBlock);
+    __shared__ __attribute__((aligned(16))) float s_actor[ActLds<ACT>::Floats];
+    if constexpr (ACT != kActOff) {
+        actor_stage_blob<ACT>(ac.blob, s_actor, threadIdx.x, kBlock);
         __syncthreads();
     }
     const long long base = (long long)blockIdx.x * kBlock;
     const long long i = base + threadIdx.x;
     const bool active = i < P.n;
-    const long long il = (ACT && !active) ? P.n - 1 : i;
+    const long long il = (HAS_ACT && !active) ? P.n - 1 : i;
     StepOut o;
     const uint32_t fl = FL != 0 ? FL : P.flags;
-    if (active || ACT) {
+    if (active || HAS_ACT) {
         EnvRegs e;
         load_env(st.pos, st.aux, st.ep_ret, il, P, e);
         const Rng R = make_rng(P, il);
@@ -112,23 +113,23 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
             const float2 a = reinterpret_cast<const float2*>(io.actions)[il];
             af = a.x; aa = a.y;
         }
-        step_prologue<RK45, NZ, MIS>(P, R, !ACT && !(fl & kFActions), W, af, aa, ACT && (fl & kFActorOU));
+        step_prologue<RK45, NZ, MIS>(P, R, !HAS_ACT && !(fl & kFActions), W, af, aa, HAS_ACT && (fl & kFActorOU));
         float ou0 = 0.f, ou1 = 0.f;
-        if constexpr (ACT) {
+        if constexpr (HAS_ACT) {
             float obs_cur[5];
             obs_from_state(P, fl, io.goal_table, R.env, e, obs_cur);
             if (fl & kFActorOU) {
                 const float2 u = reinterpret_cast<const float2*>(ac.ou_state)[il];
                 ou0 = u.x; ou1 = u.y;
             }
-            actor_policy<ou_nz<NZ>()>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
+            actor_policy<ou_nz<NZ>(), ACT>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
         }
         int fail = 0;
         env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, (double)af, (double)aa, W, fl, o, fail,
                                 MRSIM_ROLLOUT_TABLE ? kSinCosTab : nullptr);  // same arithmetic as the rollout: equal bits
         if (active) {
             store_env(st.pos, st.aux, st.ep_ret, i, P, e);
-            if constexpr (ACT) {
+            if constexpr (HAS_ACT) {
                 if (fl & kFActorOU) reinterpret_cast<float2*>(ac.ou_state)[i] = make_float2(ou0, ou1);
             }
             io.rew[i] = o.rew;
@@ -283,21 +284,23 @@ __device__ __forceinline__ void rotate_wave_priority(unsigned t, unsigned slot) 
 // step (or, for t = 0, the state) produced -- the DDPG collection loop of RL/MR_ddpg.py:270-311 without leaving the
 // registers.  All 64 lanes of a wave then run the whole loop (MFMA and the half swaps are wave-wide), lanes past n on a
 // copy of the last env, and only their stores are predicated.
-template <bool RK45, int NZ, bool MIS, uint32_t FL, bool ACT>
+// BLOCK: threads per workgroup (the bf16x3 actor's 27 KiB LDS image + the 16 KiB sin/cos table are shared by 8 waves).
+template <bool RK45, int NZ, bool MIS, uint32_t FL, int ACT, int BLOCK = kBlock>
 __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& st, const RolloutArgs& ra, const ActorArgs& ac) {
     // All per-step stores use a wave-uniform base (block start of row t, kept in SGPRs) plus a 32-bit
     // per-lane offset, so no 64-bit address arithmetic runs on the vector unit inside the time loop.
-    const long long blk0 = (long long)blockIdx.x * kBlock;
+    constexpr bool HAS_ACT = ACT != kActOff;
+    const long long blk0 = (long long)blockIdx.x * BLOCK;
     const unsigned tid = threadIdx.x;
     const long long i_raw = blk0 + tid;
     const bool active = i_raw < P.n;
-    const long long i = (ACT && !active) ? P.n - 1 : i_raw;
-    __shared__ __attribute__((aligned(16))) float s_actor[ACT ? kActBlobFloats : 4];
-    if constexpr (ACT) actor_stage_blob(ac.blob, s_actor, tid, kBlock);  // the barrier below (or its own) publishes it
+    const long long i = (HAS_ACT && !active) ? P.n - 1 : i_raw;
+    __shared__ __attribute__((aligned(16))) float s_actor[ActLds<ACT>::Floats];
+    if constexpr (ACT != kActOff) actor_stage_blob<ACT>(ac.blob, s_actor, tid, BLOCK);  // the barrier below (or its own) publishes it
 #if MRSIM_ROLLOUT_TABLE == 1
     // sin/cos table of the action heading (mrsim_device.h: sincos_tab): 16 KiB per block, read once from L2 per launch
     __shared__ __attribute__((aligned(16))) double2 s_sincos[MRSIM_SINCOS_N];
-    for (unsigned k = tid; k < MRSIM_SINCOS_N; k += kBlock) s_sincos[k] = kSinCosTab[k];
+    for (unsigned k = tid; k < MRSIM_SINCOS_N; k += BLOCK) s_sincos[k] = kSinCosTab[k];
     __syncthreads();
     const double2* __restrict__ sincos_lds = s_sincos;
 #elif MRSIM_ROLLOUT_TABLE == 2
@@ -306,9 +309,9 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     const double2* __restrict__ sincos_lds = nullptr;
 #endif
 #if MRSIM_ROLLOUT_TABLE != 1
-    if constexpr (ACT) __syncthreads();
+    if constexpr (HAS_ACT) __syncthreads();
 #endif
-    if constexpr (!ACT) { if (!active) return; }
+    if constexpr (!HAS_ACT) { if (!active) return; }
     EnvRegs e;
 #ifdef MRSIM_WAVE_PROBE
     const unsigned long long clk0 = wall_clock64();
@@ -335,12 +338,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     }
     float obs_cur[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float ou0 = 0.f, ou1 = 0.f;
-#ifndef MRSIM_ACTOR_A2REG   // 1: the fused rollout keeps the lane's 64 layer-2 weights in registers for the whole launch (measured:
-#define MRSIM_ACTOR_A2REG 0 // 1081 us at two waves per SIMD against 1055 us with the weights re-read from LDS; four waves: 1014 us)
-#endif
-    ActorRegs aregs;
-    if constexpr (ACT && MRSIM_ACTOR_A2REG) actor_load_regs(s_actor, aregs);
-    if constexpr (ACT) {
+    if constexpr (HAS_ACT) {
         obs_from_state(P, FL != 0 ? FL : P.flags, ra.goal_table, P.env_id0 + (uint32_t)i, e, obs_cur);
         if ((FL != 0 ? FL : P.flags) & kFActorOU) {
             const float2 u = reinterpret_cast<const float2*>(ac.ou_state)[i];
@@ -351,9 +349,9 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
 #ifndef MRSIM_ACTOR_PRIO   // issue priority of the actor-in-the-loop kernel (A/B, tools/actor_probe.py): 0 none, 1 rotate per step
 #define MRSIM_ACTOR_PRIO 1 // like the plain rollout, 2 fixed by wave slot, 3 high in the MFMA phase, 4 high in the VALU phase
 #endif
-    if constexpr (ACT && MRSIM_ACTOR_PRIO == 2) rotate_wave_priority(0u, slot);
+    if constexpr (HAS_ACT && MRSIM_ACTOR_PRIO == 2) rotate_wave_priority(0u, slot);
     for (int t = 0; t < ra.T; ++t) {
-        if constexpr (ACT) {
+        if constexpr (HAS_ACT) {
             if constexpr (MRSIM_ACTOR_PRIO == 1) rotate_wave_priority((unsigned)t, slot);
             if constexpr (MRSIM_ACTOR_PRIO == 3) __builtin_amdgcn_s_setprio(3);
             if constexpr (MRSIM_ACTOR_PRIO == 4) __builtin_amdgcn_s_setprio(0);
@@ -389,13 +387,13 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
 #define MRSIM_PRE_RESET 0 // (step_prologue_with_reset).  Measured SLOWER on the mixed trajectory set, 145.8 vs 140.8 us per launch,
 #endif                    // same bits (profiles/r03/ab_pre_reset_mixed.txt): 27 more vector instructions in EVERY wave-step cost
                           // more than the 34 they save in the 0.9 reset blocks per wave-step.
-        constexpr bool kPreReset = MRSIM_PRE_RESET != 0 && !ACT && RK45 && NZ == kNoiseFast && FL != 0 && (FL & kFGoalTable) != 0 &&
+        constexpr bool kPreReset = MRSIM_PRE_RESET != 0 && !HAS_ACT && RK45 && NZ == kNoiseFast && FL != 0 && (FL & kFGoalTable) != 0 &&
                                    (FL & kFAutoReset) != 0;
         uint32_t wr_pre[4] = {0u, 0u, 0u, 0u};
         if constexpr (kPreReset) step_prologue_with_reset<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa, wr_pre);
-        else step_prologue<RK45, NZ, MIS>(P, R, !ACT && !(fl & kFActions), W, af, aa, ACT && (fl & kFActorOU));
-        if constexpr (ACT) {
-            actor_policy<ou_nz<NZ>(), MRSIM_ACTOR_A2REG != 0>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa, &aregs);
+        else step_prologue<RK45, NZ, MIS>(P, R, !HAS_ACT && !(fl & kFActions), W, af, aa, HAS_ACT && (fl & kFActorOU));
+        if constexpr (HAS_ACT) {
+            actor_policy<ou_nz<NZ>(), ACT>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
             if constexpr (MRSIM_ACTOR_PRIO == 3) __builtin_amdgcn_s_setprio(0);
             if constexpr (MRSIM_ACTOR_PRIO == 4) __builtin_amdgcn_s_setprio(3);
         }
@@ -403,7 +401,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         StepOut o;
         env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr,
                                 kPreReset ? wr_pre : nullptr);
-        if constexpr (ACT) {
+        if constexpr (HAS_ACT) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) obs_cur[j] = o.obs[j];  // what the policy sees next (the reset row after an auto-reset)
         }
@@ -420,7 +418,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         // The [T][N] outputs are write-once streams the kernel never reads back: non-temporal stores (+1 %)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef double f64x2 __attribute__((ext_vector_type(2)));
-        if (ACT && !active) continue;  // a lane past n: nothing to store
+        if (HAS_ACT && !active) continue;  // a lane past n: nothing to store
         if (fl & kFOutTraj) {
             const f64x2 v = {o.px, o.py};
             __builtin_nontemporal_store(v, &(reinterpret_cast<f64x2*>(ra.traj_xy) + row)[tid]);
@@ -461,9 +459,9 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
             if (fl & kFOutFinalLen) ra.final_len[i] = o.flen;
         }
     }
-    if (ACT && !active) return;
+    if (HAS_ACT && !active) return;
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
-    if constexpr (ACT) {
+    if constexpr (HAS_ACT) {
         if (P.flags & kFActorOU) reinterpret_cast<float2*>(ac.ou_state)[i] = make_float2(ou0, ou1);
     }
     if (fail && (P.flags & kFOutStatus)) atomicOr(ra.status, fail);
@@ -482,29 +480,32 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
 
 template <bool RK45, int NZ, bool MIS, uint32_t FL = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void mr_rollout_kernel(const KParams P, const StateArgs st, const RolloutArgs ra) {
-    rollout_body<RK45, NZ, MIS, FL, false>(P, st, ra, ActorArgs{nullptr, nullptr, {0.f, 0.f}});
+    rollout_body<RK45, NZ, MIS, FL, kActOff>(P, st, ra, ActorArgs{nullptr, nullptr, {0.f, 0.f}});
 }
 
 // The same loop with the actor as its policy source.  Register budget: two 32-register accumulator tiles of the layer
 // being computed + the env state.  The flag-specialised DDPG collection kernel fits four waves per SIMD with 7 - 8 spilled
-// dwords (measured faster than three waves without spills, 1014 vs 1096 us per 51-step launch at N = 262 144: that launch
-// is exactly four waves per SIMD, so three resident waves leave a fourth to run alone); the generic instantiations
-// (test-oriented modes) take three.  The kernel is bound by the matrix pipe: 140 f32 MFMAs of 64 cycles per wave and step.
+// dwords (measured faster than three waves without spills at N = 262 144: that launch is exactly four waves per SIMD, so
+// three resident waves leave a fourth to run alone); the generic instantiations (test-oriented modes) take three.
+// f32 arithmetic: bound by the f32 MFMAs (140 x 64 cycles per wave and step) PLUS the vector work, which this instruction
+// does not overlap.  bf16x3 arithmetic: 512-thread blocks (8 waves share the 43 KiB of LDS).
 #ifndef MRSIM_ACTOR_WAVES
 #define MRSIM_ACTOR_WAVES 4
 #endif
 #ifndef MRSIM_ACTOR_WAVES_GENERIC
 #define MRSIM_ACTOR_WAVES_GENERIC 3
 #endif
-template <bool RK45, int NZ, bool MIS, uint32_t FL = 0>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES_GENERIC, 8))) void mr_rollout_actor_kernel(
+constexpr int kBlockBf = 512;
+template <int ACT> constexpr int actor_block() { return ACT == kActBf16x3 ? kBlockBf : kBlock; }
+template <bool RK45, int NZ, bool MIS, uint32_t FL, int ACT>
+__global__ __launch_bounds__(actor_block<ACT>()) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES_GENERIC, 8))) void mr_rollout_actor_kernel(
     const KParams P, const StateArgs st, const RolloutArgs ra, const ActorArgs ac) {
-    rollout_body<RK45, NZ, MIS, FL, true>(P, st, ra, ac);
+    rollout_body<RK45, NZ, MIS, FL, ACT, actor_block<ACT>()>(P, st, ra, ac);
 }
-template <bool RK45, int NZ, bool MIS, uint32_t FL>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES, 8))) void mr_rollout_actor_fl_kernel(
+template <bool RK45, int NZ, bool MIS, uint32_t FL, int ACT>
+__global__ __launch_bounds__(actor_block<ACT>()) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES, 8))) void mr_rollout_actor_fl_kernel(
     const KParams P, const StateArgs st, const RolloutArgs ra, const ActorArgs ac) {
-    rollout_body<RK45, NZ, MIS, FL, true>(P, st, ra, ac);
+    rollout_body<RK45, NZ, MIS, FL, ACT, actor_block<ACT>()>(P, st, ra, ac);
 }
 
 // ---------------------------------------------------------------------------
@@ -513,12 +514,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRSIM_AC
 // The gym-loop form (this kernel, then mrsim_step with its output) and the fused forms (mr_step_kernel / mr_rollout_actor_kernel
 // with ACT) evaluate the same device functions on the same bits: equal actions.  aux: the env state's {f0x, f0y, hq, counter}
 // records, read only for the episode-start reset of the OU state (kFOUReset).
-template <int OUNZ>
+template <int OUNZ, int ACT>
 __global__ __launch_bounds__(kBlock) void mr_actor_kernel(const KParams P, const ActorArgs ac, const float* __restrict__ obs,
                                                           int obs_layout, const float* __restrict__ aux,
                                                           float* __restrict__ actions) {
-    __shared__ __attribute__((aligned(16))) float s_actor[kActBlobFloats];
-    actor_stage_blob(ac.blob, s_actor, threadIdx.x, kBlock);
+    __shared__ __attribute__((aligned(16))) float s_actor[ActLds<ACT>::Floats];
+    actor_stage_blob<ACT>(ac.blob, s_actor, threadIdx.x, kBlock);
     __syncthreads();
     const long long i_raw = (long long)blockIdx.x * kBlock + threadIdx.x;
     const bool active = i_raw < P.n;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(kBlock) void mr_actor_kernel(const KParams P, const
         if (fl & kFOUReset) counter = __float_as_int(reinterpret_cast<const float4*>(aux)[i].w);
     }
     float af, aa;
-    actor_policy<OUNZ>(P, fl, ac, s_actor, o, counter, w, ou0, ou1, af, aa);
+    actor_policy<OUNZ, ACT>(P, fl, ac, s_actor, o, counter, w, ou0, ou1, af, aa);
     if (!active) return;
     reinterpret_cast<float2*>(actions)[i] = make_float2(af, aa);
     if (fl & kFActorOU) reinterpret_cast<float2*>(ac.ou_state)[i] = make_float2(ou0, ou1);
@@ -712,13 +713,17 @@ struct LaunchCfg {
     hipEvent_t start, stop;  // both null: plain launch
 };
 
+template <int BLOCK, typename Kern, typename... Args>
+static int launch_b(const LaunchCfg& lc, Kern kern, long long n, Args... args) {
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    if (grid == 0) return MRSIM_OK;
+    if (lc.start != nullptr) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, lc.stream, lc.start, lc.stop, 0, args...);
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), 0, lc.stream, args...);
+    return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+}
 template <typename Kern, typename... Args>
 static int launch(const LaunchCfg& lc, Kern kern, long long n, Args... args) {
-    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
-    if (grid == 0) return MRSIM_OK;
-    if (lc.start != nullptr) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, lc.stream, lc.start, lc.stop, 0, args...);
-    else hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, lc.stream, args...);
-    return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+    return launch_b<kBlock>(lc, kern, n, args...);
 }
 
 // runtime (integrator, noise variant, mismatch) -> template instantiation
@@ -751,11 +756,16 @@ static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams&
                        const ActorArgs& AC) {
     const bool aos = p->obs_layout == MRSIM_OBS_AOS;
     if (K.flags & kFActor) {  // policy source = in-kernel actor (RK45 only, checked by the caller)
+        const bool bf = (K.flags & kFActorBf16) != 0;
         return dispatch(true, noise_variant(p), p->mismatched != 0, [&](auto, auto NZ, auto MIS) {
             constexpr bool mis = decltype(MIS)::value;
             constexpr int nz = decltype(NZ)::value;
-            if (aos) return launch(lc, mr_step_kernel<true, nz, mis, true, 0, true>, K.n, K, S, IO, AC);
-            return launch(lc, mr_step_kernel<true, nz, mis, false, 0, true>, K.n, K, S, IO, AC);
+            if (bf) {
+                if (aos) return launch(lc, mr_step_kernel<true, nz, mis, true, 0, kActBf16x3>, K.n, K, S, IO, AC);
+                return launch(lc, mr_step_kernel<true, nz, mis, false, 0, kActBf16x3>, K.n, K, S, IO, AC);
+            }
+            if (aos) return launch(lc, mr_step_kernel<true, nz, mis, true, 0, kActF32>, K.n, K, S, IO, AC);
+            return launch(lc, mr_step_kernel<true, nz, mis, false, 0, kActF32>, K.n, K, S, IO, AC);
         });
     }
     if ((K.flags & ~kFStepBase) == kFlGym && p->integrator == MRSIM_INT_RK45 && noise_variant(p) == kNoiseFast)
@@ -783,7 +793,9 @@ static int actor_args(const MrsimParams* p, const MrsimActor* a, bool have_actio
     // x += theta (mu - x) dt + sigma sqrt(dt) N(0,1), mu = 0: the two products, formed in double and rounded once
     AC.ou.theta_dt = (float)((double)a->ou_theta * (double)a->ou_dt);
     AC.ou.sigma_sqrt_dt = (float)((double)a->ou_sigma * std::sqrt((double)a->ou_dt));
-    bits = kFActor | (a->ou_state ? kFActorOU : 0u) | ((a->ou_state && a->ou_reset_on_done) ? kFOUReset : 0u);
+    if (a->math != MRSIM_ACTOR_F32 && a->math != MRSIM_ACTOR_BF16X3) return MRSIM_EINVAL;
+    bits = kFActor | (a->ou_state ? kFActorOU : 0u) | ((a->ou_state && a->ou_reset_on_done) ? kFOUReset : 0u) |
+           (a->math == MRSIM_ACTOR_BF16X3 ? kFActorBf16 : 0u);
     on = true;
     return MRSIM_OK;
 }
@@ -811,13 +823,14 @@ static int launch_rollout_fl(const LaunchCfg& lc, int nz, bool mis, const KParam
     return MRSIM_OK;
 }
 
-template <uint32_t FL>
+template <uint32_t FL, int ACT>
 static int launch_rollout_actor_fl(const LaunchCfg& lc, int nz, bool mis, const KParams& K, const StateArgs& S,
                                    const RolloutArgs& ra, const ActorArgs& AC, bool& handled) {
     handled = true;
+    constexpr int B = actor_block<ACT>();
     if (nz == kNoiseFast)
-        return mis ? launch(lc, mr_rollout_actor_fl_kernel<true, kNoiseFast, true, FL>, K.n, K, S, ra, AC)
-                   : launch(lc, mr_rollout_actor_fl_kernel<true, kNoiseFast, false, FL>, K.n, K, S, ra, AC);
+        return mis ? launch_b<B>(lc, mr_rollout_actor_fl_kernel<true, kNoiseFast, true, FL, ACT>, K.n, K, S, ra, AC)
+                   : launch_b<B>(lc, mr_rollout_actor_fl_kernel<true, kNoiseFast, false, FL, ACT>, K.n, K, S, ra, AC);
     handled = false;
     return MRSIM_OK;
 }
@@ -1010,10 +1023,16 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     if (actor_on) {
         const int nz = noise_variant(p);
         const bool mis = p->mismatched != 0;
-        if (K.flags == kFlDdpgActor) rc = launch_rollout_actor_fl<kFlDdpgActor>(lc, nz, mis, K, S, ra, AC, handled);
+        const bool bf = (K.flags & kFActorBf16) != 0;
+        if (K.flags == kFlDdpgActor) rc = launch_rollout_actor_fl<kFlDdpgActor, kActF32>(lc, nz, mis, K, S, ra, AC, handled);
+        else if (K.flags == (kFlDdpgActor | kFActorBf16))
+            rc = launch_rollout_actor_fl<kFlDdpgActor | kFActorBf16, kActBf16x3>(lc, nz, mis, K, S, ra, AC, handled);
         if (!handled)
             rc = dispatch(true, nz, mis, [&](auto, auto NZ, auto MIS) {
-                return launch(lc, mr_rollout_actor_kernel<true, decltype(NZ)::value, decltype(MIS)::value>, K.n, K, S, ra, AC);
+                constexpr int z = decltype(NZ)::value;
+                constexpr bool m = decltype(MIS)::value;
+                if (bf) return launch_b<kBlockBf>(lc, mr_rollout_actor_kernel<true, z, m, 0, kActBf16x3>, K.n, K, S, ra, AC);
+                return launch(lc, mr_rollout_actor_kernel<true, z, m, 0, kActF32>, K.n, K, S, ra, AC);
             });
         handled = true;
     } else if (p->integrator == MRSIM_INT_RK45) {
@@ -1132,6 +1151,34 @@ int mrsim_actor_pack_host(const MrsimActorWeights* w, float* blob) {
         blob[kActTail + o] = w->b3[o];
         blob[kActTail + 2 + o] = w->action_bound[o];
     }
+    // bf16x3 section: W2 = W2_1 + W2_2 + W2_3, each term a bf16 (round to nearest even; the residuals are exact in f32);
+    // element jj of lane (r, h) at k-step s is the weight of feature kperm(8 s + jj, h): what that lane half's B operand
+    // (its accumulator registers 8 s .. 8 s + 7) holds
+    auto bf16_rne = [](float x) -> uint16_t {
+        uint32_t u;
+        std::memcpy(&u, &x, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // NaN stays NaN
+        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    auto bf16_f32 = [](uint16_t b) -> float {
+        const uint32_t u = (uint32_t)b << 16;
+        float x;
+        std::memcpy(&x, &u, 4);
+        return x;
+    };
+    uint16_t* bf = reinterpret_cast<uint16_t*>(blob + kActA2bf);
+    for (int rt = 0; rt < 2; ++rt)
+        for (int s = 0; s < 4; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float x = w->w2[(32 * rt + (lane & 31)) * H + act_kperm(8 * s + jj, lane >> 5)];
+                    float r = x;
+                    for (int part = 0; part < 3; ++part) {
+                        const uint16_t t = bf16_rne(r);
+                        bf[((((rt * 4 + s) * 3 + part) * 64 + lane) * 8) + jj] = t;
+                        r -= bf16_f32(t);
+                    }
+                }
     return MRSIM_OK;
 }
 
@@ -1155,8 +1202,13 @@ int mrsim_actor_forward(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     if ((rc = check_device())) return rc;
     K.flags |= abits;
     const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
-    if (noise_variant(p) == kNoiseFast) return launch(lc, mr_actor_kernel<kNoiseFast>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
-    return launch(lc, mr_actor_kernel<kNoiseSpec>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
+    const bool fastnz = noise_variant(p) == kNoiseFast;
+    if (abits & kFActorBf16) {
+        if (fastnz) return launch(lc, mr_actor_kernel<kNoiseFast, kActBf16x3>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
+        return launch(lc, mr_actor_kernel<kNoiseSpec, kActBf16x3>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
+    }
+    if (fastnz) return launch(lc, mr_actor_kernel<kNoiseFast, kActF32>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
+    return launch(lc, mr_actor_kernel<kNoiseSpec, kActF32>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
 }
 
 int mrsim_velocity(int64_t n, int32_t T, int32_t n_filter, const double* traj_xy, const double* time, double* v_xy,

@@ -521,6 +521,26 @@ float orc_spec_tanhf(float x) {
     return x < 0.0f ? -r : r;
 }
 
+/* bf16 helpers of the bf16 x 3 arithmetic: round-to-nearest-even as v_cvt_pk_bf16_f32 does, x = x1 + x2 + x3 */
+static float bf16_round(float x) {
+    uint32_t u = f2u(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return x;
+    u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+    return u2f(u);
+}
+static void bf16_split3(float x, float t[3]) {
+    t[0] = bf16_round(x);
+    const float r1 = x - t[0];
+    t[1] = bf16_round(r1);
+    const float r2 = r1 - t[1];
+    t[2] = bf16_round(r2);
+}
+
+/* fills OrcActor.w2_split from w2 (call after setting the weights, before math = 1 evaluations) */
+void orc_actor_prepare(OrcActor* a) {
+    for (int i = 0; i < 64 * 64; ++i) bf16_split3(a->w2[i], a->w2_split + 3 * i);
+}
+
 /* ActorNetwork.predict (RL/MR_ddpg.py:145-148) -> scaled_out (:136-137) */
 void orc_actor_forward(const OrcActor* a, const float obs[5], float act[2]) {
     float h1[64], h2[64];
@@ -529,11 +549,34 @@ void orc_actor_forward(const OrcActor* a, const float obs[5], float act[2]) {
         for (int k = 0; k < 5; ++k) acc = fmaf(a->w1[f * 5 + k], obs[k], acc);
         h1[f] = acc > 0.0f ? acc : 0.0f;
     }
-    for (int f = 0; f < 64; ++f) {                              /* fully_connected 64 + batch norm (folded), relu  :125-127 */
-        float acc = a->b2[f];
-        for (int q = 0; q < 32; ++q)
-            for (int h = 0; h < 2; ++h) acc = fmaf(a->w2[f * 64 + act_kperm(q, h)], h1[act_kperm(q, h)], acc);
-        h2[f] = acc > 0.0f ? acc : 0.0f;
+    if (a->math == 0) {
+        for (int f = 0; f < 64; ++f) {                          /* fully_connected 64 + batch norm (folded), relu  :125-127 */
+            float acc = a->b2[f];
+            for (int q = 0; q < 32; ++q)
+                for (int h = 0; h < 2; ++h) acc = fmaf(a->w2[f * 64 + act_kperm(q, h)], h1[act_kperm(q, h)], acc);
+            h2[f] = acc > 0.0f ? acc : 0.0f;
+        }
+    } else {
+        /* bf16 x 3: k-step s of v_mfma_f32_32x32x16_bf16 sums the 16 features kperm(8 s + jj, h), h = 0..1, jj = 0..7; six
+         * MFMAs per k-step in the kernel's order (a3 b1, a2 b2, a1 b3, a2 b1, a1 b2, a1 b1) */
+        static const int term[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+        float hs[64][3];
+        for (int k = 0; k < 64; ++k) bf16_split3(h1[k], hs[k]);
+        for (int f = 0; f < 64; ++f) {
+            float acc = a->b2[f];
+            const float* ws = a->w2_split + (size_t)f * 64 * 3;   /* orc_actor_prepare: the three terms of W2[f][k] */
+            for (int s = 0; s < 4; ++s)
+                for (int m = 0; m < 6; ++m) {
+                    double sum = 0.0;
+                    for (int h = 0; h < 2; ++h)
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const int k = act_kperm(8 * s + jj, h);
+                            sum += (double)ws[k * 3 + term[m][0]] * (double)hs[k][term[m][1]];
+                        }
+                    acc = (float)((double)acc + sum);
+                }
+            h2[f] = acc > 0.0f ? acc : 0.0f;
+        }
     }
     for (int o = 0; o < 2; ++o) {                               /* fully_connected 2, tanh, * action_bound  :130-137 */
         float p[2] = {0.0f, 0.0f};

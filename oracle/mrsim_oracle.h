@@ -147,7 +147,14 @@ typedef struct {
     float ou_sigma_sqrt_dt;/* sigma * sqrt(dt)                                           */
     int32_t ou_enabled;    /* 0: actor.predict alone                                     */
     int32_t ou_reset_on_done; /* 1: x_prev := 0 at the first step of an episode (counter == 0) */
+    int32_t math;          /* 0: f32 fmaf chains (bitwise = the kernel's f32 MFMA); 1: the 64 x 64 layer in bf16 x 3    */
+                           /*    arithmetic -- the same operand splits as the kernel, products exact, the 16 products of  */
+                           /*    one MFMA summed exactly and added to the f32 accumulator with one rounding (the          */
+                           /*    hardware's internal order is not documented: compared with a 2e-6 tolerance)             */
+    int32_t reserved0;
+    float w2_split[64 * 64 * 3]; /* [f][k][term]: the bf16 terms of w2, filled by orc_actor_prepare                   */
 } OrcActor;
+void orc_actor_prepare(OrcActor* a);
 float orc_spec_tanhf(float x);
 void orc_actor_forward(const OrcActor* a, const float obs[5], float act[2]);
 /* action = actor.predict(obs) + actor_noise(); ou[2] is OUNoise.x_prev, updated in place.  The OU pair's normals are

@@ -50,7 +50,7 @@ class OrcActor(C.Structure):
         ("w1", C.c_float * 320), ("b1", C.c_float * 64), ("w2", C.c_float * 4096), ("b2", C.c_float * 64),
         ("w3", C.c_float * 128), ("b3", C.c_float * 2), ("bound", C.c_float * 2),
         ("ou_theta_dt", C.c_float), ("ou_sigma_sqrt_dt", C.c_float), ("ou_enabled", C.c_int32),
-        ("ou_reset_on_done", C.c_int32),
+        ("ou_reset_on_done", C.c_int32), ("math", C.c_int32), ("reserved0", C.c_int32), ("w2_split", C.c_float * 12288),
     ]
 
 
@@ -113,6 +113,7 @@ def lib():
         L.orc_spec_tanhf.argtypes = [C.c_float]
         L.orc_spec_tanhf.restype = C.c_float
         L.orc_actor_forward.argtypes = [C.POINTER(OrcActor), fp, fp]
+        L.orc_actor_prepare.argtypes = [C.POINTER(OrcActor)]
         L.orc_vec_actor_policy.argtypes = [C.POINTER(OrcActor), C.c_int, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         _lib = L
@@ -136,7 +137,7 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def make_actor(w, ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False):
+def make_actor(w, ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False, math="f32"):
     """OrcActor from the inference-form weights dict {w1 [64,5], b1, w2 [64,64], b2, w3 [2,64], b3, obs_scale [5],
     action_bound [2]} (mr_rl_amd.actor.fold_actor's output): the obs scaling is folded into w1 exactly as
     mrsim_actor_pack_host does (float32 product)."""
@@ -152,6 +153,8 @@ def make_actor(w, ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False):
     a.ou_theta_dt = np.float32(np.float64(np.float32(theta)) * np.float64(np.float32(dt)))
     a.ou_sigma_sqrt_dt = np.float32(np.float64(np.float32(sigma)) * np.sqrt(np.float64(np.float32(dt))))
     a.ou_enabled, a.ou_reset_on_done = int(bool(ou)), int(bool(reset_on_done))
+    a.math = {"f32": 0, "bf16x3": 1}[math]
+    lib().orc_actor_prepare(C.byref(a))
     return a
 
 

@@ -67,7 +67,17 @@ def test_pack_layout_places_every_weight_where_the_kernel_reads_it():
             assert C1[h, q] == w["b1"][kperm(q, h)] and C2[h, q] == w["b2"][kperm(q, h)]
             for o in range(2):
                 assert W3[h, o, q] == w["w3"][o, kperm(q, h)]
-    assert list(blob[4736:4740]) == [9001, 9002, 20, 6.25] and not blob[4740:].any()
+    assert list(blob[4736:4740]) == [9001, 9002, 20, 6.25] and not blob[4740:4744].any()
+    # bf16x3 section [rt 2][s 4][part 3][lane 64][8 bf16]: the three terms of W2[f][kperm(8 s + jj, h)] sum back to it exactly
+    bf = blob[4744:].view(np.uint16).reshape(2, 4, 3, 64, 8)
+    as_f32 = (bf.astype(np.uint32) << 16).view(np.float32)
+    for rt in range(2):
+        for lane in (0, 17, 31, 32, 63):
+            f, h = 32 * rt + (lane & 31), lane >> 5
+            for sk in range(4):
+                for jj in range(8):
+                    terms = as_f32[rt, sk, :, lane, jj].astype(np.float64)
+                    assert terms.sum() == float(w["w2"][f, kperm(8 * sk + jj, h)])
     bad = _lib.MrsimActorWeights()
     assert _lib.lib().mrsim_actor_pack_host(C.byref(bad), blob.ctypes.data_as(C.c_void_p)) == _lib.EINVAL
 

@@ -22,6 +22,9 @@ from tests.util import orc_params_from_cfg, random_actor
 
 pytestmark = pytest.mark.gpu
 ACTOR_TOL = 1e-5   # relative to action_bound, HIP fp32 vs PyTorch fp32 (scaled observations, the twin's configuration)
+BF_TOL = 5e-6      # relative to action_bound: HIP bf16x3 layer vs the oracle's emulation of the same operand splits (the
+                   # order in which the hardware sums the 16 products of one MFMA is not documented; the emulation sums
+                   # them exactly and rounds once)
 POS_TOL = 1e-6
 SCALE = [0.01] * 5
 
@@ -47,13 +50,14 @@ def _obs(n, seed=0):
 
 @pytest.mark.parametrize("n", [1, 63, 64, 255, 257, 4096])
 @pytest.mark.parametrize("layout", ["aos", "soa"])
-def test_actor_kernel_matches_pytorch_and_oracle(n, layout):
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_actor_kernel_matches_pytorch_and_oracle(n, layout, math):
     """mrsim_actor_forward without noise: vs Actor.forward (PyTorch fp32, GPU) within ACTOR_TOL of the bound, vs the oracle
     bitwise; ragged sizes exercise the lanes-past-n handling of the wave-wide MFMA."""
     from mr_rl_amd.actor import fold_actor
     for seed, out_scale in ((0, None), (1, 30.0)):
         m = random_actor(seed, out_scale=out_scale)
-        act = _actor(m, ou=False)
+        act = _actor(m, ou=False, math=math)
         env = _env(n, obs_layout=layout, noise_var=0.0)
         obs = _obs(n, seed)
         obs_t = torch.from_numpy(obs).cuda()
@@ -63,8 +67,11 @@ def test_actor_kernel_matches_pytorch_and_oracle(n, layout):
             want = m.cuda()(obs_t * torch.tensor(SCALE, device="cuda")).cpu().numpy()
         bound = m.action_bound.cpu().numpy()
         assert (np.abs(got - want) / bound).max() < ACTOR_TOL
-        orc = O.actor_forward(O.make_actor(fold_actor(m.cpu(), SCALE)), obs)
-        assert np.array_equal(got, orc), np.abs(got - orc).max()
+        orc = O.actor_forward(O.make_actor(fold_actor(m.cpu(), SCALE), math=math), obs)
+        if math == "f32":
+            assert np.array_equal(got, orc), np.abs(got - orc).max()      # an f32 MFMA is the oracle's fmaf chain, bit for bit
+        else:
+            assert (np.abs(got - orc) / bound).max() < BF_TOL, (np.abs(got - orc) / bound).max()
 
 
 def test_actor_kernel_raw_observations_tolerance():
@@ -120,11 +127,12 @@ def _gym_loop(env, act, T, rec):
 
 @pytest.mark.parametrize("mis", [False, True])
 @pytest.mark.parametrize("sigma", [0.0, 1.0])
-def test_fused_step_equals_actor_kernel_then_step(mis, sigma):
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_fused_step_equals_actor_kernel_then_step(mis, sigma, math):
     n, T = 1000, 60
     m = random_actor(4, out_scale=20.0)
     envA, envB = (_env(n, seed=9, noise_var=sigma, is_mismatched=mis, auto_reset=True) for _ in range(2))
-    actA, actB = _actor(m), _actor(m)
+    actA, actB = _actor(m, math=math), _actor(m, math=math)
     envA.reset(); envB.reset()
     rec = {"actions": [], "obs": [], "rew": [], "done": []}
     _gym_loop(envA, actA, T, rec)
@@ -139,14 +147,15 @@ def test_fused_step_equals_actor_kernel_then_step(mis, sigma):
 
 @pytest.mark.parametrize("n", [1, 63, 257, 1000])
 @pytest.mark.parametrize("mis", [False, True])
-def test_fused_rollout_equals_gym_loop_bitwise(n, mis):
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_fused_rollout_equals_gym_loop_bitwise(n, mis, math):
     """mrsim_rollout with MrsimRolloutIO.actor (carry f32) == T x (mrsim_actor_forward -> mrsim_step): every action,
     observation, reward, done flag, the final state and the OU state; two launches back to back (state / OU state /
     observation re-derived from HBM at the launch boundary)."""
     T = 70
     m = random_actor(6, out_scale=25.0)
     envA, envB = (_env(n, seed=5, env_id0=11, noise_var=1.0, is_mismatched=mis, auto_reset=True) for _ in range(2))
-    actA, actB = _actor(m), _actor(m)
+    actA, actB = _actor(m, math=math), _actor(m, math=math)
     envA.reset(); envB.reset()
     rec = {"actions": [], "obs": [], "rew": [], "done": []}
     _gym_loop(envA, actA, T, rec)
@@ -161,7 +170,7 @@ def test_fused_rollout_equals_gym_loop_bitwise(n, mis):
     envB.check_status()
 
 
-def _closed_loop_oracle(cfg, m, n, T, seed, gpu, id0=0, reset_on_done=False, threads=8, exact_actions=True):
+def _closed_loop_oracle(cfg, m, n, T, seed, gpu, id0=0, reset_on_done=False, threads=8, exact_actions=True, math="f32"):
     """The collection loop on the CPU, teacher-forced: at every step the oracle's actor sees the observation the KERNEL's
     actor saw (row t - 1 of the kernel's observations; the reset observation for t = 0) and must produce the kernel's
     action (bitwise with noise_math="spec"); the oracle's env is then stepped with the kernel's action and must land where
@@ -171,7 +180,7 @@ def _closed_loop_oracle(cfg, m, n, T, seed, gpu, id0=0, reset_on_done=False, thr
     from mr_rl_amd.actor import fold_actor
     orc = O.VecOracle(n, orc_params_from_cfg(cfg), seed=seed, env_id0=id0, threads=threads)
     free = O.VecOracle(n, orc_params_from_cfg(cfg), seed=seed, env_id0=id0, threads=threads)
-    A = O.make_actor(fold_actor(m, SCALE), ou=True, reset_on_done=reset_on_done)
+    A = O.make_actor(fold_actor(m, SCALE), ou=True, reset_on_done=reset_on_done, math=math)
     orc.reset(0)
     obs_free = free.reset(0).astype(np.float32)
     ou, ou_free = np.zeros((n, 2), dtype=np.float32), np.zeros((n, 2), dtype=np.float32)
@@ -223,14 +232,15 @@ def test_fused_rollout_against_the_oracle_closed_loop(reset_on_done):
     assert worst["free_action"] < 1e-4 and worst["free_pos"] < 2e-5, worst
 
 
-def test_config4_full_size_actor_in_the_loop_against_the_oracle():
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_config4_full_size_actor_in_the_loop_against_the_oracle(math):
     """BASELINE config 4's 262 144 envs, one 51-step episode + the reset row, fast noise, actor + OU in the kernel,
     element-wise against the CPU restatement of the same loop (teacher-forced; the OU normals of noise_math="fast" are
-    within 1e-6 + 8e-7 r of the oracle's, so actions are compared to 1e-6 of the bound instead of bitwise)."""
+    within 1e-6 + 8e-7 r of the oracle's, so actions are compared to 1e-6 of the bound instead of bitwise; bf16x3: BF_TOL)."""
     n, T, seed = 262144, 52, 7
     m = random_actor(9, out_scale=15.0)
     env = _env(n, seed=seed, noise_var=1.0, auto_reset=True)
-    act = _actor(m)
+    act = _actor(m, math=math)
     obs0 = env.reset().cpu().numpy().copy()
     out = env.rollout(T, want=("traj", "obs", "done", "actions", "rew"), actor=act, carry="f64")
     env.check_status()
@@ -238,25 +248,26 @@ def test_config4_full_size_actor_in_the_loop_against_the_oracle():
     gpu = {"obs0": obs0, "obs": out["obs"].cpu().numpy(), "actions": out["actions"].cpu().numpy(),
            "done": out["done"].cpu().numpy().astype(np.uint8), "traj": out["traj"].cpu().numpy()}
     worst, ou, orc, free = _closed_loop_oracle(env.cfg, m, n, T, seed, gpu, threads=O.lib().orc_num_threads(),
-                                               exact_actions=False)
-    assert worst["action"] < 1e-6 and worst["pos"] < 5 * POS_TOL, worst
+                                               exact_actions=False, math=math)
+    assert worst["action"] < (1e-6 if math == "f32" else BF_TOL) and worst["pos"] < 5 * POS_TOL, worst
     assert worst["free_action"] < 1e-4 and worst["free_pos"] < 2e-5, worst
     assert (env.final_len == 51).all() and gpu["done"][50].all()
 
 
-def test_collector_with_actor_policy_equals_single_launch():
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_collector_with_actor_policy_equals_single_launch(math):
     from mr_rl_amd import MRConfig
     from mr_rl_amd.collector import RolloutCollector
     n, seed = 5000, 13
     m = random_actor(10, out_scale=10.0)
     env = _env(n, seed=seed, noise_var=1.0, auto_reset=True)
-    actA = _actor(m)
+    actA = _actor(m, math=math)
     env.reset()
     want = [env.rollout(51, want=("obs", "rew", "done", "actions"), actor=actA, carry="f64") for _ in range(1)]
     w = {k: v.clone() for k, v in want[0].items() if not k.startswith("_")}
     w2 = env.rollout(51, want=("obs", "rew", "done", "actions"), actor=actA, carry="f64")
     for S in (1, 2, 3):
-        actB = _actor(m)
+        actB = _actor(m, math=math)
         col = RolloutCollector(n, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=seed, streams=S, policy=actB)
         col.reset()
         col.collect()

@@ -16,6 +16,7 @@ ap.add_argument("--launches", type=int, default=200)
 ap.add_argument("--discard", type=int, default=50)
 ap.add_argument("--envs", type=int, default=262144)
 ap.add_argument("--no-ou", action="store_true")
+ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"])
 ap.add_argument("--streams", type=int, nargs="*", default=[], help="also time the RolloutCollector (wall clock) with these stream counts")
 ap.add_argument("--mismatched", action="store_true")
 a = ap.parse_args()
@@ -28,7 +29,7 @@ for tag in (a.variants or [None]):
     e = MRVecEnv(a.envs, cfg=cfg, seed=7)
     if tag is not None:
         e._L = _lib.load(os.path.join(ROOT, "mr_rl_amd", "variants", f"libmrsim_{tag}.so"))
-    act = DeviceActor.from_module(module, obs_scale=[0.01] * 5, device=e.device, ou=not a.no_ou)
+    act = DeviceActor.from_module(module, obs_scale=[0.01] * 5, device=e.device, ou=not a.no_ou, math=a.math)
     e.reset()
     buf = {}
     pool = [_lib.EventPair() for _ in range(a.launches)]
@@ -39,7 +40,7 @@ for tag in (a.variants or [None]):
     e.check_status()
     med = statistics.median(ms)
     print(f"{tag or 'in-tree':14s} median {med * 1e3:9.1f} us  min {min(ms) * 1e3:9.1f} us  {a.envs * T / med / 1e6:7.2f} G env-steps/s "
-          f"in-kernel  actor {a.envs * T * flop / med / 1e9:6.1f} TFLOP/s f32", flush=True)
+          f"in-kernel  actor {a.envs * T * flop / med / 1e9:6.1f} TFLOP/s (algorithmic, math={a.math})", flush=True)
     for S in a.streams:
         import time
         from mr_rl_amd.collector import RolloutCollector

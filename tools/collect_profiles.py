@@ -36,7 +36,8 @@ def sha16(path):
 EXPECTED = ["kt", "kt_s1", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
                                              for p in ("pmc_f64", "pmc_f32", "pmc_step", "cal", "cal262k")] + \
            [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")] + \
-           ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed"]
+           ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed",
+            "kt_actor_bf", "pmc_actor_bf_a"]
 if not os.path.exists(f"{src}/status.txt"):
     die(f"{src}/status.txt not found (did tools/profile_round.sh {tag} run?)")
 status = dict(l.split() for l in open(f"{src}/status.txt").read().splitlines() if l.strip())
@@ -249,6 +250,31 @@ files["pmc_actor.json"] = json.dumps({
     "hbm_bytes_per_launch": (2 * fr["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024,
     "hbm_bytes_per_env_step": (2 * fr["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024 / (N * T),
     "raw": {"a": ca, "b": cb}, "source": [prov(kta), prov(fa), prov(fb), prov(f1), prov(f2)]}, indent=1) + "\n"
+# ---- ... and in bf16 x 3 arithmetic
+ACTB = "mr_rollout_actor_fl_kernel<true, 2, false, 40565893u"
+files["kernel_stats_actor_rollout_bf16x3.csv"] = open(the_csv("kt_actor_bf", "kernel_stats.csv")).read()
+ktb = the_csv("kt_actor_bf", "kernel_trace.csv")
+bdur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(ktb)) if ACTB in r["Kernel_Name"]]
+if len(bdur) < 100:
+    die(f"{ktb}: {len(bdur)} dispatches of the bf16x3 actor rollout kernel")
+bdur = bdur[50:]
+cba, _, grid_b, fba = counters("pmc_actor_bf_a", ACTB, 0.0)
+wb = grid_b / 64
+bavg = sum(bdur) / len(bdur)
+exec_flops = wb * T * (96 * 32 * 32 * 16 * 2 + 12 * 32 * 32 * 2 * 2)
+files["pmc_actor_bf16x3.json"] = json.dumps({
+    "what": "the fused actor rollout with MrsimActor.math = BF16X3 (tools/actor_probe.py --math bf16x3): kernel trace durations and SQ "
+            "counters per wave and env step.  executed_mfma_tflops = the flops the 96 bf16 + 12 f32 MFMAs per wave-step execute / "
+            "duration, against the 2.5 PFLOP/s dense bf16 peak; the kernel is bound by vector-instruction issue (valu_insts minus "
+            "mfma_insts per wave-step), not by the matrix pipe",
+    **stamp, "kernel": "mr_rollout_actor_fl_kernel<RK45,fast,nominal,DDPG|carry64|actor|OU|bf16x3>, 512-thread blocks", "N": N, "T": T,
+    "avg_kernel_us": round(bavg, 2), "median_kernel_us": round(sorted(bdur)[len(bdur) // 2], 2), "dispatches_timed": len(bdur),
+    "in_kernel_env_steps_per_s": round(N * T / (bavg * 1e-6), 1),
+    "algorithmic_actor_tflops": round(N * T * FLOP / (bavg * 1e-6) / 1e12, 2),
+    "executed_mfma_tflops": round(exec_flops / (bavg * 1e-6) / 1e12, 1), "mfma_bf16_peak_tflops": 2500.0,
+    "mfma_frac_of_bf16_peak": round(exec_flops / (bavg * 1e-6) / 1e12 / 2500.0, 4),
+    "per_wave_step": {k: round(v / wb / T, 2) for k, v in sorted(cba.items())},
+    "source": [prov(ktb), prov(fba)]}, indent=1) + "\n"
 # ---- mixed trajectory set: VALU instructions per wave-step of the goal-table kernel
 cm, _, grid_m, fm = counters("valu_a_mixed", "mr_rollout_kernel<true, 2, false")
 files["pmc_mixed_set.json"] = json.dumps({
