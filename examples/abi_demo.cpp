@@ -1,7 +1,10 @@
 // A consumer of libmrsim's C ABI without Python or torch: device buffers from the HIP runtime, one
 // MR_Env episode of N envs through mrsim_reset / mrsim_step, then the same episode through ONE
 // mrsim_rollout launch, and a check that both give the same bits and the reference's episode shape
-// (51 steps, reward 10 per step, done by timeout: MR_env.py:62,89,136-152).
+// (51 steps, reward 10 per step, done by timeout: MR_env.py:62,89,136-152).  Then the DDPG collection loop of
+// RL/MR_ddpg.py:270-311 with the actor on the device (ABI 3): fold a batch norm, pack the network, upload the block, and
+// compare one episode as 51 x (mrsim_actor_forward -> mrsim_step) with the same episode as one mrsim_rollout whose policy
+// source is the in-kernel actor -- actions and positions must agree bitwise.
 //
 // Build: make -C mr_rl_amd/csrc demo      Run: examples/abi_demo [n_envs]
 #include <hip/hip_runtime.h>
@@ -110,11 +113,78 @@ int main(int argc, char** argv) {
     }
     std::printf("%s: n=%lld  done@51=%lld  done@50=%lld  return==510: %lld  rollout==steps (bitwise): %lld\n", name,
                 (long long)n, (long long)n_done, (long long)done_before_end, (long long)n_ret, (long long)n_same);
+    // (3) RL/MR_ddpg.py:277-278 with the actor as a policy source: actor.predict(state) + actor_noise(), env.step(action)
+    int64_t act_same = 0, act_moved = 0;
+    {
+        const int H = MRSIM_ACTOR_HIDDEN;
+        std::vector<float> w1(H * 5), b1(H), g(H), be(H), mu(H), var(H), w1f(H * 5), b1f(H), w2(H * H), b2(H), w3(2 * H), b3(2);
+        uint32_t lcg = 12345u;
+        auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)(lcg >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f; };
+        for (auto& v : w1) v = 0.4f * rnd();
+        for (auto& v : w2) v = 0.12f * rnd();
+        for (auto& v : w3) v = 0.3f * rnd();
+        for (int i = 0; i < H; ++i) { b1[i] = 0.1f * rnd(); b2[i] = 0.1f * rnd(); g[i] = 1.0f + 0.3f * rnd(); be[i] = 0.1f * rnd();
+                                      mu[i] = 0.2f * rnd(); var[i] = 1.0f + 0.5f * rnd(); }
+        b3[0] = b3[1] = 0.0f;
+        // tflearn batch_normalization at inference, folded into the first fully_connected layer
+        SIM_OK(mrsim_actor_fold_bn_host(H, 5, w1.data(), b1.data(), g.data(), be.data(), mu.data(), var.data(), 1e-5f,
+                                        w1f.data(), b1f.data()));
+        MrsimActorWeights W;
+        std::memset(&W, 0, sizeof(W));
+        W.w1 = w1f.data(); W.b1 = b1f.data(); W.w2 = w2.data(); W.b2 = b2.data(); W.w3 = w3.data(); W.b3 = b3.data();
+        for (int k = 0; k < 5; ++k) W.obs_scale[k] = 0.01f;
+        W.action_bound[0] = 20.0f; W.action_bound[1] = 6.2831853f;          // env.action_space.high, RL/MR_ddpg.py:345
+        std::vector<float> blob(MRSIM_ACTOR_BLOB_FLOATS);
+        SIM_OK(mrsim_actor_pack_host(&W, blob.data()));
+        float *blob_d = nullptr, *ou_a = nullptr, *ou_b = nullptr, *act_a = nullptr, *act_T = nullptr;
+        HIP_OK(hipMalloc(&blob_d, blob.size() * sizeof(float)));
+        HIP_OK(hipMemcpy(blob_d, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_OK(hipMalloc(&ou_a, n * 2 * sizeof(float)));
+        HIP_OK(hipMalloc(&ou_b, n * 2 * sizeof(float)));
+        HIP_OK(hipMemset(ou_a, 0, n * 2 * sizeof(float)));
+        HIP_OK(hipMemset(ou_b, 0, n * 2 * sizeof(float)));
+        HIP_OK(hipMalloc(&act_a, n * 2 * sizeof(float)));
+        HIP_OK(hipMalloc(&act_T, (size_t)T * n * 2 * sizeof(float)));
+        MrsimActor actor_a = {blob_d, ou_a, 0.15f, 0.3f, 1e-2f, 0, MRSIM_ACTOR_F32, 0};   // OUNoise defaults, :60
+        MrsimActor actor_b = actor_a;
+        actor_b.ou_state = ou_b;
+        // gym-loop form on env a
+        SIM_OK(mrsim_reset(&p, n, 0, &a.st, nullptr, nullptr, nullptr, a.obs, 0, seed, 100, stream));
+        MrsimStepIO ia;
+        std::memset(&ia, 0, sizeof(ia));
+        ia.obs = a.obs; ia.rew = a.rew; ia.done = a.done; ia.actions = act_a;
+        std::vector<float> last_a(2 * n), last_b(2 * n);
+        for (int t = 1; t <= T; ++t) {
+            SIM_OK(mrsim_actor_forward(&p, n, 0, &actor_a, nullptr, a.obs, act_a, seed, 100 + (uint64_t)t, stream));
+            SIM_OK(mrsim_step(&p, n, 0, &a.st, &ia, seed, 100 + (uint64_t)t, stream));
+        }
+        HIP_OK(hipMemcpyAsync(last_a.data(), act_a, 2 * n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(pos_a.data(), a.st.pos, 2 * n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        // fused form on env b: the whole episode in one launch, the actor evaluated on the observation held in registers
+        SIM_OK(mrsim_reset(&p, n, 0, &b.st, nullptr, nullptr, nullptr, b.obs, 0, seed, 100, stream));
+        MrsimRolloutIO rb;
+        std::memset(&rb, 0, sizeof(rb));
+        rb.T = T; rb.actions_out_T = act_T; rb.actor = &actor_b;
+        SIM_OK(mrsim_rollout(&p, n, 0, &b.st, &rb, seed, 101, stream));
+        HIP_OK(hipMemcpyAsync(last_b.data(), act_T + (size_t)(T - 1) * n * 2, 2 * n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(pos_b.data(), b.st.pos, 2 * n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        for (int64_t i = 0; i < n; ++i) {
+            act_same += std::memcmp(&last_a[2 * i], &last_b[2 * i], 2 * sizeof(float)) == 0 &&
+                        std::memcmp(&pos_a[2 * i], &pos_b[2 * i], 2 * sizeof(double)) == 0;
+            act_moved += last_a[2 * i] != 0.0f && last_a[2 * i] > -21.5f && last_a[2 * i] < 21.5f;
+        }
+        // one policy source per launch: actions AND actor is an argument error
+        rb.actions = act_T;
+        if (mrsim_rollout(&p, n, 0, &b.st, &rb, seed, 200, stream) != MRSIM_EINVAL) act_same = -1;
+        std::printf("actor in the loop: rollout(actor)==51 x (actor_forward -> step) (bitwise): %lld  actions in range: %lld\n",
+                    (long long)act_same, (long long)act_moved);
+    }
     // error behaviour of the boundary: bad arguments come back as codes, never as exceptions
     const bool errs = mrsim_step(nullptr, n, 0, &a.st, &io, seed, 0, stream) == MRSIM_EINVAL &&
                       mrsim_step(&p, -1, 0, &a.st, &io, seed, 0, stream) == MRSIM_EINVAL &&
                       mrsim_random_policy(&p, n, 0, a.rew + 1, seed, 0, stream) == MRSIM_EALIGN;
-    const bool ok = n_done == n && done_before_end == 0 && n_ret == n && n_same == n && errs;
+    const bool ok = n_done == n && done_before_end == 0 && n_ret == n && n_same == n && errs && act_same == n && act_moved == n;
     std::printf(ok ? "ABI_DEMO_OK\n" : "ABI_DEMO_FAIL\n");
     return ok ? 0 : 1;
 }
