@@ -143,11 +143,16 @@ __device__ __forceinline__ void lds_load16(const float* __restrict__ p, act_f32x
     v = act_f32x16{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
 }
 
-// ReLU as ONE instruction: v_med3_f32(x, 0, +inf) = max(x, 0) for every non-NaN x.  (__builtin_fmaxf canonicalises its
-// operand first: two v_max per activation.  An inline-asm v_max_f32 is NOT an option: the hazard recogniser cannot see
-// into asm, does not pad the MFMA-result -> VALU-read wait states, and the read returns the accumulator's old value --
-// measured: actions off by 5e-4 in one kernel instantiation and right in another.)
-__device__ __forceinline__ float act_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// ReLU as ONE instruction: v_max_i32 on the float's bits.  Non-negative floats order like their bit patterns and every
+// negative float (-0 included) is a negative integer, so max(bits, 0) IS max(x, 0) for every non-NaN x, with no
+// canonicalisation step.  (__builtin_fmaxf and v_med3_f32(x, 0, inf) both compile to TWO v_max_f32: canonicalise, then
+// max -- 256 of the kernel's 745 vector instructions per wave and step.  An inline-asm v_max_f32 is NOT an option: the hazard
+// recogniser cannot see into asm, does not pad the MFMA-result -> VALU-read wait states, and the read returns the
+// accumulator's old value -- measured: actions off by 5e-4 in one kernel instantiation and right in another.)
+__device__ __forceinline__ float act_relu(float x) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
 
 typedef __bf16 act_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 act_bf16x2 __attribute__((ext_vector_type(2)));
@@ -204,12 +209,28 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) lds_load16(sA + L::C2 + h * 32 + rt * 16, acc2[rt]);
         if constexpr (MODE == kActF32) {
+#ifndef MRSIM_ACTOR_PREFETCH   // where the A operands of k-step group s4 + 1 are requested: 0 = right behind the eight MFMAs of group
+#define MRSIM_ACTOR_PREFETCH 0 // s4, 1 = in front of them (two groups live), 2 = in front of their own MFMAs.  Built from one source and
+#endif                         // run on one box the three are equal (1010 - 1016 us per launch, profiles/r03/ab_actor_prefetch.txt); an
+                               // earlier A/B that had 4.5 % between two of them did not reproduce: box-to-box and build-to-build
+                               // (code placement) differences of this kernel are of that size.
+            act_f32x4 a4[2], a4n[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) a4[rt] = *reinterpret_cast<const act_f32x4*>(sA + L::A2 + ((rt * 8 + 0) * 64 + lane) * 4);
 #pragma unroll
             for (int s4 = 0; s4 < 8; ++s4) {
-                act_f32x4 a4[2];
+                if constexpr (MRSIM_ACTOR_PREFETCH == 2) {   // as first written: each group's operands requested right in front of it
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-                    a4[rt] = *reinterpret_cast<const act_f32x4*>(sA + L::A2 + ((rt * 8 + s4) * 64 + lane) * 4);
+                    for (int rt = 0; rt < 2; ++rt)
+                        a4[rt] = *reinterpret_cast<const act_f32x4*>(sA + L::A2 + ((rt * 8 + s4) * 64 + lane) * 4);
+                }
+                if constexpr (MRSIM_ACTOR_PREFETCH == 1) {
+                    if (s4 + 1 < 8) {
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+                            a4n[rt] = *reinterpret_cast<const act_f32x4*>(sA + L::A2 + ((rt * 8 + s4 + 1) * 64 + lane) * 4);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int q = 4 * s4 + j;
@@ -217,10 +238,21 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt][j], b, acc2[rt], 0, 0, 0);
                 }
+                if (s4 + 1 < 8 && MRSIM_ACTOR_PREFETCH != 2) {
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        if constexpr (MRSIM_ACTOR_PREFETCH == 1) a4[rt] = a4n[rt];
+                        else a4[rt] = *reinterpret_cast<const act_f32x4*>(sA + L::A2 + ((rt * 8 + s4 + 1) * 64 + lane) * 4);
+                    }
+                }
             }
         } else {
             // bf16 x 3: k-step s of the 32x32x16 instruction sums 16 features -- lane half h supplies its registers 8 s .. 8 s + 7,
             // i.e. features kperm(8 s + jj, h), and the weights are stored pre-permuted and pre-split to match.
+            // (operands of the NEXT (k-step, row tile) are requested right behind the six MFMAs of the current one, as in the f32 path)
+            act_bf16x8 ap[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ap[p] = *reinterpret_cast<const act_bf16x8*>(sA + L::A2bf + ((0 * 3 + p) * 64 + lane) * 4);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 // the three bf16 terms of this k-step's eight activations, split right before their MFMAs (12 registers live
@@ -236,10 +268,6 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
                 }
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    act_bf16x8 ap[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        ap[p] = *reinterpret_cast<const act_bf16x8*>(sA + L::A2bf + (((rt * 4 + s) * 3 + p) * 64 + lane) * 4);
                     // smallest terms first: a3 b1, a2 b2, a1 b3 (2^-16), a2 b1, a1 b2 (2^-8), a1 b1
                     acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], bp[0], acc2[rt], 0, 0, 0);
                     acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bp[1], acc2[rt], 0, 0, 0);
@@ -247,6 +275,12 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
                     acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bp[0], acc2[rt], 0, 0, 0);
                     acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[1], acc2[rt], 0, 0, 0);
                     acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[0], acc2[rt], 0, 0, 0);
+                    const int nxt = (rt == 0) ? ((1 * 4 + s) * 3) : ((0 * 4 + s + 1) * 3);   // (rt, s) -> ((rt * 4 + s) * 3 + part)
+                    if (rt == 0 || s + 1 < 4) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            ap[p] = *reinterpret_cast<const act_bf16x8*>(sA + L::A2bf + ((nxt + p) * 64 + lane) * 4);
+                    }
                 }
             }
         }

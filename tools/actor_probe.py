@@ -17,6 +17,7 @@ ap.add_argument("--discard", type=int, default=50)
 ap.add_argument("--envs", type=int, default=262144)
 ap.add_argument("--no-ou", action="store_true")
 ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"])
+ap.add_argument("--power", type=float, default=0.0, help="also run back to back for this many seconds and report package power / clock (hwmon)")
 ap.add_argument("--streams", type=int, nargs="*", default=[], help="also time the RolloutCollector (wall clock) with these stream counts")
 ap.add_argument("--mismatched", action="store_true")
 a = ap.parse_args()
@@ -41,6 +42,27 @@ for tag in (a.variants or [None]):
     med = statistics.median(ms)
     print(f"{tag or 'in-tree':14s} median {med * 1e3:9.1f} us  min {min(ms) * 1e3:9.1f} us  {a.envs * T / med / 1e6:7.2f} G env-steps/s "
           f"in-kernel  actor {a.envs * T * flop / med / 1e9:6.1f} TFLOP/s (algorithmic, math={a.math})", flush=True)
+    if a.power > 0:
+        import threading, time
+        import bench
+        h = bench.hwmon_of(e.device)
+        rd = lambda nm: int(open(os.path.join(h, nm)).read())  # noqa: E731
+        samples, stop = [], [False]
+
+        def sampler():
+            while not stop[0]:
+                samples.append((time.perf_counter(), rd("power1_input"), rd("freq1_input")))
+                time.sleep(0.02)
+        th = threading.Thread(target=sampler, daemon=True); th.start()
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < a.power:
+            for _ in range(50):
+                e.rollout(T, want=WANT, out=buf, actor=act, carry="f64")
+            torch.cuda.synchronize(); n += 50
+        t1 = time.perf_counter(); stop[0] = True; th.join()
+        load = [x for x in samples if t0 + 0.5 * (t1 - t0) < x[0] < t1]
+        print(f"{'':14s} power leg: {sum(x[1] for x in load) / len(load) * 1e-6:7.1f} W of cap {rd('power1_cap') * 1e-6:.0f} W, driver sclk "
+              f"{sum(x[2] for x in load) / len(load) * 1e-6:5.0f} MHz, {(t1 - t0) / n * 1e6:8.1f} us per launch over {t1 - t0:.1f} s", flush=True)
     for S in a.streams:
         import time
         from mr_rl_amd.collector import RolloutCollector
