@@ -784,6 +784,14 @@ def main():
     # clock settle (tools/clock_ramp_probe.py: ~35 ms of load after idle), independent of the W the caller asks for
     trace("env ready; settle phase: %d episodes" % args.settle_episodes)
     run(args.settle_episodes * ep)
+    if K <= 4 * ep:
+        # A timed region of a few launch groups (the driver's --steps 20) is mostly host time, and right behind hundreds of
+        # queued launches the HIP runtime is still retiring them: the next launches then cost 25 - 100 us instead of 13 - 22
+        # (tools/enqueue_profile.py).  Drain the settle phase, give the runtime 2 ms, and put the load back on for 60 episodes
+        # (7 ms) so that the region starts behind a SHORT queue with the chip still busy.
+        torch.cuda.synchronize(dev)
+        time.sleep(2e-3)
+        run(60 * ep)
     trace("settle issued; warm-up %d steps" % W)
     run(W)
     barrier()
