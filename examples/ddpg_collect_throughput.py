@@ -54,9 +54,10 @@ eager(2 * T)
 torch.cuda.synchronize()
 res["eager_pytorch_actor_G"] = rate(2 * T, time.perf_counter() - t0)
 
-# ---- device actor, gym-loop forms in a hipGraph of one episode
+# ---- device actor, gym-loop forms in a hipGraph of one episode (exact f32, then the bf16x3 arithmetic)
 actor = DeviceActor.from_module(agent.actor, obs_scale=SCALE, device=env.device)
-for form in ("gym", "step"):
+actor_bf_g = DeviceActor.from_module(agent.actor, obs_scale=SCALE, device=env.device, math="bf16x3")
+for form, pol in (("gym", actor), ("step", actor), ("gym_bf16x3", actor_bf_g), ("step_bf16x3", actor_bf_g)):
     e = MRVecEnv(N, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=0)
     e.reset()
     e.enable_device_step_base()
@@ -65,10 +66,10 @@ for form in ("gym", "step"):
     def body():
         e.step_idx = 0
         for _ in range(T):
-            if form == "gym":
-                e.step(actor.forward(e, out=acts))
+            if form.startswith("gym"):
+                e.step(pol.forward(e, out=acts))
             else:
-                e.step(actor=actor)
+                e.step(actor=pol)
         e.advance_step_base(T)
         e.step_idx = 0
 
