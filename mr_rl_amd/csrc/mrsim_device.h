@@ -1236,8 +1236,9 @@ __device__ __forceinline__ void pack_obs(double x, double y, double gx, double g
     obs[4] = __builtin_amdgcn_sqrtf((float)d2);  // v_sqrt_f32 (1 ulp); inputs are >= 0 and far from denormal
 }
 
-// MR_Env.step for one env (MR_env.py:70-98)
-template <bool RK45, int NZ, bool MIS>
+// MR_Env.step for one env (MR_env.py:70-98).  DEFER: on a terminal step only the terminal outputs are recorded; the caller
+// performs the auto-reset itself (the block-cooperative reset of the goal-table rollout, mrsim_kernels.hip).
+template <bool RK45, int NZ, bool MIS, bool DEFER = false>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
                                          EnvRegs& e, double act_f, double act_a, const StepWords<RK45, NZ, MIS>& W,
                                          uint32_t fl, StepOut& o, int& fail, const double2* __restrict__ sincos_lds = nullptr,
@@ -1306,6 +1307,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         for (int j = 0; j < 5; ++j) o.fobs[j] = o.obs[j];
         o.fret = e.ep_ret;
         o.flen = e.counter;
+        if constexpr (DEFER) return;
         double x0, y0, rx, ry;
         uint32_t wr[4];
         if (wr_pre != nullptr) { wr[0] = wr_pre[0]; wr[1] = wr_pre[1]; wr[2] = wr_pre[2]; wr[3] = wr_pre[3]; }  // drawn with the step's batch

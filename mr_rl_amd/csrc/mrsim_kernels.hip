@@ -290,11 +290,29 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     // All per-step stores use a wave-uniform base (block start of row t, kept in SGPRs) plus a 32-bit
     // per-lane offset, so no 64-bit address arithmetic runs on the vector unit inside the time loop.
     constexpr bool HAS_ACT = ACT != kActOff;
+#ifndef MRSIM_COOP_RESET   // A/B switch (off): block-cooperative auto-reset on goal-table launches (below).  Measured on the mixed
+#define MRSIM_COOP_RESET 0 // trajectory set: same bits, 154.4 vs 140.6 us per launch (profiles/r03/ab_coop_reset_mixed.txt) -- the
+#endif                     // block barrier every step costs more than three quarters of the reset instructions save.
+    // Block-cooperative auto-reset (goal-table launches: the mixed trajectory set).  There some lane of almost every wave
+    // terminates at almost every step (0.9 resetting waves per wave-step, 2.5 lanes each), and a wave that holds ONE such lane
+    // walks the whole ~110-instruction reset block (a Philox call, the start position, the constructor's draw and test) with
+    // 61 lanes idle.  Instead the waves of a block queue their terminated lanes in LDS and ONE wave per step (rotating, so that
+    // the four SIMDs share the work) resets them all, one per lane: same RNG counters, same arithmetic, same bits -- a quarter of
+    // the instructions.  A wave with more than kCoopMax terminated lanes (a whole cohort timing out together) resets them itself.
+    // (It needs a block barrier in every step, which puts the block's four waves -- one per SIMD -- in lockstep: slower, see above.)
+    constexpr bool COOP = MRSIM_COOP_RESET != 0 && !HAS_ACT && RK45 && NZ == kNoiseFast && !MIS && FL != 0 && BLOCK == kBlock &&
+                          (FL & kFGoalTable) != 0 && (FL & kFAutoReset) != 0 && (FL & kFOutStatePrime) == 0;
+    constexpr unsigned kCoopMax = 8;
+    struct CoopSlot { double x, y, f0x, f0y, h_abs; };
+    __shared__ unsigned s_coop_cnt[COOP ? 3 : 1];
+    __shared__ unsigned char s_coop_idx[COOP ? 64 : 1];
+    __shared__ CoopSlot s_coop_res[COOP ? 64 : 1];
+    if constexpr (COOP) { if (threadIdx.x < 3) s_coop_cnt[threadIdx.x] = 0u; }   // published by the table barrier below
     const long long blk0 = (long long)blockIdx.x * BLOCK;
     const unsigned tid = threadIdx.x;
     const long long i_raw = blk0 + tid;
     const bool active = i_raw < P.n;
-    const long long i = (HAS_ACT && !active) ? P.n - 1 : i_raw;
+    const long long i = ((HAS_ACT || COOP) && !active) ? P.n - 1 : i_raw;
     __shared__ __attribute__((aligned(16))) float s_actor[ActLds<ACT>::Floats];
     if constexpr (ACT != kActOff) actor_stage_blob<ACT>(ac.blob, s_actor, tid, BLOCK);  // the barrier below (or its own) publishes it
 #if MRSIM_ROLLOUT_TABLE == 1
@@ -311,7 +329,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
 #if MRSIM_ROLLOUT_TABLE != 1
     if constexpr (HAS_ACT) __syncthreads();
 #endif
-    if constexpr (!HAS_ACT) { if (!active) return; }
+    if constexpr (!HAS_ACT && !COOP) { if (!active) return; }   // (wave-wide MFMA / block barriers in the loop: every lane stays)
     EnvRegs e;
 #ifdef MRSIM_WAVE_PROBE
     const unsigned long long clk0 = wall_clock64();
@@ -399,8 +417,55 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         }
         if (!(fl & kFActions64)) { adf = (double)af; ada = (double)aa; }
         StepOut o;
-        env_step<RK45, NZ, MIS>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr,
-                                kPreReset ? wr_pre : nullptr);
+        env_step<RK45, NZ, MIS, COOP>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr,
+                                      kPreReset ? wr_pre : nullptr);
+        if constexpr (COOP) {
+            const bool dn = o.has_final && active;
+            const unsigned long long m = __ballot(dn);
+            const unsigned nw = (unsigned)__builtin_popcountll(m);
+            const bool own = nw > kCoopMax;                 // wave-uniform
+            unsigned* cnt = &s_coop_cnt[(unsigned)t % 3u];
+            unsigned slot = 0u;
+            if (nw != 0u && !own) {
+                unsigned base = 0u;
+                if ((tid & 63u) == (unsigned)__builtin_ctzll(m)) base = atomicAdd(cnt, nw);   // one lane of the wave claims nw slots
+                base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+                slot = base + (unsigned)__builtin_popcountll(m & ((1ull << (tid & 63u)) - 1ull));
+                if (dn) s_coop_idx[slot] = (unsigned char)tid;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (A) the step's queue is complete (LDS only: the
+            const unsigned total = *cnt;                                          //     transition stores stay in flight)
+            if (tid == 0) s_coop_cnt[((unsigned)t + 2u) % 3u] = 0u;               // the counter of step t + 2 (nobody is there yet)
+            auto do_reset = [&](const Rng& RR, EnvRegs& ee) {
+                double x0, y0, rx, ry;
+                uint32_t wr[4];
+                reset_words(RR, wr);
+                sample_init(P, wr, x0, y0);
+                reset_env<RK45, NZ, false>(P, RR, x0, y0, ee, rx, ry, wr, false, /*in_init_box=*/true);
+            };
+            if (total != 0u) {                                                    // block-uniform
+                if ((tid >> 6) == ((unsigned)t & 3u) && (tid & 63u) < total) {    // this step's server wave: one queued env per lane
+                    const unsigned who = s_coop_idx[tid & 63u];
+                    Rng R2 = R;
+                    R2.env = P.env_id0 + (uint32_t)(blk0 + who);
+                    EnvRegs e2;
+                    do_reset(R2, e2);
+                    s_coop_res[tid & 63u] = CoopSlot{e2.x, e2.y, e2.f0x, e2.f0y, e2.h_abs};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (B) results are there
+            }
+            if (dn) {
+                if (own) {
+                    do_reset(R, e);
+                } else {
+                    const CoopSlot r = s_coop_res[slot];
+                    e.x = r.x; e.y = r.y; e.f0x = r.f0x; e.f0y = r.f0y; e.h_abs = r.h_abs;
+                    e.counter = 0; e.ep_ret = 0.f;
+                }
+                const double gx0 = (double)goal0.x, gy0 = (double)goal0.y, ex = gx0 - e.x, ey = gy0 - e.y;
+                pack_obs(e.x, e.y, gx0, gy0, __builtin_fma(ex, ex, ey * ey), o.obs);
+            }
+        }
         if constexpr (HAS_ACT) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) obs_cur[j] = o.obs[j];  // what the policy sees next (the reset row after an auto-reset)
@@ -418,7 +483,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         // The [T][N] outputs are write-once streams the kernel never reads back: non-temporal stores (+1 %)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef double f64x2 __attribute__((ext_vector_type(2)));
-        if (HAS_ACT && !active) continue;  // a lane past n: nothing to store
+        if ((HAS_ACT || COOP) && !active) continue;  // a lane past n: nothing to store
         if (fl & kFOutTraj) {
             const f64x2 v = {o.px, o.py};
             __builtin_nontemporal_store(v, &(reinterpret_cast<f64x2*>(ra.traj_xy) + row)[tid]);
@@ -459,7 +524,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
             if (fl & kFOutFinalLen) ra.final_len[i] = o.flen;
         }
     }
-    if (HAS_ACT && !active) return;
+    if ((HAS_ACT || COOP) && !active) return;
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
     if constexpr (HAS_ACT) {
         if (P.flags & kFActorOU) reinterpret_cast<float2*>(ac.ou_state)[i] = make_float2(ou0, ou1);
