@@ -585,7 +585,7 @@ def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event
     waves = (n_local + 63) // 64
     exec_flops = waves * ep * (96 * 32 * 32 * 16 * 2 + 12 * 32 * 32 * 2 * 2)   # executed MFMA flops: 96 bf16 + 12 f32 per wave-step
     bf16x3 = {"what": "the same with MrsimActor.math = BF16X3: every f32 operand of the 64 x 64 layer as three bf16 terms, the six "
-                      "products above 2^-24 on v_mfma_f32_32x32x16_bf16 with f32 accumulation (within 2e-6 of the action bound of the "
+                      "products above 2^-24 on v_mfma_f32_32x32x16_bf16 with f32 accumulation (within 5e-6 of the action bound of the "
                       "f32 result; tests/test_gpu_actor.py) -- the matrix cores proper, which run beside the vector unit",
               "value": n_local * ep * episodes / el_bf, "unit": "env-steps/s", "ms_per_step": el_bf / (episodes * ep) * 1e3,
               "one_stream_with_events": {"value": n_local * ep * event_episodes / el1_bf, "avg_kernel_us": round(avg_bf, 2),

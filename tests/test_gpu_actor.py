@@ -72,6 +72,9 @@ def test_actor_kernel_matches_pytorch_and_oracle(n, layout, math):
             assert np.array_equal(got, orc), np.abs(got - orc).max()      # an f32 MFMA is the oracle's fmaf chain, bit for bit
         else:
             assert (np.abs(got - orc) / bound).max() < BF_TOL, (np.abs(got - orc) / bound).max()
+            # ... and the exact-f32 arithmetic (the oracle's fmaf chains = the F32 kernel, bitwise): the split keeps f32-class accuracy
+            orc32 = O.actor_forward(O.make_actor(fold_actor(m.cpu(), SCALE)), obs)
+            assert (np.abs(got - orc32) / bound).max() < BF_TOL, (np.abs(got - orc32) / bound).max()
 
 
 def test_actor_kernel_raw_observations_tolerance():
