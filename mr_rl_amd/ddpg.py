@@ -188,6 +188,54 @@ class DDPG:
             self.actor.train()
         return float(loss_c.detach()), float(loss_a.detach())
 
+    def train_collected(self, episodes, updates_per_episode=4, sample=4096, streams=2, math="f32"):
+        """The loop of RL/MR_ddpg.py:251-323 at collection speed: every episode of all N envs is ONE fused launch group of
+        the rollout kernel with this agent's actor (+ OU noise) as its in-kernel policy (RolloutCollector(policy=DeviceActor)),
+        `sample` of its N x 51 transitions go into the replay ring, `updates_per_episode` learner updates follow, and the new
+        parameters are uploaded before the next episode starts (the upload waits for the launches that still read the old
+        block).  Needs an env config with auto_reset=True.  Returns the mean return of every episode."""
+        from .actor import DeviceActor
+        from .collector import RolloutCollector
+        env = self.env
+        if not env.cfg.auto_reset:
+            raise ValueError("train_collected needs MRConfig(auto_reset=True)")
+        scale = None if self.obs_scale is None else self.obs_scale.cpu().numpy()
+        self.actor.eval()
+        pol = DeviceActor.from_module(self.actor, obs_scale=scale, device=env.device, ou=True, theta=self.noise.theta,
+                                      sigma=self.noise.sigma, dt=self.noise.dt, reset_on_done=True, math=math)
+        self.actor.train()
+        col = RolloutCollector(env.num_envs, cfg=env.cfg, device=env.device, seed=env.seed_value, env_id0=env.env_id0,
+                               goal_table=env.goal_table, streams=streams, policy=pol)
+        prev_obs = col.reset().clone()                      # the observation the first action of the episode is computed from
+        T, N = col.T, col.N
+        gen = torch.Generator(device=env.device)
+        gen.manual_seed(12345)
+        returns = []
+        for k in range(episodes):
+            col.collect()
+            b = col.ready(k)
+            obs_T = b["obs"]
+            n_s = min(int(sample), T * N)
+            ti = torch.randint(0, T, (n_s,), device=env.device, generator=gen)
+            ei = torch.randint(0, N, (n_s,), device=env.device, generator=gen)
+            s = torch.where((ti == 0)[:, None], prev_obs[ei], obs_T[(ti - 1).clamp(min=0), ei])
+            # s2 of a terminal transition is the next episode's reset observation here; its target is r alone (1 - done = 0)
+            self.buffer.add(self._prep(s), b["actions"][ti, ei], b["rew"][ti, ei], b["done"][ti, ei].float(),
+                            self._prep(obs_T[ti, ei]))
+            ended = b["final_len"] > 0
+            returns.append(float(b["final_ret"][ended].mean()) if bool(ended.any()) else float("nan"))
+            prev_obs = obs_T[T - 1].clone()
+            col.release(k)
+            for _ in range(updates_per_episode):
+                self.update()
+            col.join()                                       # no launch reads the parameter block any more
+            self.actor.eval()
+            pol.load_module(self.actor)
+            self.actor.train()
+        col.check_status()
+        self.collector, self.device_actor = col, pol
+        return returns
+
     def train(self, total_steps, updates_per_step=1, log_every=0):
         """Runs `total_steps` lockstep env steps (N transitions each); returns per-episode returns seen."""
         env = self.env

@@ -338,3 +338,27 @@ def test_ddpg_twin_trains_with_the_device_actor():
     assert ((got - want).abs() / bound).max().item() < ACTOR_TOL
     follow = DeviceActor(agent.device_actor.weights, device="cuda", ou=False)   # what train() uploaded last
     assert torch.equal(follow.forward(env), got)
+
+
+def test_ddpg_twin_trains_at_collection_speed():
+    """DDPG.train_collected: every episode of all envs is one fused launch group with the agent's actor in the kernel; sampled
+    transitions (s from the previous row / the previous episode's last row, a = the action the kernel applied) feed the replay
+    ring; the uploaded parameters follow the learner."""
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.ddpg import DDPG
+    cfg = MRConfig(noise_var=0.1, reward_mode="goal", auto_reset=True, init_low=(20.0, 20.0), init_high=(30.0, 30.0),
+                   min_dist2goal=25.0)
+    env = MRVecEnv(4096, cfg=cfg, seed=0)
+    agent = DDPG(env, seed=0, obs_scale=SCALE)
+    rets = agent.train_collected(6, updates_per_episode=3, sample=4000)
+    assert len(rets) == 6 and np.isfinite(rets).all()
+    assert agent.buffer.size() == 10000 and agent._updates == 18
+    # a stored transition is consistent: its action lies in the actor's range + OU noise, its state / next state are scaled obs
+    assert float(agent.buffer.a[:, 0].abs().max()) < 20 + 3 and float(agent.buffer.s.abs().max()) < 60
+    agent.actor.eval()
+    with torch.no_grad():
+        want = agent.actor(agent.collector.env.obs * torch.tensor(SCALE, device="cuda"))
+    from mr_rl_amd.actor import DeviceActor
+    quiet = DeviceActor(agent.device_actor.weights, device="cuda", ou=False)
+    got = quiet.forward(agent.collector.env)
+    assert ((got - want).abs() / agent.actor.action_bound).max().item() < ACTOR_TOL
