@@ -90,34 +90,42 @@ class DeviceActor:
         self.ou, self.theta, self.sigma, self.dt = bool(ou), float(theta), float(sigma), float(dt)
         self.reset_on_done = bool(reset_on_done)
         self.blob = torch.empty(_lib.ACTOR_BLOB_FLOATS, dtype=torch.float32, device=self.device)
-        self.ou_state = None
+        self._ou = {}          # env count -> [n, 2] OU state (prepared launches hold raw pointers into these: never reallocated)
+        self.ou_state = None   # the one used last
         self.weights = None
-        self.load(weights)
+        self.load(weights, sync=False)
 
     @classmethod
     def from_module(cls, module, obs_scale=None, **kw):
         return cls(fold_actor(module, obs_scale), **kw)
 
-    def load(self, weights):
-        """(Re)upload the parameters -- after a learner update, on the current stream."""
+    def load(self, weights, sync=True):
+        """(Re)upload the parameters, e.g. after a learner update.  Kernels stage the block into LDS when their workgroups
+        start, so a launch that is still running (on any stream: RolloutCollector's sub-shard streams) while the block is
+        overwritten would mix old and new parameters: sync=True (default) waits for the device first; pass sync=False only
+        when no launch that reads the block can be in flight (e.g. right after RolloutCollector.join() + a stream wait)."""
         import torch
         self.weights = {k: _f32(v) for k, v in weights.items()}
-        self.blob.copy_(torch.from_numpy(pack_weights(self.weights)), non_blocking=False)
+        host = torch.from_numpy(pack_weights(self.weights))
+        if sync:
+            torch.cuda.synchronize(self.device)
+        self.blob.copy_(host, non_blocking=False)
 
-    def load_module(self, module, obs_scale=None):
-        self.load(fold_actor(module, self.weights["obs_scale"] if obs_scale is None else obs_scale))
+    def load_module(self, module, obs_scale=None, sync=True):
+        self.load(fold_actor(module, self.weights["obs_scale"] if obs_scale is None else obs_scale), sync=sync)
 
     def ou_tensor(self, n):
         import torch
         if not self.ou:
             return None
-        if self.ou_state is None or self.ou_state.shape[0] != n:
-            self.ou_state = torch.zeros((n, 2), dtype=torch.float32, device=self.device)
+        if n not in self._ou:
+            self._ou[n] = torch.zeros((n, 2), dtype=torch.float32, device=self.device)
+        self.ou_state = self._ou[n]
         return self.ou_state
 
     def reset_noise(self):
-        if self.ou_state is not None:
-            self.ou_state.zero_()
+        for t in self._ou.values():
+            t.zero_()
 
     def struct(self, n, first=0, count=None):
         """MrsimActor for the envs [first, first + count) of an n-env set (the OU state pointer advanced to `first`)."""
