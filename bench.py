@@ -547,7 +547,6 @@ def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event
     torch.manual_seed(seed)
     module = Actor().eval()
     actor = DeviceActor.from_module(module, obs_scale=[0.01] * 5, device=dev)
-    actor_bf = DeviceActor.from_module(module, obs_scale=[0.01] * 5, device=dev, math="bf16x3")
     cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math, seed=seed,
                    is_mismatched=args.mismatched)
     ep = cfg.max_timesteps + 1
@@ -575,30 +574,35 @@ def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event
     avg_us, med_us = stats_us(ms)
     tflops = n_local * ep * ACTOR_FLOP_PER_ENV_STEP / (avg_us * 1e-6) / 1e12
     # the same with the 64 x 64 layer in bf16 x 3 arithmetic (three bf16 terms per f32 operand, six bf16 MFMAs, f32 accumulate)
-    el_bf = run(streams, episodes, actor=actor_bf)
-    pool = [EventPair() for _ in range(event_episodes)]
-    el1_bf = run(1, event_episodes, pool, actor=actor_bf)
-    ms_bf = [p.elapsed_ms() for p in pool]
-    for p in pool:
-        p.close()
-    avg_bf, med_bf = stats_us(ms_bf)
+    # and in plain bf16 (one term, one MFMA)
     waves = (n_local + 63) // 64
-    exec_flops = waves * ep * (96 * 32 * 32 * 16 * 2 + 12 * 32 * 32 * 2 * 2)   # executed MFMA flops: 96 bf16 + 12 f32 per wave-step
-    bf16x3 = {"what": "the same with MrsimActor.math = BF16X3: every f32 operand of the 64 x 64 layer as three bf16 terms, the six "
-                      "products above 2^-24 on v_mfma_f32_32x32x16_bf16 with f32 accumulation (within 5e-6 of the action bound of the "
-                      "f32 result; tests/test_gpu_actor.py) -- the matrix cores proper, which run beside the vector unit",
-              "value": n_local * ep * episodes / el_bf, "unit": "env-steps/s", "ms_per_step": el_bf / (episodes * ep) * 1e3,
-              "one_stream_with_events": {"value": n_local * ep * event_episodes / el1_bf, "avg_kernel_us": round(avg_bf, 2),
-                                         "median_kernel_us": round(med_bf, 2)},
-              "roofline": {"bound": "mfma", "achieved": round(exec_flops / (avg_bf * 1e-6) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(exec_flops / (avg_bf * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                           "traffic": None,
-                           "note": "EXECUTED matrix flops (96 bf16 MFMAs of 32x32x16 + 12 f32 MFMAs per wave and step) / kernel "
-                                   "duration against the dense bf16 MFMA peak; the kernel is bound by vector-instruction issue "
-                                   "(operand splitting, ReLU, the output layer, the env step: ~1050 per wave and step), not by the "
-                                   "matrix pipe",
-                           "algorithmic_actor_TFLOPs": round(n_local * ep * ACTOR_FLOP_PER_ENV_STEP / (avg_bf * 1e-6) / 1e12, 1)}}
-    return {"bf16x3": bf16x3, "what": "BASELINE config 4 with the reference's DDPG actor (5-64-64-2, eval-mode batch norm folded, tanh x bound) "
+
+    def variant(math, mfma_bf16_per_wave_step, what, bound_note):
+        pol = DeviceActor.from_module(module, obs_scale=[0.01] * 5, device=dev, math=math)
+        el_v = run(streams, episodes, actor=pol)
+        pool_v = [EventPair() for _ in range(event_episodes)]
+        el1_v = run(1, event_episodes, pool_v, actor=pol)
+        ms_v = [p.elapsed_ms() for p in pool_v]
+        for p in pool_v:
+            p.close()
+        avg_v, med_v = stats_us(ms_v)
+        exec_flops = waves * ep * (mfma_bf16_per_wave_step * 32 * 32 * 16 * 2 + 12 * 32 * 32 * 2 * 2)
+        return {"what": what, "value": n_local * ep * episodes / el_v, "unit": "env-steps/s", "ms_per_step": el_v / (episodes * ep) * 1e3,
+                "one_stream_with_events": {"value": n_local * ep * event_episodes / el1_v, "avg_kernel_us": round(avg_v, 2),
+                                           "median_kernel_us": round(med_v, 2)},
+                "roofline": {"bound": "mfma", "achieved": round(exec_flops / (avg_v * 1e-6) / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(exec_flops / (avg_v * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                             "traffic": None, "note": bound_note,
+                             "algorithmic_actor_TFLOPs": round(n_local * ep * ACTOR_FLOP_PER_ENV_STEP / (avg_v * 1e-6) / 1e12, 1)}}
+    note = ("EXECUTED matrix flops (%d bf16 MFMAs of 32x32x16 + 12 f32 MFMAs per wave and step) / kernel duration against the dense "
+            "bf16 MFMA peak; the kernel is bound by vector-instruction issue at the package power cap (operand conversion, ReLU, the "
+            "output layer, the env step), not by the matrix pipe")
+    bf16x3 = variant("bf16x3", 96, "the same with MrsimActor.math = BF16X3: every f32 operand of the 64 x 64 layer as three bf16 terms, "
+                     "the six products above 2^-24 on v_mfma_f32_32x32x16_bf16 with f32 accumulation (within 5e-6 of the action bound of "
+                     "the f32 result; tests/test_gpu_actor.py) -- the matrix cores proper, which run beside the vector unit", note % 96)
+    bf16 = variant("bf16", 16, "the same with MrsimActor.math = BF16: plain bf16 operands, f32 accumulation -- ordinary bf16 inference "
+                   "(bitwise equal to the oracle's bf16 emulation up to accumulation order; tests/test_gpu_actor.py bounds the action's distance from the f32 result at 6e-2 of its bound): exploration-grade collection", note % 16)
+    return {"bf16x3": bf16x3, "bf16": bf16, "what": "BASELINE config 4 with the reference's DDPG actor (5-64-64-2, eval-mode batch norm folded, tanh x bound) "
                     "+ OU noise as the policy, evaluated INSIDE the fused rollout kernel on each step's observation "
                     "(RL/MR_ddpg.py:277-278 without leaving the registers); random-initialised weights, every transition written",
             "value": n_local * ep * episodes / el, "unit": "env-steps/s", "episodes": episodes, "streams": streams,

@@ -112,20 +112,21 @@ for S in (1, 2):
     res[f"fused_collector_streams{S}_ms_per_episode"] = el / EPISODES * 1e3
     col.check_status()
 
-# ---- fused, 64 x 64 layer in bf16 x 3 arithmetic
-actor_bf = DeviceActor.from_module(agent.actor, obs_scale=SCALE, device=env.device, math="bf16x3")
-col = RolloutCollector(N, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=0, streams=2, policy=actor_bf)
-col.reset()
-for k in range(30):
-    col.collect(); col.ready(); col.release()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for k in range(EPISODES):
-    col.collect(); col.ready(); col.release()
-col.join()
-torch.cuda.synchronize()
-res["fused_collector_bf16x3_G"] = rate(EPISODES * T, time.perf_counter() - t0)
-col.check_status()
+# ---- fused, 64 x 64 layer in bf16 x 3 arithmetic (f32-class accuracy) and in plain bf16 (ordinary bf16 inference)
+for math in ("bf16x3", "bf16"):
+    actor_bf = DeviceActor.from_module(agent.actor, obs_scale=SCALE, device=env.device, math=math)
+    col = RolloutCollector(N, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=0, streams=2, policy=actor_bf)
+    col.reset()
+    for k in range(30):
+        col.collect(); col.ready(); col.release()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(EPISODES):
+        col.collect(); col.ready(); col.release()
+    col.join()
+    torch.cuda.synchronize()
+    res[f"fused_collector_{math}_G"] = rate(EPISODES * T, time.perf_counter() - t0)
+    col.check_status()
 
 # flop accounting of the actor: 2 * (5*64 + 64*64 + 64*2) per env-step
 flop = 2 * (5 * 64 + 64 * 64 + 64 * 2)
@@ -134,6 +135,7 @@ res["actor_flop_per_env_step"] = flop
 res["fused_actor_TFLOPs"] = best * 1e9 * flop / 1e12
 res["speedup_vs_eager"] = best / res["eager_pytorch_actor_G"]
 res["speedup_vs_eager_bf16x3"] = res["fused_collector_bf16x3_G"] / res["eager_pytorch_actor_G"]
+res["speedup_vs_eager_bf16"] = res["fused_collector_bf16_G"] / res["eager_pytorch_actor_G"]
 if "--json" in sys.argv:
     print(json.dumps(res))
 else:

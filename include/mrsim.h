@@ -132,7 +132,9 @@ typedef struct MrsimState {
  * fmaf chain in the documented order.  BF16X3: every f32 operand as the sum of three bf16 terms, the six products above
  * 2^-24 on v_mfma_f32_32x32x16_bf16 with f32 accumulation -- f32-class accuracy (within 5e-6 of the action bound of the F32
  * result in the tests) on the matrix cores proper, which run beside the vector unit; about 1.5 x the collection rate. */
-enum { MRSIM_ACTOR_F32 = 0, MRSIM_ACTOR_BF16X3 = 1 };
+/* BF16: plain bf16 operands (weights and activations rounded once), f32 accumulation -- ordinary bf16 inference: the action
+ * within ~1e-2 of its bound of the F32 result (more where the output layer saturates), for exploration-grade collection. */
+enum { MRSIM_ACTOR_F32 = 0, MRSIM_ACTOR_BF16X3 = 1, MRSIM_ACTOR_BF16 = 2 };
 
 typedef struct MrsimActorWeights {   /* HOST pointers, row-major float32: the network in inference form */
     const float* w1;        /* [64][5]   first fully_connected (+ folded batch norm)   RL/MR_ddpg.py:122-123 */
@@ -163,7 +165,7 @@ typedef struct MrsimActor {
     float ou_dt;              /* 1e-2                                                                         */
     int32_t ou_reset_on_done; /* 0 = the reference (the process is never reset, :270-311); 1 = x_prev := 0 at  */
                               /*   the first step of every episode (MR_Env.counter == 0)                      */
-    int32_t math;             /* MRSIM_ACTOR_F32 (default) | MRSIM_ACTOR_BF16X3                               */
+    int32_t math;             /* MRSIM_ACTOR_F32 (default) | MRSIM_ACTOR_BF16X3 | MRSIM_ACTOR_BF16            */
     int32_t reserved0;        /* 0                                                                            */
 } MrsimActor;
 

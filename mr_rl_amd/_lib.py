@@ -13,7 +13,7 @@ OBS_AOS, OBS_SOA = 0, 1
 NOISE_FAST, NOISE_SPEC = 0, 1
 ABI_VERSION = 3
 ACTOR_HIDDEN, ACTOR_BLOB_FLOATS = 64, 10888
-ACTOR_F32, ACTOR_BF16X3 = 0, 1
+ACTOR_F32, ACTOR_BF16X3, ACTOR_BF16 = 0, 1, 2
 
 # every symbol include/mrsim.h declares (tests check the .so exports exactly these)
 SYMBOLS = (

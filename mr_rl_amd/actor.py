@@ -76,15 +76,16 @@ class DeviceActor:
     every episode (what mr_rl_amd.ddpg.DDPG.train does with its own OUNoise).
     The OU state tensor [num_envs, 2] is created on first use for the env count it is used with."""
 
-    MATH = {"f32": _lib.ACTOR_F32, "bf16x3": _lib.ACTOR_BF16X3}
+    MATH = {"f32": _lib.ACTOR_F32, "bf16x3": _lib.ACTOR_BF16X3, "bf16": _lib.ACTOR_BF16}
 
     def __init__(self, weights, device="cuda", ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False, math="f32"):
         """math: arithmetic of the 64 x 64 layer.  "f32" (default) = exact f32 MFMA, bit-for-bit the documented fmaf chain;
         "bf16x3" = every f32 operand as three bf16 terms, six bf16 MFMAs with f32 accumulation: f32-class accuracy (within
-        5e-6 of the action bound of the f32 result; tests/test_gpu_actor.py), about 1.5 x the collection rate."""
+        5e-6 of the action bound of the f32 result; tests/test_gpu_actor.py), about 1.5 x the collection rate; "bf16" = plain
+        bf16 operands, ordinary bf16 inference (~1e-2 of the bound), for exploration-grade collection."""
         import torch
         if math not in self.MATH:
-            raise ValueError("math must be 'f32' or 'bf16x3'")
+            raise ValueError("math must be 'f32', 'bf16x3' or 'bf16'")
         self.math = math
         self.device = torch.device(device)
         self.ou, self.theta, self.sigma, self.dt = bool(ou), float(theta), float(sigma), float(dt)

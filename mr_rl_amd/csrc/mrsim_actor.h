@@ -43,7 +43,10 @@ constexpr int kActHidden = 64;
 //               keeps f32-class accuracy (tests: <= 5e-6 of the action bound against the F32 result and against the oracle's emulation of the same
 //               splits, <= 1e-5 against PyTorch fp32) at 6/16 of the f32-MFMA cycles, on the matrix cores proper, which
 //               DO run beside the vector unit.
-enum : int { kActOff = 0, kActF32 = 1, kActBf16x3 = 2 };
+//   kActBf16    plain bf16 operands (the first term alone), one MFMA per k-step and row tile, f32 accumulation: what bf16 inference
+//               is -- 1e-2-class accuracy of the action (tests: <= 6e-2 of the bound against PyTorch fp32 on nets whose output layer
+//               saturates, 1e-4 on freshly initialised ones) for exploration-grade collection at twice the bf16x3 rate.
+enum : int { kActOff = 0, kActF32 = 1, kActBf16x3 = 2, kActBf16 = 3 };
 // packed parameter block (float offsets); the kernels copy the part their arithmetic needs to LDS once per block
 constexpr int kActA1 = 0;                    // [rt 2][s 3][lane 64]      layer-1 A operands
 constexpr int kActA2 = kActA1 + 2 * 3 * 64;  // [rt 2][s4 8][lane 64][4]  layer-2 A operands, four k-steps per ds_read_b128
@@ -69,6 +72,7 @@ template <> struct ActLds<kActBf16x3> {
     static constexpr int A1 = 0, A2 = 0, C1 = kActA2, C2 = C1 + 64, W3 = C2 + 64, Tail = W3 + 128, A2bf = Tail + 8,
                          Floats = A2bf + kActA2bfFloats;
 };
+template <> struct ActLds<kActBf16> : ActLds<kActBf16x3> {};
 template <> struct ActLds<kActOff> {
     static constexpr int A1 = 0, A2 = 0, C1 = 0, C2 = 0, W3 = 0, Tail = 0, A2bf = 0, Floats = 4;
 };
@@ -91,7 +95,7 @@ __device__ __forceinline__ void actor_stage_blob(const float* __restrict__ blob,
     using L = ActLds<MODE>;
     if constexpr (MODE == kActF32) {
         act_copy4(blob, s_blob, kActF32Floats, tid, nthreads);
-    } else if constexpr (MODE == kActBf16x3) {
+    } else if constexpr (MODE == kActBf16x3 || MODE == kActBf16) {
         act_copy4(blob + kActA1, s_blob + L::A1, kActA2 - kActA1, tid, nthreads);             // layer-1 operands
         act_copy4(blob + kActC1, s_blob + L::C1, kActF32Floats - kActC1, tid, nthreads);      // biases, output layer, tail
         act_copy4(blob + kActA2bf, s_blob + L::A2bf, kActA2bfFloats, tid, nthreads);          // layer-2 bf16 terms
@@ -244,6 +248,24 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
                         if constexpr (MRSIM_ACTOR_PREFETCH == 1) a4[rt] = a4n[rt];
                         else a4[rt] = *reinterpret_cast<const act_f32x4*>(sA + L::A2 + ((rt * 8 + s4 + 1) * 64 + lane) * 4);
                     }
+                }
+            }
+        } else if constexpr (MODE == kActBf16) {
+            // plain bf16: the activations rounded once (v_cvt_pk_bf16_f32), the weights' first term, one MFMA per (k-step, row tile)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                act_bf16x8 bp;
+#pragma unroll
+                for (int jj = 0; jj < 8; jj += 2) {
+                    const int q = 8 * s + jj;
+                    const act_f32x2 v = {act_relu(acc1[q / 16][q % 16]), act_relu(acc1[(q + 1) / 16][(q + 1) % 16])};
+                    const act_bf16x2 t = __builtin_convertvector(v, act_bf16x2);
+                    bp[jj] = t[0]; bp[jj + 1] = t[1];
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const act_bf16x8 ap = *reinterpret_cast<const act_bf16x8*>(sA + L::A2bf + (((rt * 4 + s) * 3 + 0) * 64 + lane) * 4);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp, acc2[rt], 0, 0, 0);
                 }
             }
         } else {

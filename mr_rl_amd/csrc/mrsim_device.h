@@ -87,6 +87,7 @@ enum : uint32_t {
     kFActor = 1u << 21, kFActorOU = 1u << 22, kFOUReset = 1u << 23,
     kFResetFresh = 1u << 24,  // auto-reset = a fresh MR_Env (nominal-law constructor) instead of the re-used one
     kFActorBf16 = 1u << 25,   // the actor's 64 x 64 layer in bf16 x 3 arithmetic (mrsim_actor.h: kActBf16x3)
+    kFActorBf16s = 1u << 26,  // ... in plain bf16 (kActBf16)
 };
 __device__ __forceinline__ uint32_t live_flags(uint32_t f) {
     asm volatile("" : "+s"(f));

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
 #define MRSIM_ACTOR_WAVES_GENERIC 3
 #endif
 constexpr int kBlockBf = 512;
-template <int ACT> constexpr int actor_block() { return ACT == kActBf16x3 ? kBlockBf : kBlock; }
+template <int ACT> constexpr int actor_block() { return (ACT == kActBf16x3 || ACT == kActBf16) ? kBlockBf : kBlock; }
 template <bool RK45, int NZ, bool MIS, uint32_t FL, int ACT>
 __global__ __launch_bounds__(actor_block<ACT>()) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES_GENERIC, 8))) void mr_rollout_actor_kernel(
     const KParams P, const StateArgs st, const RolloutArgs ra, const ActorArgs ac) {
@@ -821,10 +821,14 @@ static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams&
                        const ActorArgs& AC) {
     const bool aos = p->obs_layout == MRSIM_OBS_AOS;
     if (K.flags & kFActor) {  // policy source = in-kernel actor (RK45 only, checked by the caller)
-        const bool bf = (K.flags & kFActorBf16) != 0;
+        const bool bf = (K.flags & kFActorBf16) != 0, bfs = (K.flags & kFActorBf16s) != 0;
         return dispatch(true, noise_variant(p), p->mismatched != 0, [&](auto, auto NZ, auto MIS) {
             constexpr bool mis = decltype(MIS)::value;
             constexpr int nz = decltype(NZ)::value;
+            if (bfs) {
+                if (aos) return launch(lc, mr_step_kernel<true, nz, mis, true, 0, kActBf16>, K.n, K, S, IO, AC);
+                return launch(lc, mr_step_kernel<true, nz, mis, false, 0, kActBf16>, K.n, K, S, IO, AC);
+            }
             if (bf) {
                 if (aos) return launch(lc, mr_step_kernel<true, nz, mis, true, 0, kActBf16x3>, K.n, K, S, IO, AC);
                 return launch(lc, mr_step_kernel<true, nz, mis, false, 0, kActBf16x3>, K.n, K, S, IO, AC);
@@ -858,9 +862,9 @@ static int actor_args(const MrsimParams* p, const MrsimActor* a, bool have_actio
     // x += theta (mu - x) dt + sigma sqrt(dt) N(0,1), mu = 0: the two products, formed in double and rounded once
     AC.ou.theta_dt = (float)((double)a->ou_theta * (double)a->ou_dt);
     AC.ou.sigma_sqrt_dt = (float)((double)a->ou_sigma * std::sqrt((double)a->ou_dt));
-    if (a->math != MRSIM_ACTOR_F32 && a->math != MRSIM_ACTOR_BF16X3) return MRSIM_EINVAL;
+    if (a->math != MRSIM_ACTOR_F32 && a->math != MRSIM_ACTOR_BF16X3 && a->math != MRSIM_ACTOR_BF16) return MRSIM_EINVAL;
     bits = kFActor | (a->ou_state ? kFActorOU : 0u) | ((a->ou_state && a->ou_reset_on_done) ? kFOUReset : 0u) |
-           (a->math == MRSIM_ACTOR_BF16X3 ? kFActorBf16 : 0u);
+           (a->math == MRSIM_ACTOR_BF16X3 ? kFActorBf16 : 0u) | (a->math == MRSIM_ACTOR_BF16 ? kFActorBf16s : 0u);
     on = true;
     return MRSIM_OK;
 }
@@ -1088,14 +1092,17 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     if (actor_on) {
         const int nz = noise_variant(p);
         const bool mis = p->mismatched != 0;
-        const bool bf = (K.flags & kFActorBf16) != 0;
+        const bool bf = (K.flags & kFActorBf16) != 0, bfs = (K.flags & kFActorBf16s) != 0;
         if (K.flags == kFlDdpgActor) rc = launch_rollout_actor_fl<kFlDdpgActor, kActF32>(lc, nz, mis, K, S, ra, AC, handled);
         else if (K.flags == (kFlDdpgActor | kFActorBf16))
             rc = launch_rollout_actor_fl<kFlDdpgActor | kFActorBf16, kActBf16x3>(lc, nz, mis, K, S, ra, AC, handled);
+        else if (K.flags == (kFlDdpgActor | kFActorBf16s))
+            rc = launch_rollout_actor_fl<kFlDdpgActor | kFActorBf16s, kActBf16>(lc, nz, mis, K, S, ra, AC, handled);
         if (!handled)
             rc = dispatch(true, nz, mis, [&](auto, auto NZ, auto MIS) {
                 constexpr int z = decltype(NZ)::value;
                 constexpr bool m = decltype(MIS)::value;
+                if (bfs) return launch_b<kBlockBf>(lc, mr_rollout_actor_kernel<true, z, m, 0, kActBf16>, K.n, K, S, ra, AC);
                 if (bf) return launch_b<kBlockBf>(lc, mr_rollout_actor_kernel<true, z, m, 0, kActBf16x3>, K.n, K, S, ra, AC);
                 return launch(lc, mr_rollout_actor_kernel<true, z, m, 0, kActF32>, K.n, K, S, ra, AC);
             });
@@ -1268,6 +1275,10 @@ int mrsim_actor_forward(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     K.flags |= abits;
     const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
     const bool fastnz = noise_variant(p) == kNoiseFast;
+    if (abits & kFActorBf16s) {
+        if (fastnz) return launch(lc, mr_actor_kernel<kNoiseFast, kActBf16>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
+        return launch(lc, mr_actor_kernel<kNoiseSpec, kActBf16>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
+    }
     if (abits & kFActorBf16) {
         if (fastnz) return launch(lc, mr_actor_kernel<kNoiseFast, kActBf16x3>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
         return launch(lc, mr_actor_kernel<kNoiseSpec, kActBf16x3>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);

@@ -559,14 +559,17 @@ void orc_actor_forward(const OrcActor* a, const float obs[5], float act[2]) {
     } else {
         /* bf16 x 3: k-step s of v_mfma_f32_32x32x16_bf16 sums the 16 features kperm(8 s + jj, h), h = 0..1, jj = 0..7; six
          * MFMAs per k-step in the kernel's order (a3 b1, a2 b2, a1 b3, a2 b1, a1 b2, a1 b1) */
-        static const int term[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+        static const int term6[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+        static const int term1[1][2] = {{0, 0}};                /* math = 2: plain bf16 operands, one MFMA per k-step */
+        const int (*term)[2] = a->math == 1 ? term6 : term1;
+        const int nterm = a->math == 1 ? 6 : 1;
         float hs[64][3];
         for (int k = 0; k < 64; ++k) bf16_split3(h1[k], hs[k]);
         for (int f = 0; f < 64; ++f) {
             float acc = a->b2[f];
             const float* ws = a->w2_split + (size_t)f * 64 * 3;   /* orc_actor_prepare: the three terms of W2[f][k] */
             for (int s = 0; s < 4; ++s)
-                for (int m = 0; m < 6; ++m) {
+                for (int m = 0; m < nterm; ++m) {
                     double sum = 0.0;
                     for (int h = 0; h < 2; ++h)
                         for (int jj = 0; jj < 8; ++jj) {

@@ -147,7 +147,7 @@ typedef struct {
     float ou_sigma_sqrt_dt;/* sigma * sqrt(dt)                                           */
     int32_t ou_enabled;    /* 0: actor.predict alone                                     */
     int32_t ou_reset_on_done; /* 1: x_prev := 0 at the first step of an episode (counter == 0) */
-    int32_t math;          /* 0: f32 fmaf chains (bitwise = the kernel's f32 MFMA); 1: the 64 x 64 layer in bf16 x 3    */
+    int32_t math;          /* 0: f32 fmaf chains (bitwise = the kernel's f32 MFMA); 2: plain bf16 operands; 1: bf16 x 3 */
                            /*    arithmetic -- the same operand splits as the kernel, products exact, the 16 products of  */
                            /*    one MFMA summed exactly and added to the f32 accumulator with one rounding (the          */
                            /*    hardware's internal order is not documented: compared with a 2e-6 tolerance)             */

@@ -153,7 +153,7 @@ def make_actor(w, ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False, 
     a.ou_theta_dt = np.float32(np.float64(np.float32(theta)) * np.float64(np.float32(dt)))
     a.ou_sigma_sqrt_dt = np.float32(np.float64(np.float32(sigma)) * np.sqrt(np.float64(np.float32(dt))))
     a.ou_enabled, a.ou_reset_on_done = int(bool(ou)), int(bool(reset_on_done))
-    a.math = {"f32": 0, "bf16x3": 1}[math]
+    a.math = {"f32": 0, "bf16x3": 1, "bf16": 2}[math]
     lib().orc_actor_prepare(C.byref(a))
     return a
 

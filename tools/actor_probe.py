@@ -16,7 +16,7 @@ ap.add_argument("--launches", type=int, default=200)
 ap.add_argument("--discard", type=int, default=50)
 ap.add_argument("--envs", type=int, default=262144)
 ap.add_argument("--no-ou", action="store_true")
-ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"])
+ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16"])
 ap.add_argument("--power", type=float, default=0.0, help="also run back to back for this many seconds and report package power / clock (hwmon)")
 ap.add_argument("--streams", type=int, nargs="*", default=[], help="also time the RolloutCollector (wall clock) with these stream counts")
 ap.add_argument("--mismatched", action="store_true")

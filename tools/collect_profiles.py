@@ -37,7 +37,7 @@ EXPECTED = ["kt", "kt_s1", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETC
                                              for p in ("pmc_f64", "pmc_f32", "pmc_step", "cal", "cal262k")] + \
            [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")] + \
            ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed",
-            "kt_actor_bf", "pmc_actor_bf_a"]
+            "kt_actor_bf", "pmc_actor_bf_a", "kt_actor_b1"]
 if not os.path.exists(f"{src}/status.txt"):
     die(f"{src}/status.txt not found (did tools/profile_round.sh {tag} run?)")
 status = dict(l.split() for l in open(f"{src}/status.txt").read().splitlines() if l.strip())
@@ -275,6 +275,7 @@ files["pmc_actor_bf16x3.json"] = json.dumps({
     "mfma_frac_of_bf16_peak": round(exec_flops / (bavg * 1e-6) / 1e12 / 2500.0, 4),
     "per_wave_step": {k: round(v / wb / T, 2) for k, v in sorted(cba.items())},
     "source": [prov(ktb), prov(fba)]}, indent=1) + "\n"
+files["kernel_stats_actor_rollout_bf16.csv"] = open(the_csv("kt_actor_b1", "kernel_stats.csv")).read()   # plain bf16 arithmetic
 # ---- mixed trajectory set: VALU instructions per wave-step of the goal-table kernel
 cm, _, grid_m, fm = counters("valu_a_mixed", "mr_rollout_kernel<true, 2, false")
 files["pmc_mixed_set.json"] = json.dumps({
