@@ -147,3 +147,64 @@ def test_oracle_ou_recurrence_and_moments():
     z0 = np.array([O.normals4(seed, i, 999, O.c0(O.STREAM_DYN))[:2] for i in range(4)])
     np.testing.assert_allclose(ou[:4], np.float32(0.3 * math.sqrt(1e-2)) * z0, rtol=1e-6)
     assert np.abs(ou[100:] - before[100:] * np.float32(a)).max() < 0.2   # the others continued from their state
+
+
+def _bf16(x):
+    """float32 -> nearest-even bf16, kept as float32 (what v_cvt_pk_bf16_f32 returns, widened again)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def test_oracle_bf16_arithmetics_against_a_numpy_emulation():
+    """MrsimActor.math = BF16X3 / BF16 in the oracle (orc_actor_forward's second branch) against the same arithmetic written
+    independently with numpy: operands rounded to bf16 (three-term split or one term), each 16-wide k-step summed exactly
+    (fp64 holds a sum of 16 bf16 x bf16 products without rounding at these magnitudes), then ONE fp32 rounding into the
+    accumulator, k-steps and terms in the kernel's order.  Also: bf16x3 stays within BF_TOL of the f32 arithmetic and plain
+    bf16 within BF16_TOL, the bounds tests/test_gpu_actor.py uses for the kernel."""
+    kperm = lambda q, h: 32 * (q // 16) + 8 * ((q % 16) // 4) + 4 * h + (q % 4)  # noqa: E731
+    L = O.lib()
+    m = random_actor(5, out_scale=20.0)
+    w = fold_actor(m, [0.01] * 5)
+    obs = _obs(512, 9)
+    w1 = (w["w1"] * np.float32(w["obs_scale"])[None, :]).astype(np.float32)
+    h1 = np.tile(w["b1"].astype(np.float32), (len(obs), 1))
+    for k in range(5):                                        # fmaf chain in k order: one rounding per term
+        h1 = (h1.astype(np.float64) + w1[:, k].astype(np.float64)[None, :] * obs[:, k].astype(np.float64)[:, None]).astype(np.float32)
+    h1 = np.maximum(h1, 0)
+
+    def split(x, nterm):
+        t, r = [], x.astype(np.float32)
+        for _ in range(nterm):
+            t.append(_bf16(r))
+            r = (r - t[-1]).astype(np.float32)
+        return t
+
+    want = {}
+    for math_name, pairs in (("bf16x3", [(2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]), ("bf16", [(0, 0)])):
+        ws, hs = split(w["w2"], 3), split(h1, 3)
+        acc = np.tile(w["b2"].astype(np.float32), (len(obs), 1))
+        for s in range(4):
+            ks = [kperm(8 * s + jj, h) for h in range(2) for jj in range(8)]
+            for (a, b) in pairs:
+                part = hs[b][:, ks].astype(np.float64) @ ws[a][:, ks].astype(np.float64).T
+                acc = (acc.astype(np.float64) + part).astype(np.float32)
+        h2 = np.maximum(acc, 0)
+        out = np.zeros((len(obs), 2), np.float32)
+        for o in range(2):
+            p = np.zeros((len(obs), 2), np.float32)
+            for h in range(2):
+                for q in range(32):
+                    k = kperm(q, h)
+                    p[:, h] = (p[:, h].astype(np.float64) + np.float64(w["w3"][o, k]) * h2[:, k].astype(np.float64)).astype(np.float32)
+            pre = (p[:, 0] + p[:, 1]) + np.float32(w["b3"][o])
+            out[:, o] = [np.float32(L.orc_spec_tanhf(float(x))) * np.float32(w["action_bound"][o]) for x in pre]
+        want[math_name] = out
+        got = O.actor_forward(O.make_actor(w, math=math_name), obs)
+        # the k-step sums of 16 products are exact in fp64 only while their exponents span < 53 - 16 bits; they do here
+        np.testing.assert_array_equal(got, want[math_name], err_msg=math_name)
+    f32 = O.actor_forward(O.make_actor(w), obs)
+    bound = np.float32(w["action_bound"])
+    assert (np.abs(want["bf16x3"] - f32) / bound).max() < 5e-6
+    e1 = (np.abs(want["bf16"] - f32) / bound).max()
+    assert 1e-5 < e1 < 6e-2, e1                               # plain bf16 is visibly, boundedly different
