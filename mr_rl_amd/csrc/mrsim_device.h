@@ -1210,25 +1210,15 @@ __device__ __forceinline__ void step_prologue(const KParams& P, const Rng& R, bo
     if (random_policy) action_from_words(P, W.w[0], af, aa);
 }
 
-// The same prologue with the step's auto-reset call RESET_POS(0,0) drawn in the SAME interleaved batch (same counter, same
-// key: same words as reset_words()).  For launches on a goal table, where some lane of almost every wave terminates at
-// almost every step: the reset block then starts with its words in hand instead of running a lone ten-round Philox chain
-// (ILP 2) with one or two lanes active.
-template <bool RK45, int NZ, bool MIS>
-__device__ __forceinline__ void step_prologue_with_reset(const KParams& P, const Rng& R, bool random_policy,
-                                                         StepWords<RK45, NZ, MIS>& W, float& af, float& aa,
-                                                         uint32_t (&wr)[4]) {
-    using SW = StepWords<RK45, NZ, MIS>;
-    static_assert(SW::NDYN > 0, "only for the noisy RK45 kernels");
-    uint32_t c0s[SW::NDYN + 1], w[SW::NDYN + 1][4];
-#pragma unroll
-    for (int j = 0; j < SW::NDYN; ++j) c0s[j] = c0_of(kStreamDyn, 0, (uint32_t)j);
-    c0s[SW::NDYN] = c0_of(kStreamResetPos, 0, 0);
-    philox_multi<SW::NDYN + 1>(R, c0s, w);
-#pragma unroll
-    for (int j = 0; j < SW::NDYN; ++j) { W.w[j][0] = w[j][0]; W.w[j][1] = w[j][1]; W.w[j][2] = w[j][2]; W.w[j][3] = w[j][3]; }
-    wr[0] = w[SW::NDYN][0]; wr[1] = w[SW::NDYN][1]; wr[2] = w[SW::NDYN][2]; wr[3] = w[SW::NDYN][3];
-    if (random_policy) action_from_words(P, W.w[0], af, aa);
+// RNG position of an auto-reset's draws (RESET_POS / RESET_CTOR streams): the step index at which the episode that ends
+// took its FIRST step = step - (length - 1), 64-bit modular (oracle: orc_env_step).  One counter block per episode, known
+// from the episode's start: a fused rollout can prepare the resets of a wave's envs together (mrsim_kernels.hip, reset cache).
+__device__ __forceinline__ Rng reset_rng(const Rng& R, int32_t counter) {
+    Rng Q = R;
+    const uint32_t back = (uint32_t)(counter - 1);
+    Q.step_lo = R.step_lo - back;
+    Q.step_hi = R.step_hi - (R.step_lo < back ? 1u : 0u);
+    return Q;
 }
 
 __device__ __forceinline__ void pack_obs(double x, double y, double gx, double gy, double d2, float (&obs)[5]) {
@@ -1237,14 +1227,42 @@ __device__ __forceinline__ void pack_obs(double x, double y, double gx, double g
     obs[4] = __builtin_amdgcn_sqrtf((float)d2);  // v_sqrt_f32 (1 ulp); inputs are >= 0 and far from denormal
 }
 
+// The state an auto-reset puts an env in (MR_Env.reset(init=None) on the env object of an episode loop): start position,
+// RK45 constructor.  `counter` = length of the episode that ends at step R (its draws sit at reset_rng(R, counter)).
+// Shared by the in-step reset (env_step) and the fused rollout's reset cache (mrsim_kernels.hip), which calls it for the
+// envs of a wave together, ahead of time: same function of (env, first step of the episode), same bits.
+template <bool RK45, int NZ, bool MIS>
+__device__ __forceinline__ void auto_reset_env(const KParams& P, const Rng& R, uint32_t fl, int32_t counter, EnvRegs& e,
+                                               double& rx, double& ry) {
+    double x0, y0;
+    uint32_t wr[4];
+    const Rng Q = reset_rng(R, counter);
+    reset_words(Q, wr);
+    sample_init(P, wr, x0, y0);
+    // The host-certified shortcut of the constructor test only where resets are hot: on a goal table episodes end at
+    // different steps, so some lane of most waves resets at most steps.  With the constant goal all
+    // episodes of the DDPG workload end together every max_timesteps + 1 steps, and its flag-specialised kernel keeps
+    // the code (and the register allocation of its time loop) it had.
+    // Which law the RK45 constructor inside reset runs under (MR_env.py:181-183 sets is_mismatched AFTER
+    // reset_start_pos): the re-used env object of an episode loop (RL/MR_ddpg.py:270) still carries the previous
+    // episode's law -- under is_mismatched the stale first stage of the new episode is the drift (0.2, -0.1) (+ noise) --
+    // a fresh env (kFResetFresh) the nominal one.
+    const bool need_sp = (fl & kFOutStatePrime) != 0;
+    if constexpr (MIS) {
+        if (fl & kFResetFresh) reset_env<RK45, NZ, false>(P, Q, x0, y0, e, rx, ry, wr, need_sp, (fl & kFGoalTable) != 0);
+        else reset_env<RK45, NZ, true>(P, Q, x0, y0, e, rx, ry, wr, need_sp, false);
+    } else {
+        reset_env<RK45, NZ, false>(P, Q, x0, y0, e, rx, ry, wr, need_sp, /*in_init_box=*/(fl & kFGoalTable) != 0);
+    }
+}
+
 // MR_Env.step for one env (MR_env.py:70-98).  DEFER: on a terminal step only the terminal outputs are recorded; the caller
-// performs the auto-reset itself (the block-cooperative reset of the goal-table rollout, mrsim_kernels.hip).
+// performs the auto-reset itself (the reset cache of the goal-table rollout, mrsim_kernels.hip).
 template <bool RK45, int NZ, bool MIS, bool DEFER = false>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
                                          EnvRegs& e, double act_f, double act_a, const StepWords<RK45, NZ, MIS>& W,
                                          uint32_t fl, StepOut& o, int& fail, const double2* __restrict__ sincos_lds = nullptr,
-                                         const float2* goal_pre = nullptr, const float2* goal0_pre = nullptr,
-                                         const uint32_t* wr_pre = nullptr) {
+                                         const float2* goal_pre = nullptr, const float2* goal0_pre = nullptr) {
     e.counter += 1;  // :80
     // the goal of this step only depends on the counter: the one-launch-per-step kernel fetches it now, so that the table
     // read (an L1/L2 hit, but hundreds of cycles) completes behind the integrator instead of stalling the termination
@@ -1309,26 +1327,8 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         o.fret = e.ep_ret;
         o.flen = e.counter;
         if constexpr (DEFER) return;
-        double x0, y0, rx, ry;
-        uint32_t wr[4];
-        if (wr_pre != nullptr) { wr[0] = wr_pre[0]; wr[1] = wr_pre[1]; wr[2] = wr_pre[2]; wr[3] = wr_pre[3]; }  // drawn with the step's batch
-        else reset_words(R, wr);
-        sample_init(P, wr, x0, y0);
-        // The host-certified shortcut of the constructor test only where resets are hot: on a goal table episodes end at
-        // different steps, so some lane of almost every wave resets at almost every step.  With the constant goal all
-        // episodes of the DDPG workload end together every max_timesteps + 1 steps, and its flag-specialised kernel keeps
-        // the code (and the register allocation of its time loop) it had.
-        // Which law the RK45 constructor inside reset runs under (MR_env.py:181-183 sets is_mismatched AFTER
-        // reset_start_pos): the re-used env object of an episode loop (RL/MR_ddpg.py:270) still carries the previous
-        // episode's law -- under is_mismatched the stale first stage of the new episode is the drift (0.2, -0.1) (+ noise) --
-        // a fresh env (kFResetFresh) the nominal one.
-        const bool need_sp = (fl & kFOutStatePrime) != 0;
-        if constexpr (MIS) {
-            if (fl & kFResetFresh) reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry, wr, need_sp, (fl & kFGoalTable) != 0);
-            else reset_env<RK45, NZ, true>(P, R, x0, y0, e, rx, ry, wr, need_sp, false);
-        } else {
-            reset_env<RK45, NZ, false>(P, R, x0, y0, e, rx, ry, wr, need_sp, /*in_init_box=*/(fl & kFGoalTable) != 0);
-        }
+        double rx, ry;
+        auto_reset_env<RK45, NZ, MIS>(P, R, fl, e.counter, e, rx, ry);
         if constexpr (RK45) { o.spx = (float)rx; o.spy = (float)ry; }  // state_prime = last RHS value
         if (goal0_pre != nullptr) { gx = (double)goal0_pre->x; gy = (double)goal0_pre->y; }  // row 0: loaded once per launch
         else goal_at(P, fl, goal_table, R.env, 0, gx, gy);

@@ -290,29 +290,28 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     // All per-step stores use a wave-uniform base (block start of row t, kept in SGPRs) plus a 32-bit
     // per-lane offset, so no 64-bit address arithmetic runs on the vector unit inside the time loop.
     constexpr bool HAS_ACT = ACT != kActOff;
-#ifndef MRSIM_COOP_RESET   // A/B switch (off): block-cooperative auto-reset on goal-table launches (below).  Measured on the mixed
-#define MRSIM_COOP_RESET 0 // trajectory set: same bits, 154.4 vs 140.6 us per launch (profiles/r03/ab_coop_reset_mixed.txt) -- the
-#endif                     // block barrier every step costs more than three quarters of the reset instructions save.
-    // Block-cooperative auto-reset (goal-table launches: the mixed trajectory set).  There some lane of almost every wave
-    // terminates at almost every step (0.9 resetting waves per wave-step, 2.5 lanes each), and a wave that holds ONE such lane
-    // walks the whole ~110-instruction reset block (a Philox call, the start position, the constructor's draw and test) with
-    // 61 lanes idle.  Instead the waves of a block queue their terminated lanes in LDS and ONE wave per step (rotating, so that
-    // the four SIMDs share the work) resets them all, one per lane: same RNG counters, same arithmetic, same bits -- a quarter of
-    // the instructions.  A wave with more than kCoopMax terminated lanes (a whole cohort timing out together) resets them itself.
-    // (It needs a block barrier in every step, which puts the block's four waves -- one per SIMD -- in lockstep: slower, see above.)
-    constexpr bool COOP = MRSIM_COOP_RESET != 0 && !HAS_ACT && RK45 && NZ == kNoiseFast && !MIS && FL != 0 && BLOCK == kBlock &&
-                          (FL & kFGoalTable) != 0 && (FL & kFAutoReset) != 0 && (FL & kFOutStatePrime) == 0;
-    constexpr unsigned kCoopMax = 8;
-    struct CoopSlot { double x, y, f0x, f0y, h_abs; };
-    __shared__ unsigned s_coop_cnt[COOP ? 3 : 1];
-    __shared__ unsigned char s_coop_idx[COOP ? 64 : 1];
-    __shared__ CoopSlot s_coop_res[COOP ? 64 : 1];
-    if constexpr (COOP) { if (threadIdx.x < 3) s_coop_cnt[threadIdx.x] = 0u; }   // published by the table barrier below
+#ifndef MRSIM_RESET_CACHE   // 1 (default): the reset cache below; 0: every terminated lane resets inside env_step (A/B, same bits)
+#define MRSIM_RESET_CACHE 1
+#endif
+    // Reset cache (goal-table launches: the mixed trajectory set).  There episodes end at different steps: 0.6 of the waves hold
+    // a terminated env at any step, 2.5 of their 64 on average, and inside env_step such a wave walks the whole reset block
+    // (a Philox call, the start position, the constructor's draw and test: ~115 instructions) with 61 lanes idle.  But the
+    // state a reset produces is a function of (env, first step of the episode that ends) alone -- auto_reset_env /
+    // reset_rng, mrsim_device.h -- so it can be computed any time after that episode has started.  Each lane keeps the state
+    // of ITS next reset in an LDS slot; a terminated lane just loads it.  Slots are (re)filled for all lanes of the wave that
+    // have none, together, when a lane without one terminates: every 15 steps on the mixed set, 25 lanes at a time instead
+    // of 2.5.  Same function, same arguments, same bits as the in-step reset (which the one-launch-per-step kernel, the
+    // generic kernel and the state_prime output keep using).
+    constexpr bool CACHE = MRSIM_RESET_CACHE != 0 && !HAS_ACT && RK45 && NZ != kNoNoise && FL != 0 && (FL & kFGoalTable) != 0 &&
+                           (FL & kFAutoReset) != 0 && (FL & kFOutStatePrime) == 0;
+    struct __attribute__((aligned(16))) ResetSlot { double x, y, f0x, f0y, h_abs; float d, pad; };
+    __shared__ ResetSlot s_reset[CACHE ? BLOCK : 1];
+    unsigned long long have_slot = 0ull;   // wave-uniform: lanes whose slot holds the reset of their CURRENT episode
     const long long blk0 = (long long)blockIdx.x * BLOCK;
     const unsigned tid = threadIdx.x;
     const long long i_raw = blk0 + tid;
     const bool active = i_raw < P.n;
-    const long long i = ((HAS_ACT || COOP) && !active) ? P.n - 1 : i_raw;
+    const long long i = (HAS_ACT && !active) ? P.n - 1 : i_raw;
     __shared__ __attribute__((aligned(16))) float s_actor[ActLds<ACT>::Floats];
     if constexpr (ACT != kActOff) actor_stage_blob<ACT>(ac.blob, s_actor, tid, BLOCK);  // the barrier below (or its own) publishes it
 #if MRSIM_ROLLOUT_TABLE == 1
@@ -329,7 +328,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
 #if MRSIM_ROLLOUT_TABLE != 1
     if constexpr (HAS_ACT) __syncthreads();
 #endif
-    if constexpr (!HAS_ACT && !COOP) { if (!active) return; }   // (wave-wide MFMA / block barriers in the loop: every lane stays)
+    if constexpr (!HAS_ACT) { if (!active) return; }   // (wave-wide MFMA in the loop: every lane stays)
     EnvRegs e;
 #ifdef MRSIM_WAVE_PROBE
     const unsigned long long clk0 = wall_clock64();
@@ -401,15 +400,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
             const float2 a = (reinterpret_cast<const float2*>(ra.actions) + row)[tid];
             af = a.x; aa = a.y;
         }
-#ifndef MRSIM_PRE_RESET   // A/B switch (off): 1 = on goal-table launches the auto-reset's Philox call rides in the step's batch
-#define MRSIM_PRE_RESET 0 // (step_prologue_with_reset).  Measured SLOWER on the mixed trajectory set, 145.8 vs 140.8 us per launch,
-#endif                    // same bits (profiles/r03/ab_pre_reset_mixed.txt): 27 more vector instructions in EVERY wave-step cost
-                          // more than the 34 they save in the 0.9 reset blocks per wave-step.
-        constexpr bool kPreReset = MRSIM_PRE_RESET != 0 && !HAS_ACT && RK45 && NZ == kNoiseFast && FL != 0 && (FL & kFGoalTable) != 0 &&
-                                   (FL & kFAutoReset) != 0;
-        uint32_t wr_pre[4] = {0u, 0u, 0u, 0u};
-        if constexpr (kPreReset) step_prologue_with_reset<RK45, NZ, MIS>(P, R, !(fl & kFActions), W, af, aa, wr_pre);
-        else step_prologue<RK45, NZ, MIS>(P, R, !HAS_ACT && !(fl & kFActions), W, af, aa, HAS_ACT && (fl & kFActorOU));
+        step_prologue<RK45, NZ, MIS>(P, R, !HAS_ACT && !(fl & kFActions), W, af, aa, HAS_ACT && (fl & kFActorOU));
         if constexpr (HAS_ACT) {
             actor_policy<ou_nz<NZ>(), ACT>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
             if constexpr (MRSIM_ACTOR_PRIO == 3) __builtin_amdgcn_s_setprio(0);
@@ -417,53 +408,30 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         }
         if (!(fl & kFActions64)) { adf = (double)af; ada = (double)aa; }
         StepOut o;
-        env_step<RK45, NZ, MIS, COOP>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr,
-                                      kPreReset ? wr_pre : nullptr);
-        if constexpr (COOP) {
-            const bool dn = o.has_final && active;
-            const unsigned long long m = __ballot(dn);
-            const unsigned nw = (unsigned)__builtin_popcountll(m);
-            const bool own = nw > kCoopMax;                 // wave-uniform
-            unsigned* cnt = &s_coop_cnt[(unsigned)t % 3u];
-            unsigned slot = 0u;
-            if (nw != 0u && !own) {
-                unsigned base = 0u;
-                if ((tid & 63u) == (unsigned)__builtin_ctzll(m)) base = atomicAdd(cnt, nw);   // one lane of the wave claims nw slots
-                base = (unsigned)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
-                slot = base + (unsigned)__builtin_popcountll(m & ((1ull << (tid & 63u)) - 1ull));
-                if (dn) s_coop_idx[slot] = (unsigned char)tid;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (A) the step's queue is complete (LDS only: the
-            const unsigned total = *cnt;                                          //     transition stores stay in flight)
-            if (tid == 0) s_coop_cnt[((unsigned)t + 2u) % 3u] = 0u;               // the counter of step t + 2 (nobody is there yet)
-            auto do_reset = [&](const Rng& RR, EnvRegs& ee) {
-                double x0, y0, rx, ry;
-                uint32_t wr[4];
-                reset_words(RR, wr);
-                sample_init(P, wr, x0, y0);
-                reset_env<RK45, NZ, false>(P, RR, x0, y0, ee, rx, ry, wr, false, /*in_init_box=*/true);
-            };
-            if (total != 0u) {                                                    // block-uniform
-                if ((tid >> 6) == ((unsigned)t & 3u) && (tid & 63u) < total) {    // this step's server wave: one queued env per lane
-                    const unsigned who = s_coop_idx[tid & 63u];
-                    Rng R2 = R;
-                    R2.env = P.env_id0 + (uint32_t)(blk0 + who);
-                    EnvRegs e2;
-                    do_reset(R2, e2);
-                    s_coop_res[tid & 63u] = CoopSlot{e2.x, e2.y, e2.f0x, e2.f0y, e2.h_abs};
+        env_step<RK45, NZ, MIS, CACHE>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr);
+        if constexpr (CACHE) {
+            const unsigned long long ended = __ballot(o.has_final);
+            if (ended != 0ull) {                                   // wave-uniform
+                const unsigned lane = tid & 63u;
+                if ((ended & ~have_slot) != 0ull) {                // a lane without a slot terminated: fill every empty slot
+                    if (!((have_slot >> lane) & 1ull)) {
+                        EnvRegs q;
+                        double rx, ry;
+                        auto_reset_env<RK45, NZ, MIS>(P, R, fl, e.counter, q, rx, ry);   // e.counter: steps of the episode so far
+                        const double gx0 = (double)goal0.x, gy0 = (double)goal0.y, ex = gx0 - q.x, ey = gy0 - q.y;
+                        float ob[5];
+                        pack_obs(q.x, q.y, gx0, gy0, __builtin_fma(ex, ex, ey * ey), ob);
+                        s_reset[tid] = ResetSlot{q.x, q.y, q.f0x, q.f0y, q.h_abs, ob[4], 0.f};
+                    }
+                    have_slot = ~0ull;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (B) results are there
-            }
-            if (dn) {
-                if (own) {
-                    do_reset(R, e);
-                } else {
-                    const CoopSlot r = s_coop_res[slot];
+                if (o.has_final) {
+                    const ResetSlot r = s_reset[tid];
                     e.x = r.x; e.y = r.y; e.f0x = r.f0x; e.f0y = r.f0y; e.h_abs = r.h_abs;
                     e.counter = 0; e.ep_ret = 0.f;
+                    o.obs[0] = (float)r.x; o.obs[1] = (float)r.y; o.obs[2] = goal0.x; o.obs[3] = goal0.y; o.obs[4] = r.d;
                 }
-                const double gx0 = (double)goal0.x, gy0 = (double)goal0.y, ex = gx0 - e.x, ey = gy0 - e.y;
-                pack_obs(e.x, e.y, gx0, gy0, __builtin_fma(ex, ex, ey * ey), o.obs);
+                have_slot &= ~ended;                               // their next episode starts now: no slot for it yet
             }
         }
         if constexpr (HAS_ACT) {
@@ -483,7 +451,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         // The [T][N] outputs are write-once streams the kernel never reads back: non-temporal stores (+1 %)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef double f64x2 __attribute__((ext_vector_type(2)));
-        if ((HAS_ACT || COOP) && !active) continue;  // a lane past n: nothing to store
+        if (HAS_ACT && !active) continue;  // a lane past n: nothing to store
         if (fl & kFOutTraj) {
             const f64x2 v = {o.px, o.py};
             __builtin_nontemporal_store(v, &(reinterpret_cast<f64x2*>(ra.traj_xy) + row)[tid]);
@@ -524,7 +492,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
             if (fl & kFOutFinalLen) ra.final_len[i] = o.flen;
         }
     }
-    if ((HAS_ACT || COOP) && !active) return;
+    if (HAS_ACT && !active) return;
     store_env(st.pos, st.aux, st.ep_ret, i, P, e);
     if constexpr (HAS_ACT) {
         if (P.flags & kFActorOU) reinterpret_cast<float2*>(ac.ou_state)[i] = make_float2(ou0, ou1);

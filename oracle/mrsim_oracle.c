@@ -652,11 +652,18 @@ int orc_env_step(const OrcParams* p, OrcEnv* e, const float* goal_table, double 
         if (final_obs) memcpy(final_obs, obs, 5 * sizeof(double));
         if (final_ret) *final_ret = e->ep_ret;
         if (final_len) *final_len = e->counter;
+        /* RNG position of an auto-reset's draws (start position, constructor noise): the step index at which the episode
+         * that just ended took its FIRST step, step_idx - (length - 1) in 64-bit modular arithmetic.  Every episode has its
+         * own first step, so every reset has its own counter block -- and the block is known from the moment the episode
+         * starts, which lets the GPU rollout prepare the resets of a wave's envs together (mrsim_kernels.hip: reset cache). */
+        const uint64_t step_now = nz->step_idx;
+        nz->step_idx = step_now - (uint64_t)(uint32_t)(e->counter - 1);
         double xy[2];
         orc_sample_init(p, nz->seed, env_id, nz->step_idx, xy);
         /* MR_env.py:181-183: reset_start_pos runs BEFORE is_mismatched is assigned, so the env object an episode loop
          * re-uses builds its RK45 under the previous episode's law; a fresh object under the nominal one */
         orc_env_reset(p, e, goal_table, xy[0], xy[1], (p->mismatched && !p->auto_reset_fresh_env) ? 1 : 0, nz, env_id, obs);
+        nz->step_idx = step_now;
     }
     return 0;
 }
