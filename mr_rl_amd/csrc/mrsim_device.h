@@ -1109,13 +1109,24 @@ __device__ __forceinline__ void store_env(double* __restrict__ pos, float* __res
 }
 
 // goal of (env, episode step): MR_Env.init_goal = (0,0) (MR_env.py:57) or a trajectory table
-__device__ __forceinline__ float2 goal_fetch(const KParams& P, uint32_t fl, const float* __restrict__ goal_table,
-                                             uint32_t env, int32_t counter) {
-    if (!(fl & kFGoalTable)) return make_float2(0.f, 0.f);
+// row pointer of an env's trajectory in the goal table (nullptr: constant goal (0, 0)); loop-invariant for a lane
+__device__ __forceinline__ const float2* goal_row_of(const KParams& P, uint32_t fl, const float* __restrict__ goal_table,
+                                                     uint32_t env) {
+    if (!(fl & kFGoalTable)) return nullptr;
     const int K = P.goal_K > 0 ? P.goal_K : 1, T = P.goal_T > 0 ? P.goal_T : 1;
     const int k = (K == 1) ? 0 : (int)(env % (uint32_t)K);
-    const int r = counter < 0 ? 0 : (counter >= T ? T - 1 : counter);
-    return reinterpret_cast<const float2*>(goal_table)[(long long)k * T + r];
+    return reinterpret_cast<const float2*>(goal_table) + (long long)k * T;
+}
+__device__ __forceinline__ float2 goal_from_row(const KParams& P, const float2* __restrict__ row, int32_t counter) {
+    if (row == nullptr) return make_float2(0.f, 0.f);
+    const int T = P.goal_T > 0 ? P.goal_T : 1;
+    int r;  // clamp(counter, 0, T - 1)
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(counter), "s"(T - 1));
+    return row[r];
+}
+__device__ __forceinline__ float2 goal_fetch(const KParams& P, uint32_t fl, const float* __restrict__ goal_table,
+                                             uint32_t env, int32_t counter) {
+    return goal_from_row(P, goal_row_of(P, fl, goal_table, env), counter);
 }
 __device__ __forceinline__ void goal_at(const KParams& P, uint32_t fl, const float* __restrict__ goal_table,
                                         uint32_t env, int32_t counter, double& gx, double& gy) {

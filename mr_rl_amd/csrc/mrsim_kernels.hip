@@ -341,7 +341,10 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     int fail = 0;
     const unsigned slot = hw_wave_slot();
     float* obs_lane = ra.obs_T != nullptr ? ra.obs_T + (blk0 + tid) * 5 : nullptr;  // row t = 0 of this lane's [N][5] record
-    float2 goal_next = goal_fetch(P, FL != 0 ? FL : P.flags, ra.goal_table, P.env_id0 + (uint32_t)i, e.counter + 1);
+    // this lane's row of the goal table: two registers instead of an integer multiply-add and two 64-bit shifts per step
+    const float2* goal_row = goal_row_of(P, FL != 0 ? FL : P.flags, ra.goal_table, P.env_id0 + (uint32_t)i);
+    if constexpr (FL != 0 && (FL & kFGoalTable) != 0) __builtin_assume(goal_row != nullptr);   // (validated by the launcher)
+    float2 goal_next = goal_from_row(P, goal_row, e.counter + 1);
     // consumed HERE for the same reason as the state above: otherwise the in-loop use of the first goal carries an
     // s_waitcnt vmcnt(0) that, on every later iteration, drains the previous step's stores
     asm volatile("" : "+v"(goal_next.x), "+v"(goal_next.y));
@@ -350,7 +353,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     constexpr bool kGoal0 = FL == 0 || (FL & kFGoalTable) != 0;
     float2 goal0 = make_float2(0.f, 0.f);
     if constexpr (kGoal0) {
-        goal0 = goal_fetch(P, FL != 0 ? FL : P.flags, ra.goal_table, P.env_id0 + (uint32_t)i, 0);
+        goal0 = goal_from_row(P, goal_row, 0);
         asm volatile("" : "+v"(goal0.x), "+v"(goal0.y));
     }
     float obs_cur[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -443,7 +446,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         // after the stores makes its s_waitcnt vmcnt(0) wait for every one of them; issued before, the wait is vmcnt(5)
         // (the stores stay in flight).  Measured +0.7 % on the mixed trajectory set: the stores have long retired by then
         // (what that workload really pays for is its frequent divergent auto-resets, 398 vs 272 VALU per wave-step).
-        goal_next = goal_fetch(P, fl, ra.goal_table, R.env, e.counter + 1);
+        goal_next = goal_from_row(P, goal_row, e.counter + 1);
         asm volatile("" ::: "memory");  // the stores below stay below the load
         // default: carry K0 / h_abs exactly as a step-by-step run stores them in HBM (fp32), so that a rollout and T
         // single steps give identical bits; kFCarry64 keeps them in fp64 registers until the launch ends

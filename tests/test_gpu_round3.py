@@ -27,6 +27,60 @@ def _env(n, seed=0, goal_table=None, env_id0=0, **cfg_kw):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# the fused rollout's reset cache (goal-table launches) against the in-step reset and the oracle
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("carry", ["f32", "f64"])
+@pytest.mark.parametrize("mis", [False, True])
+def test_reset_cache_with_episodes_of_a_few_steps(mis, carry):
+    """The flag-specialised goal-table rollout keeps each lane's NEXT reset in an LDS slot and refills the empty slots of a
+    wave together (mrsim_kernels.hip).  Hard case: goals inside the init box and a goal radius of 6, so that episodes last 1-10
+    steps -- lanes terminate several times between two refills, in consecutive steps, right after a launch starts, and
+    whole waves at once.  Three launches of 40 steps against (a) 120 single steps (the in-step reset: same bits, every
+    transition, the carried state, returns, lengths) and (b) the oracle (noise_math='spec': positions to POS_TOL, the same
+    dones, lengths), both laws; the fp64 carry against the oracle alone (tools/ab_rollout.py compares it bitwise with a build
+    without the cache: profiles/r03/ab_reset_cache_mixed.txt)."""
+    from oracle import oracle as O
+    from tests.util import orc_params_from_cfg
+    from mr_rl_amd import MRConfig, MRVecEnv
+    n, T, L = 1500, 40, 3
+    tab = np.random.default_rng(3).uniform(104, 116, (3, 52, 2)).astype(np.float32)
+    cfg = lambda: MRConfig(noise_var=1.0, auto_reset=True, is_mismatched=mis, noise_math="spec", reward_mode="goal",  # noqa: E731
+                           min_dist2goal=6.0, rollout_carry=carry, seed=13)
+    e1 = MRVecEnv(n, cfg=cfg(), seed=13, env_id0=77, goal_table=tab)
+    e2 = MRVecEnv(n, cfg=cfg(), seed=13, env_id0=77, goal_table=tab)
+    orc = O.VecOracle(n, orc_params_from_cfg(cfg(), 3, 52), seed=13, env_id0=77, goal_table=tab, threads=8)
+    e1.reset(); e2.reset(); orc.reset(0)
+    lens = []
+    t_abs = 0
+    for launch in range(L):
+        out = e1.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
+        obs, rew, done, act = (out[q].cpu().numpy() for q in ("obs", "rew", "done", "actions"))
+        for t in range(T):
+            t_abs += 1
+            a = orc.random_policy(t_abs, cfg().policy_low, cfg().policy_high)
+            np.testing.assert_array_equal(act[t], a)
+            orc.step(a, step_idx=t_abs)
+            np.testing.assert_array_equal(done[t].astype(np.uint8), orc.done, err_msg=f"launch {launch} step {t}")
+            np.testing.assert_allclose(obs[t][:, :2], orc.obs[:, :2], rtol=0, atol=2e-5)
+            if carry == "f32":
+                o2, r2, d2, _ = e2.step(None)
+                np.testing.assert_array_equal(obs[t].view(np.uint32), o2.cpu().numpy().view(np.uint32))
+                np.testing.assert_array_equal(rew[t], r2.cpu().numpy())
+                np.testing.assert_array_equal(done[t], d2.cpu().numpy())
+            lens.append(orc.final_len[orc.done.astype(bool)].copy())
+        np.testing.assert_allclose(e1.pos.cpu().numpy(), orc.envs["y"], rtol=0, atol=POS_TOL)
+    if carry == "f32":
+        np.testing.assert_array_equal(e1.pos.cpu().numpy().view(np.uint64), e2.pos.cpu().numpy().view(np.uint64))
+        np.testing.assert_array_equal(e1.aux.cpu().numpy().view(np.uint32), e2.aux.cpu().numpy().view(np.uint32))
+        np.testing.assert_array_equal(e1.final_ret.cpu().numpy(), e2.final_ret.cpu().numpy())
+        np.testing.assert_array_equal(e1.final_len.cpu().numpy(), e2.final_len.cpu().numpy())
+    np.testing.assert_array_equal(e1.final_len.cpu().numpy(), orc.final_len)
+    lens = np.concatenate(lens)
+    assert len(lens) > 12 * n and np.median(lens) <= 6 and (lens == 1).sum() > 3 * n   # many resets, many one-step episodes
+    e1.check_status()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # auto-reset = reset() on the SAME env object (RL/MR_ddpg.py:270; MR_env.py:181-183)
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", [k for k in sorted(REUSED) if float(REUSED[k]["sigma"]) == 0.0])
