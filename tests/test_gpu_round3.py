@@ -80,6 +80,42 @@ def test_reset_cache_with_episodes_of_a_few_steps(mis, carry):
     e1.check_status()
 
 
+def test_auto_reset_key_wraps_when_the_step_index_is_set_back():
+    """The draws of an auto-reset sit at step - (length - 1) in 64-bit modular arithmetic (reset_rng / orc_env_step).  Setting
+    the step index back in the middle of the episodes makes that difference negative: kernel (borrow across the two 32-bit
+    words, through the reset cache and through single steps) and oracle must wrap the same way."""
+    from oracle import oracle as O
+    from tests.util import orc_params_from_cfg
+    from mr_rl_amd import MRConfig, MRVecEnv
+    n = 700
+    tab = np.random.default_rng(5).uniform(104, 116, (3, 52, 2)).astype(np.float32)
+    cfg = lambda: MRConfig(noise_var=1.0, auto_reset=True, noise_math="spec", reward_mode="goal", min_dist2goal=4.0, seed=3)  # noqa: E731
+    e1 = MRVecEnv(n, cfg=cfg(), seed=3, goal_table=tab)
+    e2 = MRVecEnv(n, cfg=cfg(), seed=3, goal_table=tab)
+    orc = O.VecOracle(n, orc_params_from_cfg(cfg(), 3, 52), seed=3, goal_table=tab, threads=8)
+    e1.reset(); e2.reset(); orc.reset(0)
+    e1.step_idx = e2.step_idx = k = 2**32 - 3          # the low word is about to carry
+    ndone = 0
+    for launch, T in enumerate((9, 30, 30)):
+        if launch == 1:
+            e1.step_idx = e2.step_idx = k = 2            # back to the start: step - (length - 1) < 0 for every running episode
+        out = e1.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
+        obs, done = out["obs"].cpu().numpy(), out["done"].cpu().numpy()
+        for t in range(T):
+            a = orc.random_policy(k, cfg().policy_low, cfg().policy_high)
+            orc.step(a, step_idx=k)
+            k += 1
+            o2, r2, d2, _ = e2.step(None)
+            np.testing.assert_array_equal(done[t].astype(np.uint8), orc.done)
+            np.testing.assert_array_equal(obs[t].view(np.uint32), o2.cpu().numpy().view(np.uint32))
+            np.testing.assert_allclose(obs[t][:, :2], orc.obs[:, :2], rtol=0, atol=2e-5)   # the reset rows: same start positions
+            ndone += int(orc.done.sum())
+    assert ndone > 3 * n
+    np.testing.assert_array_equal(e1.pos.cpu().numpy().view(np.uint64), e2.pos.cpu().numpy().view(np.uint64))
+    np.testing.assert_allclose(e1.pos.cpu().numpy(), orc.envs["y"], rtol=0, atol=POS_TOL)
+    e1.check_status()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # auto-reset = reset() on the SAME env object (RL/MR_ddpg.py:270; MR_env.py:181-183)
 # ----------------------------------------------------------------------------------------------------------------------
