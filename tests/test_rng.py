@@ -69,3 +69,36 @@ def test_noise_increment_law():
     assert abs(d[:, 1].mean() - 0.03 * vy) < 5 * sd / np.sqrt(n)
     assert abs(d[:, 0].std() / sd - 1) < 0.03 and abs(d[:, 1].std() / sd - 1) < 0.03
     assert (v.envs["n_attempts"] == 1).all()
+
+
+def test_auto_reset_draws_sit_at_the_first_step_of_the_episode_that_ends():
+    """the start position of an auto-reset is RESET_POS(0) at step - (length - 1) -- the step at which the
+    episode that ends took its first step -- for the global env id; distinct episodes of an env get distinct positions."""
+    import ctypes as C
+    from mr_rl_amd import MRConfig
+    from tests.util import orc_params_from_cfg
+    n, id0, seed = 300, 1000, 21
+    cfg = MRConfig(noise_var=1.0, auto_reset=True, reward_mode="goal", min_dist2goal=5.0, seed=seed)
+    tab = np.random.default_rng(1).uniform(104, 116, (3, 52, 2)).astype(np.float32)
+    p = orc_params_from_cfg(cfg, 3, 52)
+    v = O.VecOracle(n, p, seed=seed, env_id0=id0, goal_table=tab, threads=4)
+    v.reset(0)
+    first = np.full(n, 5, dtype=np.int64)            # step index of the first step of the running episode
+    seen, checked = [set() for _ in range(n)], 0
+    L = O.lib()
+    L.orc_sample_init.argtypes = [C.POINTER(O.OrcParams), C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_double)]
+    L.orc_sample_init.restype = None
+    for k in range(5, 5 + 150):
+        a = v.random_policy(k, cfg.policy_low, cfg.policy_high)
+        v.step(a, step_idx=k)
+        for i in np.nonzero(v.done)[0]:
+            assert v.final_len[i] == k - first[i] + 1
+            xy = (C.c_double * 2)()
+            L.orc_sample_init(C.byref(p), seed, id0 + int(i), int(first[i]), xy)
+            np.testing.assert_array_equal(v.envs["y"][i], [xy[0], xy[1]])
+            np.testing.assert_array_equal(v.obs[i, :2], [xy[0], xy[1]])
+            assert (xy[0], xy[1]) not in seen[i]
+            seen[i].add((xy[0], xy[1]))
+            first[i] = k + 1
+            checked += 1
+    assert checked > 5 * n
