@@ -6,7 +6,7 @@ the GPU and is meant for plumbing / parity, not speed -- use MRVecEnv for throug
 """
 import numpy as np
 
-from . import recorder
+from . import recorder, spaces
 from .config import MRConfig
 from .vec_env import MRVecEnv
 
@@ -32,6 +32,9 @@ class MR_Env:
                            track_state_prime=True)
         v = self._v
         self.action_space, self.observation_space, self.init_space = v.action_space, v.observation_space, v.init_space
+        # MR_env.py:43-45: never sampled by the reference (its only use, :158, is commented out); low > high as written there
+        self.init_goal_space = spaces.Box([-31.0, -31.0], [-32.0, -32.0])
+        self.goal_loc = None
         self.borders = [[-510, 510], [-510, -510], [510, -510], [510, 510]]  # MR_env.py:46-50 (drawing only)
         self.simulator = _Sim(self)
         self.test_performance = False
@@ -60,6 +63,9 @@ class MR_Env:
             init = self.init_space.sample()  # float32, MR_env.py:173
         init = np.asarray(init, dtype=np.float64).reshape(2)
         obs = self._v.reset(init=init[None, :], noise_var=noise_var, a0=a0, is_mismatched=is_mismatched)
+        # MR_env.py:182: a second draw from init_space at every reset; nothing reads it (the goal stays init_goal), but it
+        # advances the space's sampler, so a loop of reset(init=None) visits every OTHER sample of the stream -- as the reference
+        self.goal_loc = self.init_space.sample()
         self.last_pos = init
         self.counter = 0
         obs = obs[0].double().cpu().numpy()
