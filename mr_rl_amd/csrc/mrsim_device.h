@@ -103,6 +103,9 @@ __device__ __forceinline__ constexpr uint32_t c0_of(uint32_t stream, uint32_t bl
     return (stream << 28) | (block << 4) | call;
 }
 
+#ifndef MRSIM_PHILOX_ROUNDS     // measurement builds only (tools/ab_rollout.py): what the generator's ten rounds cost at the power
+#define MRSIM_PHILOX_ROUNDS 10  // cap.  The product and the oracle use 10 (Random123's default; 7 is its Crush-resistant minimum).
+#endif
 struct Rng {
     uint32_t k0, k1, step_lo, step_hi, env;
 };
@@ -126,7 +129,7 @@ __device__ __forceinline__ Rng make_rng(const KParams& P, long long i, unsigned 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t (&o)[4]) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < MRSIM_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         // Rounds 0-2 still have wave-uniform operands (step index, seed, call id live in SGPRs) and are
@@ -169,7 +172,7 @@ __device__ __forceinline__ void philox_multi(const Rng& R, const uint32_t (&c0s)
 #pragma unroll
     for (int j = 0; j < N; ++j) { c[j][0] = c0s[j]; c[j][1] = R.step_lo; c[j][2] = R.step_hi; c[j][3] = R.env; }
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < MRSIM_PHILOX_ROUNDS; ++r) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const uint64_t p0 = (uint64_t)0xD2511F53u * c[j][0];
