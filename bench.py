@@ -415,8 +415,9 @@ class RolloutRegion:
         self.g.finish()  # outstanding async all-gathers belong to the timed region
         torch.cuda.synchronize(self.dev)
         t2 = time.perf_counter()
-        self.barrier()
-        el = time.perf_counter() - t0
+        if self.world > 1:
+            self.barrier()   # one rank: the synchronize above IS the closing barrier + synchronize (a second device-wide
+        el = time.perf_counter() - t0   # synchronize on the idle GPU costs ~10 us: a fifth of a 20-step region's GPU work)
         # where this rank's wall time went: host enqueue (launch argument blocks, event records, collectives), waiting for
         # the GPU, closing barrier -- a region of one short launch group is mostly the first and the last
         self.last_phases_us = {"enqueue": round((t1 - t0) * 1e6, 1), "wait_gpu": round((t2 - t1) * 1e6, 1),
@@ -812,7 +813,8 @@ def main():
         run(K)
         gatherer.finish()
         torch.cuda.synchronize(dev)
-        barrier()
+        if world > 1:
+            barrier()    # (one rank: the synchronize above closes the region)
         el = time.perf_counter() - t0
         launches = n_launches[0] - l0
         per_rank_s = [el]
