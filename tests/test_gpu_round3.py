@@ -116,6 +116,43 @@ def test_auto_reset_key_wraps_when_the_step_index_is_set_back():
     e1.check_status()
 
 
+@pytest.mark.parametrize("math", ["fast", "spec"])
+def test_noise_increments_are_gaussian_at_full_size(math):
+    """SURVEY 3.3 at BASELINE config 4's size: away from the origin one env step adds, per axis, a Gaussian of standard deviation
+    dt sigma sqrt(sum B_i^2) = 0.868938 dt sigma around dt v (the five stage noises of the Dormand-Prince combination; the stale
+    first stage carries the previous constructor's draw).  262 144 envs x 3 steps through the fused rollout, default
+    (hardware-transcendental) and specified Box-Muller: Kolmogorov-Smirnov against N(0, 1) with the THEORETICAL scale, tail
+    mass beyond 3 and 4 sigma, kurtosis, and no correlation between axes, consecutive steps or neighbouring envs."""
+    import scipy.stats as st
+    from mr_rl_amd import MRConfig, MRVecEnv
+    n, T = 262144, 4
+    env = MRVecEnv(n, cfg=MRConfig(noise_var=1.0, noise_math=math, rollout_carry="f64"), seed=101)
+    env.reset(init=np.tile([[110.0, 115.0]], (n, 1)))
+    acts = np.tile(np.array([[4.0, 0.5]], dtype=np.float32), (T, 1))
+    traj = env.rollout(T, actions=acts, shared_actions=True, want=("traj",))["traj"].cpu().numpy()   # [T, n, 2]
+    v = 4.0 * np.array([np.cos(np.float64(np.float32(0.5))), np.sin(np.float64(np.float32(0.5)))])
+    sd = np.sqrt((35 / 384) ** 2 + (500 / 1113) ** 2 + (125 / 192) ** 2 + (2187 / 6784) ** 2 + (11 / 84) ** 2) * 0.03
+    z = (np.diff(traj, axis=0) - 0.03 * v) / sd                      # steps 2..4, standardised with the theoretical scale
+    assert z.shape == (T - 1, n, 2)
+    for k in range(T - 1):
+        for ax in range(2):
+            x = z[k, :, ax]
+            assert st.kstest(x, "norm").pvalue > 1e-4, (k, ax, st.kstest(x, "norm"))
+            assert abs(x.mean()) < 4.5 / np.sqrt(n) and abs(x.std() - 1) < 4.5 / np.sqrt(2 * n)
+            assert abs(st.kurtosis(x)) < 4.5 * np.sqrt(24 / n)
+            for c, p in ((3.0, 2 * st.norm.sf(3.0)), (4.0, 2 * st.norm.sf(4.0))):
+                got = (np.abs(x) > c).mean()
+                assert abs(got - p) < 4.5 * np.sqrt(p / n), (c, got, p)
+    lim = 4.5 / np.sqrt(n)
+    for k in range(T - 1):
+        assert abs(np.corrcoef(z[k, :, 0], z[k, :, 1])[0, 1]) < lim                        # the two axes
+        assert abs(np.corrcoef(z[k, :-1, 0], z[k, 1:, 0])[0, 1]) < lim                     # neighbouring envs
+    for k in range(T - 2):
+        assert abs(np.corrcoef(z[k, :, 0], z[k + 1, :, 0])[0, 1]) < lim                    # consecutive steps
+        assert abs(np.corrcoef(z[k, :, 1], z[k + 1, :, 1])[0, 1]) < lim
+    env.check_status()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # auto-reset = reset() on the SAME env object (RL/MR_ddpg.py:270; MR_env.py:181-183)
 # ----------------------------------------------------------------------------------------------------------------------

@@ -102,3 +102,42 @@ def test_auto_reset_draws_sit_at_the_first_step_of_the_episode_that_ends():
             first[i] = k + 1
             checked += 1
     assert checked > 5 * n
+
+
+def test_auto_reset_positions_are_uniform_and_uncorrelated():
+    """The start positions of auto-resets (keyed by the first step of the episode that ends): uniform over the init box
+    (chi-square on a 10 x 10 grid), uncorrelated between consecutive episodes of an env, between neighbouring envs in the same
+    step, and with the length of the episode that ended."""
+    from mr_rl_amd import MRConfig
+    from tests.util import orc_params_from_cfg
+    n, seed = 4096, 5
+    cfg = MRConfig(noise_var=1.0, auto_reset=True, reward_mode="goal", min_dist2goal=5.0, seed=seed)
+    tab = np.random.default_rng(2).uniform(104, 116, (3, 52, 2)).astype(np.float32)
+    v = O.VecOracle(n, orc_params_from_cfg(cfg, 3, 52), seed=seed, goal_table=tab, threads=8)
+    v.reset(0)
+    pos, prev, pairs, lens, neigh = [], {}, [], [], []
+    for k in range(1, 121):
+        v.step(v.random_policy(k, cfg.policy_low, cfg.policy_high), step_idx=k)
+        d = np.nonzero(v.done)[0]
+        xy = v.envs["y"][d].copy()
+        pos.append(xy); lens.append(v.final_len[d].astype(np.float64))
+        both = d[:-1][np.diff(d) == 1]                              # env i and i + 1 reset in the same step
+        neigh.append(np.stack([v.envs["y"][both, 0], v.envs["y"][both + 1, 0]], 1))
+        for i, p in zip(d, xy):
+            if i in prev:
+                pairs.append((prev[i][0], p[0], prev[i][1], p[1]))
+            prev[i] = p
+    pos, lens, pairs, neigh = np.concatenate(pos), np.concatenate(lens), np.asarray(pairs), np.concatenate(neigh)
+    assert len(pos) > 40000 and len(pairs) > 30000 and len(neigh) > 2000
+    u = (pos - 100.0) / 20.0
+    assert u.min() >= 0 and u.max() <= 1
+    h, _, _ = np.histogram2d(u[:, 0], u[:, 1], bins=10, range=[[0, 1], [0, 1]])
+    chi2 = ((h - len(u) / 100) ** 2 / (len(u) / 100)).sum()
+    assert st.chi2.sf(chi2, 99) > 1e-4, chi2
+    lim = lambda m: 4.5 / np.sqrt(m)  # noqa: E731
+    assert abs(np.corrcoef(pairs[:, 0], pairs[:, 1])[0, 1]) < lim(len(pairs))      # x of consecutive episodes of an env
+    assert abs(np.corrcoef(pairs[:, 2], pairs[:, 3])[0, 1]) < lim(len(pairs))      # y
+    assert abs(np.corrcoef(pairs[:, 0], pairs[:, 3])[0, 1]) < lim(len(pairs))      # x then y
+    assert abs(np.corrcoef(pos[:, 0], pos[:, 1])[0, 1]) < lim(len(pos))            # x and y of one reset
+    assert abs(np.corrcoef(neigh[:, 0], neigh[:, 1])[0, 1]) < lim(len(neigh))      # neighbouring envs, same step
+    assert abs(np.corrcoef(pos[:, 0], lens)[0, 1]) < lim(len(pos))                 # position vs length of the ended episode
