@@ -31,6 +31,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's fields:
   cpu_baseline  the oracle (C restatement) on this box's host cores.
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -407,6 +408,8 @@ class RolloutRegion:
         # once and reused; build the ones this region needs before the clock starts, as any steady loop has them already
         # (a 20-step region would otherwise spend half its wall time building two structs it uses once)
         self.col.prime(self.schedule(nsteps))
+        gc_was_on = gc.isenabled()
+        gc.disable()         # no collector pause inside the region (a 20-step region is ~80 us of wall time)
         self.barrier()
         l0 = self.launches
         t0 = time.perf_counter()
@@ -418,6 +421,8 @@ class RolloutRegion:
         if self.world > 1:
             self.barrier()   # one rank: the synchronize above IS the closing barrier + synchronize (a second device-wide
         el = time.perf_counter() - t0   # synchronize on the idle GPU costs ~10 us: a fifth of a 20-step region's GPU work)
+        if gc_was_on:
+            gc.enable()
         # where this rank's wall time went: host enqueue (launch argument blocks, event records, collectives), waiting for
         # the GPU, closing barrier -- a region of one short launch group is mostly the first and the last
         self.last_phases_us = {"enqueue": round((t1 - t0) * 1e6, 1), "wait_gpu": round((t2 - t1) * 1e6, 1),
@@ -809,6 +814,7 @@ def main():
         per_rank_s = reg.last_per_rank_s
     else:
         l0 = n_launches[0]
+        gc.disable()
         t0 = time.perf_counter()
         run(K)
         gatherer.finish()
@@ -816,6 +822,7 @@ def main():
         if world > 1:
             barrier()    # (one rank: the synchronize above closes the region)
         el = time.perf_counter() - t0
+        gc.enable()
         launches = n_launches[0] - l0
         per_rank_s = [el]
         if world > 1:
