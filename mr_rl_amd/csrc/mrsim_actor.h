@@ -65,16 +65,27 @@ static_assert(kActF32Floats % 4 == 0 && kActBlobFloats % 4 == 0, "blob is copied
 // layer-2 operands, then the bf16 section (27 KiB instead of 43).
 template <int MODE> struct ActLds;
 template <> struct ActLds<kActF32> {
-    static constexpr int A1 = kActA1, A2 = kActA2, C1 = kActC1, C2 = kActC2, W3 = kActW3, Tail = kActTail, A2bf = 0,
+    static constexpr int A1 = kActA1, A1bf = 0, A2 = kActA2, C1 = kActC1, C2 = kActC2, W3 = kActW3, Tail = kActTail, A2bf = 0,
                          Floats = kActF32Floats;
 };
 template <> struct ActLds<kActBf16x3> {
-    static constexpr int A1 = 0, A2 = 0, C1 = kActA2, C2 = C1 + 64, W3 = C2 + 64, Tail = W3 + 128, A2bf = Tail + 8,
+    static constexpr int A1 = 0, A1bf = 0, A2 = 0, C1 = kActA2, C2 = C1 + 64, W3 = C2 + 64, Tail = W3 + 128, A2bf = Tail + 8,
                          Floats = A2bf + kActA2bfFloats;
 };
-template <> struct ActLds<kActBf16> : ActLds<kActBf16x3> {};
+// plain bf16: layer 1 runs on the bf16 matrix cores as well (below), so its A operands are a bf16 image built while staging
+// (512 floats: [rt 2][lane 64][8 bf16]) in place of the 384 floats of f32 operands
+template <> struct ActLds<kActBf16> {
+    static constexpr int A1 = 0, A1bf = 0, A2 = 0, C1 = 512, C2 = C1 + 64, W3 = C2 + 64, Tail = W3 + 128, A2bf = Tail + 8,
+                         Floats = A2bf + kActA2bfFloats;
+};
+static_assert(ActLds<kActBf16>::A2bf % 4 == 0, "ds_read_b128 alignment");
+// Layer 1 of the plain-bf16 arithmetic: ONE v_mfma_f32_32x32x16_bf16 per (row tile, column tile) instead of three f32 MFMAs.
+// Its 16 k-slots hold the five inputs as three bf16 terms each (hi, mid, lo: the input keeps its 24 bits) against the bf16-rounded
+// weight of that input, repeated per term:  slot -> input  0 1 2 3 4 4 0 1 | 2 3 4 - 0 1 2 3   (terms: hi x5, lo of 4, mid 0 1 |
+// mid 2 3 4, -, lo 0 1 2 3).  128 matrix cycles per wave and step instead of 768.
+__host__ __device__ constexpr int act_l1_slot_input(int slot) { return (int)((0x3210F43210443210ull >> (4 * slot)) & 15ull); }  // 15: empty
 template <> struct ActLds<kActOff> {
-    static constexpr int A1 = 0, A2 = 0, C1 = 0, C2 = 0, W3 = 0, Tail = 0, A2bf = 0, Floats = 4;
+    static constexpr int A1 = 0, A1bf = 0, A2 = 0, C1 = 0, C2 = 0, W3 = 0, Tail = 0, A2bf = 0, Floats = 4;
 };
 
 __host__ __device__ constexpr int act_kperm(int q, int h) { return 32 * (q / 16) + 8 * ((q % 16) / 4) + 4 * h + (q % 4); }
@@ -95,8 +106,28 @@ __device__ __forceinline__ void actor_stage_blob(const float* __restrict__ blob,
     using L = ActLds<MODE>;
     if constexpr (MODE == kActF32) {
         act_copy4(blob, s_blob, kActF32Floats, tid, nthreads);
-    } else if constexpr (MODE == kActBf16x3 || MODE == kActBf16) {
+    } else if constexpr (MODE == kActBf16x3) {
         act_copy4(blob + kActA1, s_blob + L::A1, kActA2 - kActA1, tid, nthreads);             // layer-1 operands
+        act_copy4(blob + kActC1, s_blob + L::C1, kActF32Floats - kActC1, tid, nthreads);      // biases, output layer, tail
+        act_copy4(blob + kActA2bf, s_blob + L::A2bf, kActA2bfFloats, tid, nthreads);          // layer-2 bf16 terms
+    } else if constexpr (MODE == kActBf16) {
+        // layer-1 A operands, rounded to bf16 here (v_cvt_pk_bf16_f32: nearest even, as the host rounds the layer-2 terms):
+        // lane (j, h) of row tile rt holds W1'[32 rt + j][input of slot 8 h + jj], jj = 0..7; one dword = two slots.
+        // W1'[f][i] sits in the f32 section at [rt][s = i / 2][lane = (f & 31) + 32 (i & 1)].
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        uint32_t* __restrict__ a1 = reinterpret_cast<uint32_t*>(s_blob + L::A1bf);
+        for (unsigned d = tid; d < 2u * 64u * 4u; d += nthreads) {
+            const unsigned rt = d >> 8, lane = (d >> 2) & 63u, pair = d & 3u;
+            f2 w;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = act_l1_slot_input((int)(8u * (lane >> 5) + 2u * pair) + e);
+                w[e] = i == 15 ? 0.0f : blob[kActA1 + (rt * 3 + (unsigned)(i >> 1)) * 64 + (lane & 31u) + 32u * (unsigned)(i & 1)];
+            }
+            const bf2 t = __builtin_convertvector(w, bf2);
+            a1[d] = __builtin_bit_cast(uint32_t, t);
+        }
         act_copy4(blob + kActC1, s_blob + L::C1, kActF32Floats - kActC1, tid, nthreads);      // biases, output layer, tail
         act_copy4(blob + kActA2bf, s_blob + L::A2bf, kActA2bfFloats, tid, nthreads);          // layer-2 bf16 terms
     }
@@ -182,20 +213,44 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
     // layer-1 B operands: at k-step s lane (j, h) of column tile ct supplies obs[2 s + h] of env 32 ct + j.  One half swap
     // per k-step pair turns "lane = env" registers into both tiles' operands: {x[2s].lo | x[2s+1].lo}, {x[2s].hi | x[2s+1].hi}.
     float b1op[2][3];
+    uint32_t b1bf[2][4];   // plain bf16: the 16 k-slots of one column tile's B operand (two bf16 per register)
+    if constexpr (MODE != kActBf16) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const float va = obs[2 * s];
-        const float vb = (2 * s + 1 < 5) ? obs[2 * s + 1] : 0.0f;
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
-        b1op[0][s] = __uint_as_float(r[0]);
-        b1op[1][s] = __uint_as_float(r[1]);
+        for (int s = 0; s < 3; ++s) {
+            const float va = obs[2 * s];
+            const float vb = (2 * s + 1 < 5) ? obs[2 * s + 1] : 0.0f;
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+            b1op[0][s] = __uint_as_float(r[0]);
+            b1op[1][s] = __uint_as_float(r[1]);
+        }
+    } else {
+        // this env's five inputs as three bf16 terms each, laid into the slots of act_l1_slot_input: lane half 0 supplies
+        // slots 0..7 = {hi0 hi1 | hi2 hi3 | hi4 lo4 | mid0 mid1}, half 1 slots 8..15 = {mid2 mid3 | mid4 0 | lo0 lo1 | lo2 lo3};
+        // one half swap per register turns "lane = env" into both column tiles' operands, as above
+        act_bf16x2 t01[3], t23[3], t4[3];
+        act_split3(obs[0], obs[1], t01);
+        act_split3(obs[2], obs[3], t23);
+        act_split3(obs[4], 0.0f, t4);
+        auto u = [](const act_bf16x2& v) { return __builtin_bit_cast(uint32_t, v); };
+        const uint32_t p0[4] = {u(t01[0]), u(t23[0]), u(t4[0]) | (u(t4[2]) << 16), u(t01[1])};
+        const uint32_t p1[4] = {u(t23[1]), u(t4[1]), u(t01[2]), u(t23[2])};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const auto r = __builtin_amdgcn_permlane32_swap(p0[d], p1[d], false, false);
+            b1bf[0][d] = r[0];
+            b1bf[1][d] = r[1];
+        }
     }
     // The two column tiles one after the other, as a real loop: unrolled, the scheduler interleaves them and keeps all
     // eight 16-register accumulators live (313 registers, one wave per SIMD); rolled, a tile needs four of them.
     float part[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma nounroll
     for (int ct = 0; ct < 2; ++ct) {
-        const float bop[3] = {ct ? b1op[1][0] : b1op[0][0], ct ? b1op[1][1] : b1op[0][1], ct ? b1op[1][2] : b1op[0][2]};
+        float bop[3] = {0.f, 0.f, 0.f};
+        if constexpr (MODE != kActBf16) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) bop[s] = ct ? b1op[1][s] : b1op[0][s];
+        }
         // Every LDS address below derives from a lane id that is opaque per iteration.  Otherwise the parameter reads -- the
         // same for both tiles and for every time step of a fused rollout -- are hoisted out of all loops and 260 registers
         // of weights and bias tiles stay live across the env step (measured: 313 registers, one wave per SIMD, or spills).
@@ -203,12 +258,25 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
         asm volatile("" : "+v"(lane));
         const unsigned h = lane >> 5;
         act_f32x16 acc1[2], acc2[2];
+        if constexpr (MODE != kActBf16) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            lds_load16(sA + L::C1 + h * 32 + rt * 16, acc1[rt]);
+            for (int rt = 0; rt < 2; ++rt) {
+                lds_load16(sA + L::C1 + h * 32 + rt * 16, acc1[rt]);
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
-                acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[L::A1 + (rt * 3 + s) * 64 + lane], bop[s], acc1[rt], 0, 0, 0);
+                for (int s = 0; s < 3; ++s)
+                    acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[L::A1 + (rt * 3 + s) * 64 + lane], bop[s], acc1[rt], 0, 0, 0);
+            }
+        } else {
+            typedef uint32_t act_u32x4 __attribute__((ext_vector_type(4)));
+            const act_u32x4 bw = {ct ? b1bf[1][0] : b1bf[0][0], ct ? b1bf[1][1] : b1bf[0][1], ct ? b1bf[1][2] : b1bf[0][2],
+                                  ct ? b1bf[1][3] : b1bf[0][3]};
+            const act_bf16x8 bp1 = __builtin_bit_cast(act_bf16x8, bw);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                lds_load16(sA + L::C1 + h * 32 + rt * 16, acc1[rt]);
+                const act_bf16x8 ap1 = *reinterpret_cast<const act_bf16x8*>(sA + L::A1bf + (rt * 64 + lane) * 4);
+                acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap1, bp1, acc1[rt], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) lds_load16(sA + L::C2 + h * 32 + rt * 16, acc2[rt]);

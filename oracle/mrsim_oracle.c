@@ -544,6 +544,22 @@ void orc_actor_prepare(OrcActor* a) {
 /* ActorNetwork.predict (RL/MR_ddpg.py:145-148) -> scaled_out (:136-137) */
 void orc_actor_forward(const OrcActor* a, const float obs[5], float act[2]) {
     float h1[64], h2[64];
+    if (a->math == 2) {
+        /* plain bf16: layer 1 is ONE v_mfma_f32_32x32x16_bf16 per tile -- the five inputs as three bf16 terms each (their sum is
+         * the input, exactly) against the bf16-rounded weight, 15 exact products and the bias summed and rounded once */
+        double x[5];
+        for (int k = 0; k < 5; ++k) {
+            float t[3];
+            bf16_split3(obs[k], t);
+            x[k] = ((double)t[0] + (double)t[1]) + (double)t[2];
+        }
+        for (int f = 0; f < 64; ++f) {
+            double sum = 0.0;
+            for (int k = 0; k < 5; ++k) sum += (double)bf16_round(a->w1[f * 5 + k]) * x[k];
+            const float acc = (float)((double)a->b1[f] + sum);
+            h1[f] = acc > 0.0f ? acc : 0.0f;
+        }
+    } else
     for (int f = 0; f < 64; ++f) {                              /* fully_connected 64 + batch norm (folded), relu  :122-124 */
         float acc = a->b1[f];
         for (int k = 0; k < 5; ++k) acc = fmaf(a->w1[f * 5 + k], obs[k], acc);

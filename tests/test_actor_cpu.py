@@ -180,9 +180,15 @@ def test_oracle_bf16_arithmetics_against_a_numpy_emulation():
             r = (r - t[-1]).astype(np.float32)
         return t
 
+    # plain bf16: layer 1 on the bf16 matrix cores too -- bf16-rounded weights against the inputs' exact three-term splits,
+    # all 15 products and the bias in ONE instruction: summed exactly, rounded once
+    xs = split(obs, 3)
+    assert np.array_equal((xs[0].astype(np.float64) + xs[1]) + xs[2], obs.astype(np.float64))      # the split loses nothing
+    h1_bf = np.maximum((w["b1"].astype(np.float64)[None, :] + obs.astype(np.float64) @ _bf16(w1).astype(np.float64).T)
+                       .astype(np.float32), 0)
     want = {}
     for math_name, pairs in (("bf16x3", [(2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]), ("bf16", [(0, 0)])):
-        ws, hs = split(w["w2"], 3), split(h1, 3)
+        ws, hs = split(w["w2"], 3), split(h1_bf if math_name == "bf16" else h1, 3)
         acc = np.tile(w["b2"].astype(np.float32), (len(obs), 1))
         for s in range(4):
             ks = [kperm(8 * s + jj, h) for h in range(2) for jj in range(8)]
