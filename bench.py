@@ -592,7 +592,7 @@ def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event
         for p in pool_v:
             p.close()
         avg_v, med_v = stats_us(ms_v)
-        exec_flops = waves * ep * (mfma_bf16_per_wave_step * 32 * 32 * 16 * 2 + 12 * 32 * 32 * 2 * 2)
+        exec_flops = waves * ep * mfma_bf16_per_wave_step * 32 * 32 * 16 * 2     # both hidden layers run on the bf16 matrix cores
         return {"what": what, "value": n_local * ep * episodes / el_v, "unit": "env-steps/s", "ms_per_step": el_v / (episodes * ep) * 1e3,
                 "one_stream_with_events": {"value": n_local * ep * event_episodes / el1_v, "avg_kernel_us": round(avg_v, 2),
                                            "median_kernel_us": round(med_v, 2)},
@@ -600,14 +600,14 @@ def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event
                              "unit": "TFLOP/s", "frac": round(exec_flops / (avg_v * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                              "traffic": None, "note": bound_note,
                              "algorithmic_actor_TFLOPs": round(n_local * ep * ACTOR_FLOP_PER_ENV_STEP / (avg_v * 1e-6) / 1e12, 1)}}
-    note = ("EXECUTED matrix flops (%d bf16 MFMAs of 32x32x16 + 12 f32 MFMAs per wave and step) / kernel duration against the dense "
+    note = ("EXECUTED matrix flops (%d bf16 MFMAs of 32x32x16 per wave and step, layer 1 included) / kernel duration against the dense "
             "bf16 MFMA peak; the kernel is bound by vector-instruction issue at the package power cap (operand conversion, ReLU, the "
             "output layer, the env step), not by the matrix pipe")
-    bf16x3 = variant("bf16x3", 96, "the same with MrsimActor.math = BF16X3: every f32 operand of the 64 x 64 layer as three bf16 terms, "
+    bf16x3 = variant("bf16x3", 104, "the same with MrsimActor.math = BF16X3: every f32 operand of the two hidden layers as three bf16 terms, "
                      "the six products above 2^-24 on v_mfma_f32_32x32x16_bf16 with f32 accumulation (within 5e-6 of the action bound of "
-                     "the f32 result; tests/test_gpu_actor.py) -- the matrix cores proper, which run beside the vector unit", note % 96)
-    bf16 = variant("bf16", 16, "the same with MrsimActor.math = BF16: plain bf16 operands, f32 accumulation -- ordinary bf16 inference "
-                   "(bitwise equal to the oracle's bf16 emulation up to accumulation order; tests/test_gpu_actor.py bounds the action's distance from the f32 result at 6e-2 of its bound): exploration-grade collection", note % 16)
+                     "the f32 result; tests/test_gpu_actor.py) -- the matrix cores proper, which run beside the vector unit", note % 104)
+    bf16 = variant("bf16", 20, "the same with MrsimActor.math = BF16: plain bf16 operands, f32 accumulation -- ordinary bf16 inference "
+                   "(bitwise equal to the oracle's bf16 emulation up to accumulation order; tests/test_gpu_actor.py bounds the action's distance from the f32 result at 6e-2 of its bound): exploration-grade collection", note % 20)
     return {"bf16x3": bf16x3, "bf16": bf16, "what": "BASELINE config 4 with the reference's DDPG actor (5-64-64-2, eval-mode batch norm folded, tanh x bound) "
                     "+ OU noise as the policy, evaluated INSIDE the fused rollout kernel on each step's observation "
                     "(RL/MR_ddpg.py:277-278 without leaving the registers); random-initialised weights, every transition written",

@@ -128,7 +128,7 @@ typedef struct MrsimState {
  * --------------------------------------------------------------------------------------------------------- */
 #define MRSIM_ACTOR_HIDDEN 64
 #define MRSIM_ACTOR_BLOB_FLOATS 10888  /* size of the packed parameter block (f32 section 4744 + bf16x3 section 6144) */
-/* Arithmetic of the 64 x 64 layer (MrsimActor.math).  F32: exact f32 products on v_mfma_f32_32x32x2_f32, bit-for-bit an
+/* Arithmetic of the two hidden layers (MrsimActor.math).  F32: exact f32 products on v_mfma_f32_32x32x2_f32, bit-for-bit an
  * fmaf chain in the documented order.  BF16X3: every f32 operand as the sum of three bf16 terms, the six products above
  * 2^-24 on v_mfma_f32_32x32x16_bf16 with f32 accumulation -- f32-class accuracy (within 5e-6 of the action bound of the F32
  * result in the tests) on the matrix cores proper, which run beside the vector unit; about 1.5 x the collection rate. */

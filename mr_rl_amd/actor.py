@@ -79,11 +79,11 @@ class DeviceActor:
     MATH = {"f32": _lib.ACTOR_F32, "bf16x3": _lib.ACTOR_BF16X3, "bf16": _lib.ACTOR_BF16}
 
     def __init__(self, weights, device="cuda", ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False, math="f32"):
-        """math: arithmetic of the 64 x 64 layer.  "f32" (default) = exact f32 MFMA, bit-for-bit the documented fmaf chain;
+        """math: arithmetic of the two hidden layers.  "f32" (default) = exact f32 MFMA, bit-for-bit the documented fmaf chain;
         "bf16x3" = every f32 operand as three bf16 terms, six bf16 MFMAs with f32 accumulation: f32-class accuracy (within
         5e-6 of the action bound of the f32 result; tests/test_gpu_actor.py), about 1.5 x the collection rate; "bf16" = plain
         bf16 operands, ordinary bf16 inference (the action within 4e-5 of its bound of the f32 result with the reference's
-        U[-3e-3, 3e-3] output layer, up to 3e-2 at output gains of 20-40 x), about 3 x: exploration-grade collection."""
+        U[-3e-3, 3e-3] output layer, up to 3e-2 at output gains of 20-40 x), about 3.4 x: exploration-grade collection."""
         import torch
         if math not in self.MATH:
             raise ValueError("math must be 'f32', 'bf16x3' or 'bf16'")

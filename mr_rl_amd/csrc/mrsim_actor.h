@@ -33,7 +33,8 @@
 namespace mrsim {
 
 constexpr int kActHidden = 64;
-// Arithmetic of the 64 x 64 layer (MrsimActor.math):
+// Arithmetic of the two hidden layers (MrsimActor.math; in the bf16 arithmetics layer 1 runs on the bf16 matrix cores as well,
+// see act_l1_slot_input / act_l1x3_slot_input below):
 //   kActF32     exact f32 on v_mfma_f32_32x32x2_f32 (the definition above; bitwise against the oracle).  On gfx950 this
 //               instruction runs at the f32 VECTOR rate and -- measured -- does not overlap the vector unit's own work: the
 //               fused rollout takes (MFMA cycles + VALU cycles).
@@ -68,10 +69,11 @@ template <> struct ActLds<kActF32> {
     static constexpr int A1 = kActA1, A1bf = 0, A2 = kActA2, C1 = kActC1, C2 = kActC2, W3 = kActW3, Tail = kActTail, A2bf = 0,
                          Floats = kActF32Floats;
 };
-template <> struct ActLds<kActBf16x3> {
-    static constexpr int A1 = 0, A1bf = 0, A2 = 0, C1 = kActA2, C2 = C1 + 64, W3 = C2 + 64, Tail = W3 + 128, A2bf = Tail + 8,
+template <> struct ActLds<kActBf16x3> {   // A1bf: [m 2][rt 2][lane 64][8 bf16], the layer-1 operands of its two MFMAs per tile (below)
+    static constexpr int A1 = 0, A1bf = 0, A2 = 0, C1 = 1024, C2 = C1 + 64, W3 = C2 + 64, Tail = W3 + 128, A2bf = Tail + 8,
                          Floats = A2bf + kActA2bfFloats;
 };
+static_assert(ActLds<kActBf16x3>::A2bf % 4 == 0, "ds_read_b128 alignment");
 // plain bf16: layer 1 runs on the bf16 matrix cores as well (below), so its A operands are a bf16 image built while staging
 // (512 floats: [rt 2][lane 64][8 bf16]) in place of the 384 floats of f32 operands
 template <> struct ActLds<kActBf16> {
@@ -84,6 +86,14 @@ static_assert(ActLds<kActBf16>::A2bf % 4 == 0, "ds_read_b128 alignment");
 // weight of that input, repeated per term:  slot -> input  0 1 2 3 4 4 0 1 | 2 3 4 - 0 1 2 3   (terms: hi x5, lo of 4, mid 0 1 |
 // mid 2 3 4, -, lo 0 1 2 3).  128 matrix cycles per wave and step instead of 768.
 __host__ __device__ constexpr int act_l1_slot_input(int slot) { return (int)((0x3210F43210443210ull >> (4 * slot)) & 15ull); }  // 15: empty
+// Layer 1 of the bf16 x 3 arithmetic: weights AND inputs as three bf16 terms, the six products above 2^-24 of each of the five
+// inputs = 30 slots = TWO v_mfma_f32_32x32x16_bf16 per tile (256 matrix cycles per wave and step instead of 768), small terms first:
+//   MFMA 1 (2^-16 terms)  slots 0-3 w1 x3 | 4-7 w2 x2 | 8-11 w3 x1 | 12-14 input 4: w1 x3, w2 x2, w3 x1 | 15 empty      (inputs 0..3 in 0-11)
+//   MFMA 0                slots 0-3 w1 x1 | 4-7 w1 x2 | 8-11 w2 x1 | 12-14 input 4: w1 x1, w1 x2, w2 x1 | 15 empty
+__host__ __device__ constexpr int act_l1x3_slot_input(int slot) { return (int)((0xF444321032103210ull >> (4 * slot)) & 15ull); }
+__host__ __device__ constexpr int act_l1x3_slot_wterm(int m, int slot) {   // 0-based term of the weight in MFMA m's slot
+    return (int)(((m ? 0x0210222211110000ull : 0x0100111100000000ull) >> (4 * slot)) & 15ull);
+}
 template <> struct ActLds<kActOff> {
     static constexpr int A1 = 0, A1bf = 0, A2 = 0, C1 = 0, C2 = 0, W3 = 0, Tail = 0, A2bf = 0, Floats = 4;
 };
@@ -107,7 +117,32 @@ __device__ __forceinline__ void actor_stage_blob(const float* __restrict__ blob,
     if constexpr (MODE == kActF32) {
         act_copy4(blob, s_blob, kActF32Floats, tid, nthreads);
     } else if constexpr (MODE == kActBf16x3) {
-        act_copy4(blob + kActA1, s_blob + L::A1, kActA2 - kActA1, tid, nthreads);             // layer-1 operands
+        // layer-1 A operands of the two MFMAs per tile: the bf16 terms of W1' (split here, as act_split3 splits the inputs)
+        uint32_t* __restrict__ a1 = reinterpret_cast<uint32_t*>(s_blob + L::A1bf);
+        for (unsigned d = tid; d < 2u * 2u * 64u * 4u; d += nthreads) {
+            const unsigned m = d >> 9, rt = (d >> 8) & 1u, lane = (d >> 2) & 63u, pair = d & 3u;
+            float w[2];
+            int term[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int slot = (int)(8u * (lane >> 5) + 2u * pair) + e;
+                const int i = act_l1x3_slot_input(slot);
+                term[e] = act_l1x3_slot_wterm((int)m, slot);
+                w[e] = i == 15 ? 0.0f : blob[kActA1 + (rt * 3 + (unsigned)(i >> 1)) * 64 + (lane & 31u) + 32u * (unsigned)(i & 1)];
+            }
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 v = {w[0], w[1]};
+            const bf2 t0 = __builtin_convertvector(v, bf2);
+            const f2 r1 = v - __builtin_convertvector(t0, f2);
+            const bf2 t1 = __builtin_convertvector(r1, bf2);
+            const f2 r2 = r1 - __builtin_convertvector(t1, f2);
+            const bf2 t2 = __builtin_convertvector(r2, bf2);
+            bf2 o;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) o[e] = term[e] == 0 ? t0[e] : (term[e] == 1 ? t1[e] : t2[e]);
+            a1[d] = __builtin_bit_cast(uint32_t, o);
+        }
         act_copy4(blob + kActC1, s_blob + L::C1, kActF32Floats - kActC1, tid, nthreads);      // biases, output layer, tail
         act_copy4(blob + kActA2bf, s_blob + L::A2bf, kActA2bfFloats, tid, nthreads);          // layer-2 bf16 terms
     } else if constexpr (MODE == kActBf16) {
@@ -214,7 +249,28 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
     // per k-step pair turns "lane = env" registers into both tiles' operands: {x[2s].lo | x[2s+1].lo}, {x[2s].hi | x[2s+1].hi}.
     float b1op[2][3];
     uint32_t b1bf[2][4];   // plain bf16: the 16 k-slots of one column tile's B operand (two bf16 per register)
-    if constexpr (MODE != kActBf16) {
+    uint32_t b1x3[2][2][4];  // bf16 x 3: [MFMA m][column tile][register]
+    if constexpr (MODE == kActBf16x3) {
+        // slots of MFMA 0:  half 0 {x1_0 x1_1 | x1_2 x1_3 | x2_0 x2_1 | x2_2 x2_3}   half 1 {x1_0 x1_1 | x1_2 x1_3 | x1_4 x2_4 | x1_4 0}
+        //          MFMA 1:  half 0 {x3_0 x3_1 | x3_2 x3_3 | x2_0 x2_1 | x2_2 x2_3}   half 1 {x1_0 x1_1 | x1_2 x1_3 | x3_4 x2_4 | x1_4 0}
+        act_bf16x2 t01[3], t23[3], t4[3];
+        act_split3(obs[0], obs[1], t01);
+        act_split3(obs[2], obs[3], t23);
+        act_split3(obs[4], 0.0f, t4);
+        auto u = [](const act_bf16x2& v) { return __builtin_bit_cast(uint32_t, v); };
+        const uint32_t p0[2][4] = {{u(t01[0]), u(t23[0]), u(t01[1]), u(t23[1])}, {u(t01[2]), u(t23[2]), u(t01[1]), u(t23[1])}};
+        const uint32_t p1[2][4] = {{u(t01[0]), u(t23[0]), u(t4[0]) | (u(t4[1]) << 16), u(t4[0])},
+                                   {u(t01[0]), u(t23[0]), u(t4[2]) | (u(t4[1]) << 16), u(t4[0])}};
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const auto r = __builtin_amdgcn_permlane32_swap(p0[m][d], p1[m][d], false, false);
+                b1x3[m][0][d] = r[0];
+                b1x3[m][1][d] = r[1];
+            }
+        }
+    } else if constexpr (MODE != kActBf16) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const float va = obs[2 * s];
@@ -247,7 +303,7 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
 #pragma nounroll
     for (int ct = 0; ct < 2; ++ct) {
         float bop[3] = {0.f, 0.f, 0.f};
-        if constexpr (MODE != kActBf16) {
+        if constexpr (MODE == kActF32) {
 #pragma unroll
             for (int s = 0; s < 3; ++s) bop[s] = ct ? b1op[1][s] : b1op[0][s];
         }
@@ -258,7 +314,8 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
         asm volatile("" : "+v"(lane));
         const unsigned h = lane >> 5;
         act_f32x16 acc1[2], acc2[2];
-        if constexpr (MODE != kActBf16) {
+        typedef uint32_t act_u32x4 __attribute__((ext_vector_type(4)));
+        if constexpr (MODE == kActF32) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 lds_load16(sA + L::C1 + h * 32 + rt * 16, acc1[rt]);
@@ -266,8 +323,24 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
                 for (int s = 0; s < 3; ++s)
                     acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[L::A1 + (rt * 3 + s) * 64 + lane], bop[s], acc1[rt], 0, 0, 0);
             }
+        } else if constexpr (MODE == kActBf16x3) {
+            act_bf16x8 bpm[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const act_u32x4 bw = {ct ? b1x3[m][1][0] : b1x3[m][0][0], ct ? b1x3[m][1][1] : b1x3[m][0][1],
+                                      ct ? b1x3[m][1][2] : b1x3[m][0][2], ct ? b1x3[m][1][3] : b1x3[m][0][3]};
+                bpm[m] = __builtin_bit_cast(act_bf16x8, bw);
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                lds_load16(sA + L::C1 + h * 32 + rt * 16, acc1[rt]);
+#pragma unroll
+                for (int m = 1; m >= 0; --m) {   // the 2^-16 terms first
+                    const act_bf16x8 ap1 = *reinterpret_cast<const act_bf16x8*>(sA + L::A1bf + ((m * 2 + rt) * 64 + lane) * 4);
+                    acc1[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap1, bpm[m], acc1[rt], 0, 0, 0);
+                }
+            }
         } else {
-            typedef uint32_t act_u32x4 __attribute__((ext_vector_type(4)));
             const act_u32x4 bw = {ct ? b1bf[1][0] : b1bf[0][0], ct ? b1bf[1][1] : b1bf[0][1], ct ? b1bf[1][2] : b1bf[0][2],
                                   ct ? b1bf[1][3] : b1bf[0][3]};
             const act_bf16x8 bp1 = __builtin_bit_cast(act_bf16x8, bw);

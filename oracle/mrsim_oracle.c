@@ -539,6 +539,7 @@ static void bf16_split3(float x, float t[3]) {
 /* fills OrcActor.w2_split from w2 (call after setting the weights, before math = 1 evaluations) */
 void orc_actor_prepare(OrcActor* a) {
     for (int i = 0; i < 64 * 64; ++i) bf16_split3(a->w2[i], a->w2_split + 3 * i);
+    for (int i = 0; i < 64 * 5; ++i) bf16_split3(a->w1[i], a->w1_split + 3 * i);
 }
 
 /* ActorNetwork.predict (RL/MR_ddpg.py:145-148) -> scaled_out (:136-137) */
@@ -557,6 +558,22 @@ void orc_actor_forward(const OrcActor* a, const float obs[5], float act[2]) {
             double sum = 0.0;
             for (int k = 0; k < 5; ++k) sum += (double)bf16_round(a->w1[f * 5 + k]) * x[k];
             const float acc = (float)((double)a->b1[f] + sum);
+            h1[f] = acc > 0.0f ? acc : 0.0f;
+        }
+    } else if (a->math == 1) {
+        /* bf16 x 3: weights and inputs as three bf16 terms, the six products above 2^-24 in TWO MFMAs per tile, the 2^-16
+         * terms (w1 x3 + w2 x2 + w3 x1) first; each instruction's products summed exactly and rounded once */
+        float xs[5][3];
+        for (int k = 0; k < 5; ++k) bf16_split3(obs[k], xs[k]);
+        for (int f = 0; f < 64; ++f) {
+            const float* ws = a->w1_split + (size_t)f * 5 * 3;
+            double small = 0.0, big = 0.0;
+            for (int k = 0; k < 5; ++k) {
+                small += (double)ws[k * 3 + 0] * xs[k][2] + (double)ws[k * 3 + 1] * xs[k][1] + (double)ws[k * 3 + 2] * xs[k][0];
+                big += (double)ws[k * 3 + 0] * xs[k][0] + (double)ws[k * 3 + 0] * xs[k][1] + (double)ws[k * 3 + 1] * xs[k][0];
+            }
+            float acc = (float)((double)a->b1[f] + small);
+            acc = (float)((double)acc + big);
             h1[f] = acc > 0.0f ? acc : 0.0f;
         }
     } else

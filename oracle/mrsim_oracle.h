@@ -153,6 +153,7 @@ typedef struct {
                            /*    hardware's internal order is not documented: compared with a 2e-6 tolerance)             */
     int32_t reserved0;
     float w2_split[64 * 64 * 3]; /* [f][k][term]: the bf16 terms of w2, filled by orc_actor_prepare                   */
+    float w1_split[64 * 5 * 3];  /* [f][k][term]: the bf16 terms of w1 (scaled), filled by orc_actor_prepare         */
 } OrcActor;
 void orc_actor_prepare(OrcActor* a);
 float orc_spec_tanhf(float x);

@@ -51,6 +51,7 @@ class OrcActor(C.Structure):
         ("w3", C.c_float * 128), ("b3", C.c_float * 2), ("bound", C.c_float * 2),
         ("ou_theta_dt", C.c_float), ("ou_sigma_sqrt_dt", C.c_float), ("ou_enabled", C.c_int32),
         ("ou_reset_on_done", C.c_int32), ("math", C.c_int32), ("reserved0", C.c_int32), ("w2_split", C.c_float * 12288),
+        ("w1_split", C.c_float * 960),
     ]
 
 

@@ -186,9 +186,16 @@ def test_oracle_bf16_arithmetics_against_a_numpy_emulation():
     assert np.array_equal((xs[0].astype(np.float64) + xs[1]) + xs[2], obs.astype(np.float64))      # the split loses nothing
     h1_bf = np.maximum((w["b1"].astype(np.float64)[None, :] + obs.astype(np.float64) @ _bf16(w1).astype(np.float64).T)
                        .astype(np.float32), 0)
+    # bf16 x 3: layer 1 as two instructions per tile -- w1 x3 + w2 x2 + w3 x1 of all five inputs first, then w1 x1 + w1 x2 + w2 x1
+    wt = split(w1, 3)
+    f64 = lambda a: a.astype(np.float64)  # noqa: E731
+    small = f64(xs[2]) @ f64(wt[0]).T + f64(xs[1]) @ f64(wt[1]).T + f64(xs[0]) @ f64(wt[2]).T
+    big = f64(xs[0]) @ f64(wt[0]).T + f64(xs[1]) @ f64(wt[0]).T + f64(xs[0]) @ f64(wt[1]).T
+    acc = (f64(w["b1"])[None, :] + small).astype(np.float32)
+    h1_x3 = np.maximum((f64(acc) + big).astype(np.float32), 0)
     want = {}
     for math_name, pairs in (("bf16x3", [(2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]), ("bf16", [(0, 0)])):
-        ws, hs = split(w["w2"], 3), split(h1_bf if math_name == "bf16" else h1, 3)
+        ws, hs = split(w["w2"], 3), split(h1_bf if math_name == "bf16" else h1_x3, 3)
         acc = np.tile(w["b2"].astype(np.float32), (len(obs), 1))
         for s in range(4):
             ks = [kperm(8 * s + jj, h) for h in range(2) for jj in range(8)]
