@@ -261,10 +261,10 @@ bdur = bdur[50:]
 cba, _, grid_b, fba = counters("pmc_actor_bf_a", ACTB, 0.0)
 wb = grid_b / 64
 bavg = sum(bdur) / len(bdur)
-exec_flops = wb * T * (96 * 32 * 32 * 16 * 2 + 12 * 32 * 32 * 2 * 2)
+exec_flops = wb * T * 104 * 32 * 32 * 16 * 2     # 96 (64 x 64 layer) + 8 (layer 1) bf16 MFMAs per wave-step
 files["pmc_actor_bf16x3.json"] = json.dumps({
     "what": "the fused actor rollout with MrsimActor.math = BF16X3 (tools/actor_probe.py --math bf16x3): kernel trace durations and SQ "
-            "counters per wave and env step.  executed_mfma_tflops = the flops the 96 bf16 + 12 f32 MFMAs per wave-step execute / "
+            "counters per wave and env step.  executed_mfma_tflops = the flops the 104 bf16 MFMAs per wave-step execute / "
             "duration, against the 2.5 PFLOP/s dense bf16 peak; the kernel is bound by vector-instruction issue (valu_insts minus "
             "mfma_insts per wave-step), not by the matrix pipe",
     **stamp, "kernel": "mr_rollout_actor_fl_kernel<RK45,fast,nominal,DDPG|carry64|actor|OU|bf16x3>, 512-thread blocks", "N": N, "T": T,
