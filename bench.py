@@ -46,11 +46,14 @@ ALGO_BYTES_PER_ENV_STEP = 97   # fp64 positions -> reads 40 + write
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0    # same table: 6.29 TB/s measured (float4 copy, 79 %)
 SIMDS = 1024                   # 256 CUs x 4 SIMDs
-PREROLL_EPISODES = 300         # untimed episodes issued right in front of every secondary timed region: after ANY host-side
+PREROLL_EPISODES = 900         # untimed episodes issued right in front of every secondary timed region: after ANY host-side
                                # pause of a millisecond or more (allocating buffers, creating or reading a thousand events)
                                # the GPU has dropped its clock and needs ~40 ms of load to bring it back (rocprofv3 kernel
                                # trace of this script, profiles/r02/rollout_kernel_by_region.json: 150 us per launch right
-                               # after a pause, 126 us from 300 launches on)
+                               # after a pause, 126 us from 300 launches on).  900, not 300: behind the driver's 20-step region
+                               # (drained queue, 2 ms pause, short burst) 300 episodes left the sustained legs 10 % low --
+                               # 101-104 G against 113-115 G behind 900 or 2000 and behind the default 1000-episode region
+                               # (profiles/r03/NOTES.md)
 
 _T0 = time.perf_counter()
 
