@@ -80,6 +80,51 @@ def test_reset_cache_with_episodes_of_a_few_steps(mis, carry):
     e1.check_status()
 
 
+@pytest.mark.parametrize("case", range(10))
+def test_reset_cache_randomised_tables_and_sizes(case):
+    """The goal-table rollout (reset cache, hoisted row pointer, v_med3 row clamp) on random shapes: K trajectories of T_tab rows
+    (rows shorter and longer than an episode: the row index clamps), episode limits 6-50, goal radius 2-7, ragged env counts,
+    env-id offsets, both laws, launches of random lengths -- every transition bitwise against single steps, dones / lengths /
+    reset rows against the oracle."""
+    from oracle import oracle as O
+    from tests.util import orc_params_from_cfg
+    from mr_rl_amd import MRConfig, MRVecEnv
+    r = np.random.default_rng(1000 + case)
+    n = int(r.choice([1, 63, 64, 65, 257, 777, 1500]))
+    K, Ttab = int(r.choice([1, 2, 3, 5])), int(r.choice([4, 20, 52, 90]))
+    maxT = int(r.choice([6, 17, 50]))
+    mis = bool(r.integers(2))
+    id0 = int(r.choice([0, 12345, 2**31 + 7]))
+    tab = r.uniform(103, 117, (K, Ttab, 2)).astype(np.float32)
+    kw = dict(noise_var=float(r.choice([0.5, 1.0, 2.0])), auto_reset=True, is_mismatched=mis, noise_math="spec", reward_mode="goal",
+              min_dist2goal=float(r.uniform(2, 7)), max_timesteps=maxT, seed=50 + case)
+    e1 = MRVecEnv(n, cfg=MRConfig(**kw), seed=50 + case, env_id0=id0, goal_table=tab)
+    e2 = MRVecEnv(n, cfg=MRConfig(**kw), seed=50 + case, env_id0=id0, goal_table=tab)
+    orc = O.VecOracle(n, orc_params_from_cfg(MRConfig(**kw), K, Ttab), seed=50 + case, env_id0=id0, goal_table=tab, threads=8)
+    e1.reset(); e2.reset(); orc.reset(0)
+    k, ndone = 0, 0
+    for T in [int(x) for x in r.integers(1, 45, size=4)]:
+        out = e1.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
+        obs, rew, done = (out[q].cpu().numpy() for q in ("obs", "rew", "done"))
+        for t in range(T):
+            k += 1
+            orc.step(orc.random_policy(k, kw.get("policy_low", MRConfig().policy_low), MRConfig().policy_high), step_idx=k)
+            o2, r2, d2, _ = e2.step(None)
+            np.testing.assert_array_equal(obs[t].view(np.uint32), o2.cpu().numpy().view(np.uint32), err_msg=f"T={T} t={t}")
+            np.testing.assert_array_equal(rew[t], r2.cpu().numpy())
+            np.testing.assert_array_equal(done[t], d2.cpu().numpy())
+            np.testing.assert_array_equal(done[t].astype(np.uint8), orc.done)
+            np.testing.assert_allclose(obs[t], orc.obs, rtol=0, atol=3e-5)
+            ndone += int(orc.done.sum())
+    np.testing.assert_array_equal(e1.pos.cpu().numpy().view(np.uint64), e2.pos.cpu().numpy().view(np.uint64))
+    np.testing.assert_array_equal(e1.aux.cpu().numpy().view(np.uint32), e2.aux.cpu().numpy().view(np.uint32))
+    np.testing.assert_array_equal(e1.final_len.cpu().numpy(), e2.final_len.cpu().numpy())
+    np.testing.assert_array_equal(e1.final_len.cpu().numpy(), orc.final_len)
+    np.testing.assert_allclose(e1.pos.cpu().numpy(), orc.envs["y"], rtol=0, atol=POS_TOL)
+    assert ndone > 0 or n == 1
+    e1.check_status()
+
+
 def test_auto_reset_key_wraps_when_the_step_index_is_set_back():
     """The draws of an auto-reset sit at step - (length - 1) in 64-bit modular arithmetic (reset_rng / orc_env_step).  Setting
     the step index back in the middle of the episodes makes that difference negative: kernel (borrow across the two 32-bit
