@@ -11,7 +11,7 @@ EXPECTED = ["kt", "kt_s1", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETC
                                              for p in ("pmc_f64", "pmc_f32", "pmc_step", "cal", "cal262k")] + \
            [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")] + \
            ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed",
-            "kt_actor_bf", "pmc_actor_bf_a", "kt_actor_b1"]
+            "kt_actor_bf", "pmc_actor_bf_a", "kt_actor_b1", "pmc_actor_b1_a"]
 
 
 def _tree(tmp_path, status_lines, sha_ok=True):

@@ -37,7 +37,7 @@ EXPECTED = ["kt", "kt_s1", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETC
                                              for p in ("pmc_f64", "pmc_f32", "pmc_step", "cal", "cal262k")] + \
            [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")] + \
            ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed",
-            "kt_actor_bf", "pmc_actor_bf_a", "kt_actor_b1"]
+            "kt_actor_bf", "pmc_actor_bf_a", "kt_actor_b1", "pmc_actor_b1_a"]
 if not os.path.exists(f"{src}/status.txt"):
     die(f"{src}/status.txt not found (did tools/profile_round.sh {tag} run?)")
 status = dict(l.split() for l in open(f"{src}/status.txt").read().splitlines() if l.strip())
@@ -276,6 +276,27 @@ files["pmc_actor_bf16x3.json"] = json.dumps({
     "per_wave_step": {k: round(v / wb / T, 2) for k, v in sorted(cba.items())},
     "source": [prov(ktb), prov(fba)]}, indent=1) + "\n"
 files["kernel_stats_actor_rollout_bf16.csv"] = open(the_csv("kt_actor_b1", "kernel_stats.csv")).read()   # plain bf16 arithmetic
+ACT1 = "mr_rollout_actor_fl_kernel<true, 2, false, 74120325u, 3>"
+kt1 = the_csv("kt_actor_b1", "kernel_trace.csv")
+d1dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt1)) if ACT1 in r["Kernel_Name"]]
+if len(d1dur) < 100:
+    die(f"{kt1}: {len(d1dur)} dispatches of the plain-bf16 actor rollout kernel")
+d1dur = d1dur[50:]
+c1a, _, grid_1, f1a = counters("pmc_actor_b1_a", ACT1, 0.0)
+w1 = grid_1 / 64
+avg1 = sum(d1dur) / len(d1dur)
+flops1 = w1 * T * 20 * 32 * 32 * 16 * 2     # 16 (64 x 64 layer) + 4 (layer 1) bf16 MFMAs per wave-step
+files["pmc_actor_bf16.json"] = json.dumps({
+    "what": "the fused actor rollout with MrsimActor.math = BF16 (tools/actor_probe.py --math bf16): kernel trace durations and SQ "
+            "counters per wave and env step; 20 bf16 MFMAs per wave-step, no f32 MFMA",
+    **stamp, "kernel": "mr_rollout_actor_fl_kernel<RK45,fast,nominal,DDPG|carry64|actor|OU|bf16>, 512-thread blocks", "N": N, "T": T,
+    "avg_kernel_us": round(avg1, 2), "median_kernel_us": round(sorted(d1dur)[len(d1dur) // 2], 2), "dispatches_timed": len(d1dur),
+    "in_kernel_env_steps_per_s": round(N * T / (avg1 * 1e-6), 1),
+    "algorithmic_actor_tflops": round(N * T * FLOP / (avg1 * 1e-6) / 1e12, 2),
+    "executed_mfma_tflops": round(flops1 / (avg1 * 1e-6) / 1e12, 1), "mfma_bf16_peak_tflops": 2500.0,
+    "mfma_frac_of_bf16_peak": round(flops1 / (avg1 * 1e-6) / 1e12 / 2500.0, 4),
+    "per_wave_step": {k: round(v / w1 / T, 2) for k, v in sorted(c1a.items())},
+    "source": [prov(kt1), prov(f1a)]}, indent=1) + "\n"
 # ---- mixed trajectory set: VALU instructions per wave-step of the goal-table kernel
 cm, _, grid_m, fm = counters("valu_a_mixed", "mr_rollout_kernel<true, 2, false")
 files["pmc_mixed_set.json"] = json.dumps({

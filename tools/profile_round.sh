@@ -46,6 +46,7 @@ done
 pass kt_actor_bf rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_actor_bf -- python3 $R/tools/actor_probe.py --math bf16x3 --launches 200
 pass pmc_actor_bf_a rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/pmc_actor_bf_a -- python3 $R/tools/actor_probe.py --math bf16x3 --launches 6 --discard 0
 pass kt_actor_b1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_actor_b1 -- python3 $R/tools/actor_probe.py --math bf16 --launches 200
+pass pmc_actor_b1_a rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/pmc_actor_b1_a -- python3 $R/tools/actor_probe.py --math bf16 --launches 6 --discard 0
 # ---- the mixed trajectory set (BASELINE config 5's workload): instruction count per wave-step
 pass valu_a_mixed rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/valu_a_mixed -- python3 $R/bench.py $PMCARGS --workload mixed --carry f64
 pass instbench $R/tools/instbench --json
