@@ -301,8 +301,9 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     // of ITS next reset in an LDS slot; a terminated lane just loads it.  Slots are (re)filled for all lanes of the wave that
     // have none, together, when a lane without one terminates: every 15 steps on the mixed set, 25 lanes at a time instead
     // of 2.5.  Same function, same arguments, same bits as the in-step reset (which the one-launch-per-step kernel, the
-    // generic kernel and the state_prime output keep using).
-    constexpr bool CACHE = MRSIM_RESET_CACHE != 0 && !HAS_ACT && RK45 && NZ != kNoNoise && FL != 0 && (FL & kFGoalTable) != 0 &&
+    // generic kernel and the state_prime output keep using).  With the actor in the kernel lanes past n stay in the loop on a copy
+    // of the last env (wave-wide MFMA): they take part like any lane -- own slot, nothing stored.
+    constexpr bool CACHE = MRSIM_RESET_CACHE != 0 && RK45 && NZ != kNoNoise && FL != 0 && (FL & kFGoalTable) != 0 &&
                            (FL & kFAutoReset) != 0 && (FL & kFOutStatePrime) == 0;
     struct __attribute__((aligned(16))) ResetSlot { double x, y, f0x, f0y, h_abs; float d, pad; };
     __shared__ ResetSlot s_reset[CACHE ? BLOCK : 1];
@@ -533,15 +534,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
 #endif
 constexpr int kBlockBf = 512;
 template <int ACT> constexpr int actor_block() { return (ACT == kActBf16x3 || ACT == kActBf16) ? kBlockBf : kBlock; }
+// the flag-specialised actor rollout on a goal table also keeps the reset cache in LDS (48 B per env): 512-thread blocks for every
+// arithmetic there, so that two blocks = four waves per SIMD still fit the CU's 160 KiB
+template <uint32_t FL, int ACT> constexpr int actor_fl_block() { return (FL & kFGoalTable) != 0 ? kBlockBf : actor_block<ACT>(); }
 template <bool RK45, int NZ, bool MIS, uint32_t FL, int ACT>
 __global__ __launch_bounds__(actor_block<ACT>()) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES_GENERIC, 8))) void mr_rollout_actor_kernel(
     const KParams P, const StateArgs st, const RolloutArgs ra, const ActorArgs ac) {
     rollout_body<RK45, NZ, MIS, FL, ACT, actor_block<ACT>()>(P, st, ra, ac);
 }
 template <bool RK45, int NZ, bool MIS, uint32_t FL, int ACT>
-__global__ __launch_bounds__(actor_block<ACT>()) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES, 8))) void mr_rollout_actor_fl_kernel(
+__global__ __launch_bounds__((actor_fl_block<FL, ACT>())) __attribute__((amdgpu_waves_per_eu(MRSIM_ACTOR_WAVES, 8))) void mr_rollout_actor_fl_kernel(
     const KParams P, const StateArgs st, const RolloutArgs ra, const ActorArgs ac) {
-    rollout_body<RK45, NZ, MIS, FL, ACT, actor_block<ACT>()>(P, st, ra, ac);
+    rollout_body<RK45, NZ, MIS, FL, ACT, actor_fl_block<FL, ACT>()>(P, st, ra, ac);
 }
 
 // ---------------------------------------------------------------------------
@@ -851,6 +855,8 @@ constexpr uint32_t kFlMixed = kFlDdpg | kFGoalTable | kFRewardGoal;
 constexpr uint32_t kFlDdpgSoa = kFlDdpg & ~kFObsAos;  // the same with [T][5][N] observations
 // the DDPG collection loop with the actor in the kernel (RolloutCollector(policy=actor)): actor + OU noise, fp64 carry
 constexpr uint32_t kFlDdpgActor = kFlDdpg | kFCarry64 | kFActor | kFActorOU;
+// the same on a goal table with the goal reward (a policy collecting on BASELINE config 5's trajectory set): reset cache on
+constexpr uint32_t kFlMixedActor = kFlMixed | kFCarry64 | kFActor | kFActorOU;
 
 template <uint32_t FL>
 static int launch_rollout_fl(const LaunchCfg& lc, int nz, bool mis, const KParams& K, const StateArgs& S,
@@ -867,7 +873,7 @@ template <uint32_t FL, int ACT>
 static int launch_rollout_actor_fl(const LaunchCfg& lc, int nz, bool mis, const KParams& K, const StateArgs& S,
                                    const RolloutArgs& ra, const ActorArgs& AC, bool& handled) {
     handled = true;
-    constexpr int B = actor_block<ACT>();
+    constexpr int B = actor_fl_block<FL, ACT>();
     if (nz == kNoiseFast)
         return mis ? launch_b<B>(lc, mr_rollout_actor_fl_kernel<true, kNoiseFast, true, FL, ACT>, K.n, K, S, ra, AC)
                    : launch_b<B>(lc, mr_rollout_actor_fl_kernel<true, kNoiseFast, false, FL, ACT>, K.n, K, S, ra, AC);
@@ -1069,6 +1075,11 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
             rc = launch_rollout_actor_fl<kFlDdpgActor | kFActorBf16, kActBf16x3>(lc, nz, mis, K, S, ra, AC, handled);
         else if (K.flags == (kFlDdpgActor | kFActorBf16s))
             rc = launch_rollout_actor_fl<kFlDdpgActor | kFActorBf16s, kActBf16>(lc, nz, mis, K, S, ra, AC, handled);
+        else if (K.flags == kFlMixedActor) rc = launch_rollout_actor_fl<kFlMixedActor, kActF32>(lc, nz, mis, K, S, ra, AC, handled);
+        else if (K.flags == (kFlMixedActor | kFActorBf16))
+            rc = launch_rollout_actor_fl<kFlMixedActor | kFActorBf16, kActBf16x3>(lc, nz, mis, K, S, ra, AC, handled);
+        else if (K.flags == (kFlMixedActor | kFActorBf16s))
+            rc = launch_rollout_actor_fl<kFlMixedActor | kFActorBf16s, kActBf16>(lc, nz, mis, K, S, ra, AC, handled);
         if (!handled)
             rc = dispatch(true, nz, mis, [&](auto, auto NZ, auto MIS) {
                 constexpr int z = decltype(NZ)::value;

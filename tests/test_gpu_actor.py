@@ -181,6 +181,44 @@ def test_fused_rollout_equals_gym_loop_bitwise(n, mis, math):
     envB.check_status()
 
 
+@pytest.mark.parametrize("n", [1, 65, 700, 1300])
+@pytest.mark.parametrize("mis", [False, True])
+@pytest.mark.parametrize("math", ["f32", "bf16x3", "bf16"])
+def test_goal_table_actor_rollout_specialised_equals_generic_and_the_gym_loop(n, mis, math):
+    """A policy collecting on a trajectory set (goal table, goal reward, fp64 carry: BASELINE config 5's workload with the actor
+    as its policy) takes a flag-specialised mr_rollout_actor_fl_kernel that keeps the reset cache and 512-thread blocks.  Goals
+    inside the init box and a goal radius of 6: episodes of 1-10 steps.  (a) bitwise equal to the generic actor rollout kernel
+    (the same launch with one more output requested), every transition, the carried state, the OU state, over three launches;
+    (b) with the fp32 carry, where a rollout equals single steps: == T x (mrsim_actor_forward -> mrsim_step)."""
+    tab = np.random.default_rng(8).uniform(104, 116, (3, 52, 2)).astype(np.float32)
+    kw = dict(noise_var=1.0, is_mismatched=mis, auto_reset=True, reward_mode="goal", min_dist2goal=6.0)
+    m = random_actor(6, out_scale=25.0)
+    envA, envB = (_env(n, seed=5, env_id0=11, goal_table=tab, **kw) for _ in range(2))
+    actA, actB = _actor(m, math=math, reset_on_done=True), _actor(m, math=math, reset_on_done=True)
+    envA.reset(); envB.reset()
+    ndone = 0
+    for T in (33, 7, 40):
+        a = envA.rollout(T, want=("obs", "rew", "done", "actions"), actor=actA, carry="f64")
+        b = envB.rollout(T, want=("obs", "rew", "done", "actions", "traj"), actor=actB, carry="f64")
+        for key in ("actions", "obs", "rew", "done"):
+            assert torch.equal(a[key], b[key]), (T, key)
+        ndone += int(a["done"].sum())
+    assert torch.equal(envA.pos, envB.pos) and torch.equal(envA.aux, envB.aux) and torch.equal(envA.ep_ret, envB.ep_ret)
+    assert torch.equal(actA.ou_state, actB.ou_state) and torch.equal(envA.final_len, envB.final_len)
+    assert ndone > (n // 2 if n > 1 else 0), ndone      # resets happened: the cache and the in-step reset were both exercised
+    envA.check_status(); envB.check_status()
+    # (b) fp32 carry against the gym loop (generic kernel: the specialised one is built for the fp64 carry only)
+    envC, envD = (_env(n, seed=6, env_id0=3, goal_table=tab, **kw) for _ in range(2))
+    actC, actD = _actor(m, math=math, reset_on_done=True), _actor(m, math=math, reset_on_done=True)
+    envC.reset(); envD.reset()
+    rec = {"actions": [], "obs": [], "rew": [], "done": []}
+    _gym_loop(envC, actC, 30, rec)
+    out = envD.rollout(30, want=("obs", "rew", "done", "actions"), actor=actD, carry="f32")
+    for key in ("actions", "obs", "rew", "done"):
+        assert torch.equal(out[key], torch.stack(rec[key])), key
+    assert torch.equal(envC.pos, envD.pos) and torch.equal(actC.ou_state, actD.ou_state)
+
+
 def _closed_loop_oracle(cfg, m, n, T, seed, gpu, id0=0, reset_on_done=False, threads=8, exact_actions=True, math="f32"):
     """The collection loop on the CPU, teacher-forced: at every step the oracle's actor sees the observation the KERNEL's
     actor saw (row t - 1 of the kernel's observations; the reset observation for t = 0) and must produce the kernel's
