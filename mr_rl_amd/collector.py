@@ -27,6 +27,22 @@ from .dist import all_shards
 from .vec_env import MRVecEnv
 
 
+_STREAMS = {}
+
+
+def _sub_shard_streams(dev, count):
+    """The HIP streams the sub-shard launches go to: ONE set per device for the whole process, shared by every collector.
+    torch hands out pool streams round robin and not every pair of them runs its kernels side by side -- measured: the second
+    collector created in a process (pool streams 2 and 3) had its two sub-shard launches run one after the other, 12 % off the
+    collection rate, every other collector overlapped them (profiles/r03/NOTES.md).  Collectors are used one at a time; two used
+    at once merely share the streams' order."""
+    import torch
+    key = (str(dev), int(count))
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(count)]
+    return _STREAMS[key]
+
+
 class RolloutCollector:
     WANT = ("obs", "rew", "done", "actions")
 
@@ -43,7 +59,7 @@ class RolloutCollector:
         self.policy = policy   # None: the uniform exploration policy drawn in-kernel; a DeviceActor: actor + OU noise in-kernel
         dev = env.device
         self.shards = [(a, n) for a, n in all_shards(self.N, self.S) if n > 0]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in self.shards]
+        self.streams = _sub_shard_streams(dev, len(self.shards))
         T_, N = self.T, self.N
         soa = env._soa
         shapes = {"traj": ((T_, N, 2), torch.float64), "state_prime": ((T_, N, 2), torch.float32),

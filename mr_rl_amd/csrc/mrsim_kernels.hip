@@ -1075,11 +1075,13 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
             rc = launch_rollout_actor_fl<kFlDdpgActor | kFActorBf16, kActBf16x3>(lc, nz, mis, K, S, ra, AC, handled);
         else if (K.flags == (kFlDdpgActor | kFActorBf16s))
             rc = launch_rollout_actor_fl<kFlDdpgActor | kFActorBf16s, kActBf16>(lc, nz, mis, K, S, ra, AC, handled);
+#ifndef MRSIM_NO_MIXED_ACTOR_FL   // (measurement builds: the generic actor rollout kernel on goal tables, tools/actor_mixed_probe.py)
         else if (K.flags == kFlMixedActor) rc = launch_rollout_actor_fl<kFlMixedActor, kActF32>(lc, nz, mis, K, S, ra, AC, handled);
         else if (K.flags == (kFlMixedActor | kFActorBf16))
             rc = launch_rollout_actor_fl<kFlMixedActor | kFActorBf16, kActBf16x3>(lc, nz, mis, K, S, ra, AC, handled);
         else if (K.flags == (kFlMixedActor | kFActorBf16s))
             rc = launch_rollout_actor_fl<kFlMixedActor | kFActorBf16s, kActBf16>(lc, nz, mis, K, S, ra, AC, handled);
+#endif
         if (!handled)
             rc = dispatch(true, nz, mis, [&](auto, auto NZ, auto MIS) {
                 constexpr int z = decltype(NZ)::value;

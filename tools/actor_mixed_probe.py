@@ -1,11 +1,12 @@
 import sys, time, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from mr_rl_amd import MRConfig
+from mr_rl_amd import MRConfig, _lib
 from mr_rl_amd.actor import DeviceActor
 from mr_rl_amd.collector import RolloutCollector
 from mr_rl_amd.ddpg import Actor
 N = 262144
+LIB = _lib.load(sys.argv[1]) if len(sys.argv) > 1 else None   # optional: another build of the library
 torch.manual_seed(0)
 m = Actor().eval()
 for math in ("f32", "bf16x3", "bf16"):
@@ -14,6 +15,8 @@ for math in ("f32", "bf16x3", "bf16"):
         tab = bench.mixed_goal_table(cfg, 0) if mixed else None
         pol = DeviceActor.from_module(m, obs_scale=[0.01] * 5, device="cuda", math=math)
         col = RolloutCollector(N, cfg=cfg, seed=0, streams=2, carry="f64", policy=pol, goal_table=tab)
+        if LIB is not None:
+            col.env._L = LIB
         col.reset()
         for _ in range(30):
             col.collect(); col.ready(); col.release()
