@@ -331,6 +331,27 @@ def test_collector_reset_right_after_collect_waits_for_the_sub_shard_streams():
     col.check_status()
 
 
+def test_collectors_share_one_set_of_sub_shard_streams():
+    """Every collector of a process launches its sub-shards on the same HIP streams (collector.py: the pool streams torch hands
+    to a second collector did not run their kernels side by side); results do not depend on it: two collectors used in turn
+    reproduce one collector's episodes."""
+    from mr_rl_amd import MRConfig
+    from mr_rl_amd.collector import RolloutCollector
+    mk = lambda: RolloutCollector(3000, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=4, streams=2)  # noqa: E731
+    a, b, ref = mk(), mk(), mk()
+    assert all(x is y for x, y in zip(a.streams, b.streams)) and len(a.streams) == 2 and a.streams[0] is not a.streams[1]
+    a.reset(); b.reset(); ref.reset()
+    for k in range(4):
+        ra = {q: v.clone() for q, v in a.ready(a.collect()).items() if torch.is_tensor(v)}; a.release()
+        rb = {q: v.clone() for q, v in b.ready(b.collect()).items() if torch.is_tensor(v)}; b.release()
+        rr = ref.ready(ref.collect())
+        for q in ("obs", "rew", "done", "actions"):
+            assert torch.equal(ra[q], rr[q]) and torch.equal(rb[q], rr[q]), (k, q)
+        ref.release()
+    a.join(); b.join(); ref.join()
+    a.check_status(); b.check_status()
+
+
 def test_state_dict_carries_the_step_outputs_and_leaves_the_callers_cfg_alone():
     from mr_rl_amd import MRConfig, MRVecEnv
     a = _env(1000, seed=4, noise_var=1.0, auto_reset=True, max_timesteps=5)
