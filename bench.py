@@ -100,6 +100,13 @@ def parse(argv=None):
     ap.add_argument("--obs-layout", choices=["aos", "soa"], default="aos")
     ap.add_argument("--noise-math", choices=["fast", "spec"], default="fast")
     ap.add_argument("--sigma", type=float, default=1.0)
+    ap.add_argument("--noise-law", choices=["collapsed", "per_stage"], default="collapsed",
+                    help="where the normals of an RK45 step enter (include/mrsim.h, MRSIM_LAW_*): per_stage = one draw per RHS "
+                         "evaluation as MR_simulator.py:73-83 (the library's default and parity mode); collapsed = the weighted stage "
+                         "sums drawn directly from their joint Gaussian -- the same distribution (tests/test_noise_law_cpu.py), element-"
+                         "wise parity against the oracle's restatement of the same law (tests/test_gpu_round4.py).  The line reports "
+                         "the other law beside the headline (`other_noise_law`)")
+    ap.add_argument("--no-other-law", action="store_true", help="skip the leg that measures the other noise law")
     ap.add_argument("--mismatched", action="store_true", help="non-default: the reference's is_mismatched=True law")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -115,6 +122,7 @@ def parse(argv=None):
     ap.add_argument("--no-mixed-set", action="store_true", help="skip the extra mixed-trajectory-set measurement")
     ap.add_argument("--no-power", action="store_true", help="skip the 1.5 s package-power leg (hwmon sysfs)")
     ap.add_argument("--no-actor-leg", action="store_true", help="skip the actor-in-the-loop collection measurement")
+    ap.add_argument("--no-learner-leg", action="store_true", help="skip the DDPG learner measurement (updates/s, end-to-end training rate)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--master-port", type=int, default=0, help="--gpus N launcher: rendezvous port (0 = pick a free one)")
@@ -260,34 +268,68 @@ def profiled_config_matches(args, n_local):
             and args.workload == "ddpg" and not args.mismatched and (args.mode == "step" or args.rollout_len == 51))
 
 
-def committed_traffic(args, n_local):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes
-    (profiles/rNN/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
-    same command and corrected as MI355X_MICROARCH.md prescribes)."""
+def loaded_lib_sha16():
+    """sha256 prefix of the libmrsim.so this process runs -- committed counters describe ONE build of the kernels"""
+    import hashlib
+    from mr_rl_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+def counters_describe_this_build(d):
+    """(ok, why_not): committed PMC records carry the sha256 prefix of the library they were taken with; counters of another
+    build are somebody else's kernel and are not quoted"""
+    want = d.get("libmrsim_so_sha16")
+    have = loaded_lib_sha16()
+    if want is None or want != have:
+        return False, "committed counters describe libmrsim.so %s, this run loaded %s: not quoted" % (want, have)
+    return True, None
+
+
+def committed_traffic(args, n_local, law=None):
+    """(HBM bytes per launch, source, why_none) of the dominant kernel from the newest committed rocprofv3 PMC passes
+    (profiles/rNN/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command and
+    corrected as MI355X_MICROARCH.md prescribes) -- only for the profiled configuration and the very build that was profiled."""
+    law = law or args.noise_law
     f = newest_profile("pmc_traffic.json")
     if f is None or not profiled_config_matches(args, n_local):
-        return None, None
+        return None, None, "no committed counters for this configuration"
     key = "mr_rollout_kernel" if args.mode == "rollout" else "mr_step_kernel"
     try:
-        for name, k in json.load(open(f))["kernels"].items():
-            if name.startswith(key) and (args.mode == "step" or k.get("carry", "f32") == args.carry):
-                return int(k["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
-    except Exception:
-        pass
-    return None, None
+        d = json.load(open(f))
+        ok, why = counters_describe_this_build(d)
+        if not ok:
+            return None, None, why
+        for name, k in d["kernels"].items():
+            if name.startswith(key) and (args.mode == "step" or (k.get("carry", "f32") == args.carry and
+                                                                 k.get("noise_law", "per_stage") == law)):
+                return int(k["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT), None
+    except Exception as exc:
+        return None, None, "unreadable %s: %s" % (f, exc)
+    return None, None, "no record for this kernel in %s" % os.path.relpath(f, ROOT)
 
 
-def committed_valu(args, n_local, T):
+def modelled_traffic(n_local, T):
+    """What one launch of the fused rollout must move when nothing is read or written twice: every transition (obs 20 +
+    action 8 + reward 4 + done 1 = 33 B per env-step), the env state in and out (pos 16 + aux 16 + ep_ret 4 each way) and the
+    episode return / length of envs whose episode ended (8 B; every env once per 51 steps).  The PMC passes of rounds 2-3
+    measured 1.01 x this figure."""
+    return n_local * (33 * T + 2 * 36 + 8)
+
+
+def committed_valu(args, n_local, T, law=None):
     """VALU-issue roofline of the rollout kernel from the committed counters (profiles/rNN/pmc_valu.json, written by
     tools/collect_profiles.py): the kernel's instruction mix per wave-step (rocprofv3 --pmc SQ_INSTS_VALU_*) priced with the
     per-instruction issue costs tools/instbench measures at the launch's occupancy, against the kernel's own SQ_WAVE_CYCLES
     -- shader cycles on both sides, so the clock the chip holds under load cancels.  Only for the profiled configuration."""
+    law = law or args.noise_law
     f = newest_profile("pmc_valu.json")
     if f is None or args.mode != "rollout" or not profiled_config_matches(args, n_local):
         return None
     try:
         d = json.load(open(f))
-        k = d["kernels"]["rollout_" + args.carry]
+        if not counters_describe_this_build(d)[0]:
+            return None
+        k = d["kernels"]["rollout_" + args.carry + ("" if law == "per_stage" else "_" + law)]
         return {"valu_issue_frac": k["valu_issue_frac"], "valu_issue_frac_at_spec_rates": k.get("valu_issue_frac_at_spec_rates"),
                 "insts_valu_per_wave_step": k["insts_valu_per_wave_step"],
                 "issue_floor_cycles_per_wave_step": k["issue_floor_cycles_per_wave_step"],
@@ -522,7 +564,7 @@ def measure_mixed_set(args, n_local, env_id0, world, dev, seed, streams, steps=1
     goal reward, returns all-gathered once per episode."""
     from mr_rl_amd import MRConfig
     cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math,
-                   seed=seed, is_mismatched=args.mismatched)
+                   seed=seed, is_mismatched=args.mismatched, noise_law=args.noise_law)
     tab = mixed_goal_table(cfg, seed)
     reg = make_region(args, cfg, n_local, env_id0, world, dev, seed, streams, goal_table=tab)
     ep = reg.ep
@@ -557,7 +599,7 @@ def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event
     module = Actor().eval()
     actor = DeviceActor.from_module(module, obs_scale=[0.01] * 5, device=dev)
     cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math, seed=seed,
-                   is_mismatched=args.mismatched)
+                   is_mismatched=args.mismatched, noise_law=args.noise_law)
     ep = cfg.max_timesteps + 1
 
     def run(S, n, events=None, actor=actor):
@@ -661,6 +703,78 @@ def trajectory_rmse(dev, carry):
     return out
 
 
+def rollout_roofline(args, n_local, T, law, avg_us, med_us, timed_where):
+    """`roofline` object of the fused rollout kernel under noise law `law`, from its average launch duration (HIP events on
+    the dispatches of a one-stream region of THIS run).
+    bound = "hbm": achieved = the HBM bytes one launch really moves / that duration.  The bytes come from the committed
+    rocprofv3 --pmc passes of this very build (`traffic`, profiles/rNN/pmc_traffic.json; refused when the library hash differs)
+    or, failing that, from the minimal-traffic model (`traffic_source` says which; the PMC passes measured 1.01 x the model).
+    SURVEY 8(d)'s algorithmic 97 B per env-step (state round-trips HBM every step) is NOT what a fused launch moves -- the
+    state stays in registers for all T steps -- and is kept as the labelled `algorithmic_equiv`, never as a fraction.
+    `valu`: the kernel's vector-issue floor from the committed SQ counters, the other resource the kernel leans on."""
+    units = n_local * T
+    traffic, traffic_src, why = committed_traffic(args, n_local, law)
+    valu = committed_valu(args, n_local, T, law)
+    moved, moved_src = (traffic, traffic_src) if traffic else (modelled_traffic(n_local, T), "model: 33 B per env-step of transitions + "
+                                                               "state in/out + episode returns (bench.py: modelled_traffic)")
+    gbs = moved / (avg_us * 1e-6) / 1e9
+    clock = valu["wave_cycles_per_wave_step"] * T / (avg_us * 1e3) if valu else None
+    nz = "nonoise" if args.sigma == 0 else args.noise_math
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_unavailable_because": why,
+            "bytes_priced": moved, "bytes_priced_source": moved_src,
+            "hbm_achievable_GBs": HBM_ACHIEVABLE_GBS, "frac_of_achievable": round(gbs / HBM_ACHIEVABLE_GBS, 4),
+            "north_star_hbm_target": 0.60, "north_star_hbm_target_met": bool(gbs / HBM_PEAK_GBS >= 0.60),
+            "noise_law": law,
+            "in_kernel_env_steps_per_s": units / (avg_us * 1e-6),
+            "valu": valu, "valu_issue_frac": valu["valu_issue_frac"] if valu else None,
+            "valu_issue_frac_at_spec_rates": valu.get("valu_issue_frac_at_spec_rates") if valu else None,
+            "in_kernel_clock_GHz": round(clock, 3) if clock else None,
+            "algorithmic_equiv": {
+                "what": "SURVEY 8(d)'s algorithmic bytes (state round-trips HBM every step) / kernel time; the fused kernel keeps "
+                        "the state in registers and does NOT move these bytes: an equivalence figure, not a fraction of any peak",
+                "bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                "GBs": round(units * ALGO_BYTES_PER_ENV_STEP / (avg_us * 1e-6) / 1e9, 1)},
+            "kernel": "mr_rollout_kernel<RK45,%s%s,%s,carry=%s>" % (nz, "" if law == "per_stage" else "+collapsed",
+                                                                    "mismatched" if args.mismatched else "nominal", args.carry),
+            "kernel_timed_over": timed_where, "avg_kernel_us": round(avg_us, 3), "median_kernel_us": round(med_us, 3),
+            "env_steps_per_launch": units}
+
+
+def measure_other_law(args, cfg, n_local, env_id0, world, dev, seed, streams, goal_table, T, law, episodes=400):
+    """The same workload under the OTHER noise law (every rank takes part): sustained wall-clock rate through the collector on
+    `streams` streams, then one launch per episode on ONE stream with a HIP event pair on every dispatch -- the kernel
+    durations of that law's `roofline` object."""
+    import copy
+    from mr_rl_amd._lib import EventPair
+    c2 = copy.copy(cfg)
+    c2.noise_law = law
+    ep = c2.max_timesteps + 1
+    reg = make_region(args, c2, n_local, env_id0, world, dev, seed, streams, goal_table=goal_table, T=T)
+    reg.run(PREROLL_EPISODES * ep)
+    el, launches = reg.timed(episodes * ep)
+    reg.col.check_status()
+    out = {"noise_law": law, "value": n_local * world * episodes * ep / el, "unit": "env-steps/s", "steps": episodes * ep,
+           "streams": reg.col.S, "launches": launches, "ms_per_step": el / (episodes * ep) * 1e3}
+    del reg
+    reg1 = make_region(args, c2, n_local, env_id0, world, dev, seed, 1, goal_table=goal_table, T=T)
+    pool = [EventPair() for _ in range(episodes)] if int(os.environ.get("RANK", "0")) == 0 else None
+    used = []
+    reg1.run(PREROLL_EPISODES * ep)
+    el1, _ = reg1.timed(episodes * ep, pool, used)
+    reg1.col.check_status()
+    ms = [e.elapsed_ms() for e in used]
+    if pool is not None:
+        for e in pool:
+            e.close()
+    out["one_stream_with_events"] = {"value": n_local * world * episodes * ep / el1}
+    if ms:
+        avg_us, med_us = stats_us(ms)
+        out["roofline"] = rollout_roofline(args, n_local, T, law, avg_us, med_us,
+                                           "the %d dispatches of a one-stream region of this leg" % len(ms))
+    return out
+
+
 def stats_us(ms):
     ms = sorted(ms)
     return sum(ms) / len(ms) * 1e3, ms[len(ms) // 2] * 1e3
@@ -724,7 +838,7 @@ def main():
     env_id0, _ = shard_of(total, rank, world)
     seed = 7
     cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math,
-                   seed=seed, is_mismatched=args.mismatched)
+                   seed=seed, is_mismatched=args.mismatched, noise_law=args.noise_law)
     goal_table = None
     if args.workload == "mixed":
         goal_table = mixed_goal_table(cfg, seed)
@@ -797,7 +911,8 @@ def main():
     # clock settle (tools/clock_ramp_probe.py: ~35 ms of load after idle), independent of the W the caller asks for
     trace("env ready; settle phase: %d episodes" % args.settle_episodes)
     run(args.settle_episodes * ep)
-    if K <= 4 * ep:
+    short_region = K <= 4 * ep
+    if short_region:
         # A timed region of a few launch groups (the driver's --steps 20) is mostly host time, and right behind hundreds of
         # queued launches the HIP runtime is still retiring them: the next launches then cost 25 - 100 us instead of 13 - 22
         # (tools/enqueue_profile.py).  Drain the settle phase, give the runtime 2 ms, and put the load back on for 60 episodes
@@ -885,6 +1000,12 @@ def main():
         mixed = measure_mixed_set(args, n_local, env_id0, world, dev, seed, streams)
         trace("mixed set done")
 
+    other_law = None
+    if args.mode == "rollout" and not args.no_other_law and args.sigma > 0 and not pmc:
+        other_law = measure_other_law(args, cfg, n_local, env_id0, world, dev, seed, streams, goal_table, args.rollout_len,
+                                      "per_stage" if args.noise_law == "collapsed" else "collapsed")
+        trace("other-law leg done")
+
     # ---- roofline of the dominant kernel (rank 0): durations from HIP events attached to the dispatches
     # (hipExtLaunchKernelGGL) on the stream they run on.  Rollout mode: the dispatches of the one-stream sustained region
     # (or of the timed region when that leg is off).  Step mode (graph replays cannot carry per-dispatch events): separate
@@ -906,50 +1027,13 @@ def main():
                       for _ in range(ns + 20)][20:]
                 timed_where = "%d launches after the timed region" % len(ms)
             avg_us, med_us = stats_us(ms)
-            units = n_local * T
-            traffic, traffic_src = committed_traffic(args, n_local)
-            valu = committed_valu(args, n_local, T)
-            ach = units / (avg_us * 1e-6) / 1e9
-            frac = valu["valu_issue_frac"] if valu else None
-            # in-kernel clock of THIS run: the kernel needs wave_cycles_per_wave_step x T shader cycles per wave, and the
-            # waves of a one-round launch live as long as the kernel
-            clock = valu["wave_cycles_per_wave_step"] * T / (avg_us * 1e3) if valu else None
-            roof = {"bound": "valu", "achieved": round(ach, 2), "peak": round(ach / frac, 2) if frac else None,
-                    "unit": "G env-steps/s in-kernel; peak = achieved / frac, frac = VALU issue cycles the kernel's measured "
-                            "instruction mix needs at the per-instruction issue costs of tools/instbench (4 waves per SIMD) / "
-                            "the kernel's SQ_WAVE_CYCLES, both from the committed rocprofv3 --pmc passes (cycles over cycles)",
-                    "frac": frac,
-                    # the same instruction counts priced at architectural issue rates (2 cycles per fp32 / int32 wave
-                    # instruction, 4 for fp64, transcendentals and v_mad_u64_u32) instead of the measured ones
-                    "frac_at_spec_issue_rates": valu.get("valu_issue_frac_at_spec_rates") if valu else None,
-                    "valu": valu,
-                    "in_kernel_clock_GHz": round(clock, 3) if clock else None,
-                    "frac_of_burst_clock_floor": round(valu["floor_us_per_launch_at_burst_clock"] / avg_us, 4) if valu else None,
-                    "traffic": traffic, "traffic_source": traffic_src,
-                    "hbm_achieved_GBs": round(traffic / (avg_us * 1e-6) / 1e9, 1) if traffic else None,
-                    "hbm_peak_GBs": HBM_PEAK_GBS,
-                    "hbm_frac": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                    "hbm_achievable_GBs": HBM_ACHIEVABLE_GBS,
-                    "hbm_frac_of_achievable": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_ACHIEVABLE_GBS, 4) if traffic else None,
-                    # north_star asks for >= 60 % of the HBM roofline; on the bytes the fused kernel really moves it is not
-                    # met (the kernel is bound by vector issue at the package power cap)
-                    "north_star_hbm_target": 0.60,
-                    "north_star_hbm_target_met": bool(traffic and traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS >= 0.60),
-                    "algorithmic_equiv": {
-                        "what": "SURVEY 8(d)'s algorithmic bytes (state round-trips HBM every step) / kernel time; the "
-                                "fused kernel keeps the state in registers and does NOT move these bytes: an "
-                                "equivalence figure, not a fraction of any peak",
-                        "bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                        "GBs": round(units * ALGO_BYTES_PER_ENV_STEP / (avg_us * 1e-6) / 1e9, 1)},
-                    "kernel": "mr_rollout_kernel<RK45,%s,%s,carry=%s>" % (nz, law, args.carry),
-                    "kernel_timed_over": timed_where, "avg_kernel_us": round(avg_us, 3),
-                    "median_kernel_us": round(med_us, 3), "env_steps_per_launch": units}
+            roof = rollout_roofline(args, n_local, T, args.noise_law, avg_us, med_us, timed_where)
         else:
             ns = args.kernel_samples or 102
             ms = [env.step_timed(env.random_policy(out=act) if args.policy != "fused" else None) for _ in range(ns)]
             avg_us, med_us = stats_us(ms)
             units = n_local
-            traffic, traffic_src = committed_traffic(args, n_local)
+            traffic, traffic_src, _why = committed_traffic(args, n_local)
             ach = units * ALGO_BYTES_PER_ENV_STEP / (avg_us * 1e-6) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -990,7 +1074,7 @@ def main():
                               "device, sigma=%g, integrator=reference(RK45), reward+done on device, auto-reset, all "
                               "transitions written to HBM" % args.sigma,
                   "trajectory_set": args.workload, "mode": args.mode, "envs_per_gpu": n_local, "total_envs": total, "obs_layout": args.obs_layout,
-                  "noise_math": args.noise_math, "sigma": args.sigma, "seed": seed,
+                  "noise_math": args.noise_math, "noise_law": args.noise_law, "sigma": args.sigma, "seed": seed,
                   "is_mismatched": bool(args.mismatched),
                   "mean_episode_return": mean_ret,
                   "ranks": dist.get_world_size() if world > 1 else 1,
@@ -1012,6 +1096,12 @@ def main():
         out["per_rank_value"] = [n_local * K / max(s_, 1e-12) for s_ in per_rank_s]
         if region_phases is not None:
             out["timed_region_phases_us"] = region_phases  # rank 0's wall time of the K-step region, by phase
+        if short_region:
+            #  said in the record, not only in a comment: a K this short is ONE launch group per stream, so `value` is
+            # a host-enqueue figure; the kernel's rate is `sustained`
+            out["short_region_preconditioning"] = ("K <= 4 episodes: the settle phase was drained, the host slept 2 ms and 60 "
+                                                   "untimed episodes were re-issued before the region; `value` of such a region "
+                                                   "is host-launch-bound -- see `sustained` for the kernel's rate")
         if sustained is not None:
             out["sustained"] = sustained
         if rmse is not None:
@@ -1020,6 +1110,8 @@ def main():
             out["step_path"] = step_path
         if mixed is not None:
             out["mixed_trajectory_set"] = mixed
+        if other_law is not None:
+            out["other_noise_law"] = other_law
         if actor_leg is not None:
             out["actor_in_loop"] = actor_leg
         if power is not None:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MRSIM_ABI_VERSION 3
+#define MRSIM_ABI_VERSION 4
 
 enum {
     MRSIM_OK = 0,
@@ -51,6 +51,16 @@ enum { MRSIM_OBS_AOS = 0 /* [N][5] */, MRSIM_OBS_SOA = 1 /* [5][N] */ };
 /* FAST: hardware v_log/v_sqrt/v_sin/v_cos (normals within ~1e-6 of SPEC).  SPEC: the operation-by-
  * operation fp32 definition shared with the CPU oracle -- normals are bit-identical to the oracle's. */
 enum { MRSIM_NOISE_FAST = 0, MRSIM_NOISE_SPEC = 1 };
+/* Where the normals of an RK45 env step enter (ABI 4).
+ * PER_STAGE (default, the parity mode): a fresh N(0, sigma) at every RHS evaluation, in the reference's order
+ *   (MR_simulator.py:73-83; 8 evaluations per env step: stages K1..K5, f_new, and the two of the next RK45 constructor).
+ * COLLAPSED (opt-in): the stage normals of one rk_step attempt reach a result only through the B-weighted sum (position)
+ *   and the E-weighted sum (error estimate); those two are jointly Gaussian with the tableau's fixed covariance and are
+ *   drawn directly (2 normals per noise component instead of 4; f_new and the constructor keep their own draws).  Every
+ *   quantity a step returns or carries has the same distribution as under PER_STAGE -- tested on the CPU oracle over 1e6
+ *   steps per configuration, tests/test_noise_law_cpu.py -- but not the same numbers for a given seed.  RK45 integrator
+ *   only (the fixed-step modes ignore it); 2 Philox calls + 2 Box-Muller pairs per env step instead of 3 + 5. */
+enum { MRSIM_LAW_PER_STAGE = 0, MRSIM_LAW_COLLAPSED = 1 };
 
 /* Tunables of the reference path, with the place each one lives in the reference. */
 typedef struct MrsimParams {
@@ -83,7 +93,7 @@ typedef struct MrsimParams {
                            /*   behind = params.mismatched.  1: a fresh MR_Env per episode (utils.run_sim,       */
                            /*   utils.py:46): the constructor runs under the nominal law.  Same thing unless     */
                            /*   mismatched != 0.                                                                 */
-    int32_t reserved0;     /* 0                                                                                  */
+    int32_t noise_law;     /* MRSIM_LAW_* (ABI 4; 0 = PER_STAGE = the reference's per-evaluation noise)          */
     const uint64_t* step_base; /* optional DEVICE word added to every step_idx argument.  Kernel      */
                            /*   arguments are frozen inside a captured hipGraph; keeping the base in */
                            /*   HBM (advanced by mrsim_advance_step_base) lets each replay draw new  */

@@ -11,7 +11,8 @@ INT_RK45, INT_EULER, INT_RK4 = 0, 1, 2
 REW_CONSTANT10, REW_GOAL = 0, 1
 OBS_AOS, OBS_SOA = 0, 1
 NOISE_FAST, NOISE_SPEC = 0, 1
-ABI_VERSION = 3
+LAW_PER_STAGE, LAW_COLLAPSED = 0, 1
+ABI_VERSION = 4
 ACTOR_HIDDEN, ACTOR_BLOB_FLOATS = 64, 10888
 ACTOR_F32, ACTOR_BF16X3, ACTOR_BF16 = 0, 1, 2
 
@@ -35,7 +36,7 @@ class MrsimParams(C.Structure):
         ("mismatched", C.c_int32), ("integrator", C.c_int32), ("substeps", C.c_int32),
         ("reward_mode", C.c_int32), ("max_timesteps", C.c_int32), ("auto_reset", C.c_int32),
         ("goal_K", C.c_int32), ("goal_T", C.c_int32), ("obs_layout", C.c_int32), ("noise_math", C.c_int32),
-        ("auto_reset_fresh_env", C.c_int32), ("reserved0", C.c_int32),
+        ("auto_reset_fresh_env", C.c_int32), ("noise_law", C.c_int32),
         ("step_base", C.c_void_p),
     ]
 

@@ -9,6 +9,7 @@ INTEGRATORS = {"reference": _lib.INT_RK45, "rk45": _lib.INT_RK45, "euler": _lib.
 REWARD_MODES = {"constant10": _lib.REW_CONSTANT10, "goal": _lib.REW_GOAL}
 OBS_LAYOUTS = {"aos": _lib.OBS_AOS, "soa": _lib.OBS_SOA}
 NOISE_MATH = {"fast": _lib.NOISE_FAST, "spec": _lib.NOISE_SPEC}
+NOISE_LAWS = {"per_stage": _lib.LAW_PER_STAGE, "collapsed": _lib.LAW_COLLAPSED}
 
 
 @dataclasses.dataclass
@@ -44,6 +45,9 @@ class MRConfig:
                                           # per episode (utils.run_sim): nominal-law constructor.  Differs only if is_mismatched.
     obs_layout: str = "aos"               # storage of obs: [N,5] rows or [5,N] planes (returned view is [N,5])
     noise_math: str = "fast"              # Box-Muller on hardware transcendentals | "spec": bit-identical to the oracle
+    noise_law: str = "per_stage"          # "per_stage": a fresh normal at every RHS evaluation (MR_simulator.py:73-83, the
+                                          # parity mode); "collapsed": the weighted stage sums of an RK45 attempt drawn
+                                          # directly from their joint Gaussian -- same law, fewer draws (include/mrsim.h)
     rollout_carry: str = "f32"            # fused rollout: "f32" = carried RK45 state rounded per step (bit-identical to
                                           # step()); "f64" = kept in fp64 registers for the whole launch
     seed: int = 0
@@ -76,4 +80,5 @@ class MRConfig:
         p.goal_K, p.goal_T = int(goal_K), int(goal_T)
         p.obs_layout = OBS_LAYOUTS[self.obs_layout]
         p.noise_math = NOISE_MATH[self.noise_math]
+        p.noise_law = NOISE_LAWS[self.noise_law]
         return p

@@ -42,6 +42,12 @@ constexpr int kBlock = 256;  // 4 waves; 16-B records => every wave moves 1 KiB 
 constexpr int kNoNoise = 0;    // sigma == 0: no RNG work at all
 constexpr int kNoiseSpec = 1;  // Box-Muller in specified fp32 arithmetic: bit-identical to the CPU oracle
 constexpr int kNoiseFast = 2;  // Box-Muller on the hardware transcendentals (v_log/v_sqrt/v_sin/v_cos)
+// the same two with the COLLAPSED noise law (MrsimParams.noise_law; RK45 only): per rk_step attempt the B- and E-weighted sums
+// of the stage noise are drawn directly from their joint Gaussian instead of stage by stage -- see "collapsed law" below
+constexpr int kNoiseSpecC = 3;
+constexpr int kNoiseFastC = 4;
+__host__ __device__ constexpr bool nz_fast(int nz) { return nz == kNoiseFast || nz == kNoiseFastC; }
+__host__ __device__ constexpr bool nz_coll(int nz) { return nz == kNoiseSpecC || nz == kNoiseFastC; }
 
 // ---------------------------------------------------------------------------
 // kernel-side parameter block (passed by value -> kernarg/SGPRs)
@@ -236,7 +242,7 @@ __device__ __forceinline__ float sqrt_rn_small(float w) {
 template <int NZ>
 __device__ __forceinline__ void box_muller(uint32_t ua, uint32_t ub, float& z0, float& z1, float* radius = nullptr) {
     const float u = __builtin_fmaf((float)ua, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-    if constexpr (NZ == kNoiseFast) {
+    if constexpr (nz_fast(NZ)) {
         const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // -2 ln2 log2 u
         // angle in revolutions for v_sin / v_cos, which are 1-periodic: 1 + (ub >> 9) * 2^-23 in [1, 2), assembled by ONE
         // v_alignbit_b32 ({0x7F, ub} >> 9 = 0x3F800000 | ub >> 9) instead of v_cvt_f32_u32 + v_fma.  Top 23 bits of ub:
@@ -519,6 +525,18 @@ __device__ __forceinline__ bool construct_level0(const KParams& P, double x, dou
     }
 }
 
+// the three normals (z_a, z_x, z_y) of the constructor's F0 from what the attempt kept: the words of one Box-Muller pair
+// (f0a, f0b) and, under the mismatched law, a third normal f0k already evaluated with its pair partner
+//   per-stage law: pair = (F0a, F0x), f0k = F0y        collapsed law: pair = (F0x, F0y), f0k = F0a
+template <int NZ, bool MIS>
+__device__ __forceinline__ void f0_normals(uint32_t f0a, uint32_t f0b, float f0k, float& za, float& zx, float& zy) {
+    float p, q;
+    box_muller<NZ>(f0a, f0b, p, q);
+    if constexpr (!MIS) { za = 0.f; zx = p; zy = q; }
+    else if constexpr (nz_coll(NZ)) { za = f0k; zx = p; zy = q; }
+    else { za = p; zx = q; zy = f0k; }
+}
+
 // ---------------------------------------------------------------------------
 // RungeKutta.__init__ + select_initial_step: what Simulator.step does after integrating
 // (MR_simulator.py:46-50) and what reset_start_pos does (:31-34).  Two RHS evaluations:
@@ -549,7 +567,7 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
                 return;
             }
             if (!LS->have3) {
-                philox_call(R, c0_of(kStreamDyn, LS->last_attempt, MIS ? 5u : 3u), LS->w3);
+                philox_call(R, c0_of(kStreamDyn, LS->last_attempt, nz_coll(NZ) ? (MIS ? 3u : 2u) : (MIS ? 5u : 3u)), LS->w3);
                 LS->have3 = true;
             }
             if constexpr (MIS) {
@@ -566,15 +584,10 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
     };
     if constexpr (NZ != kNoNoise) {
         if (LS != nullptr) {
-            float z0, z1;
-            box_muller<NZ>(LS->f0a, LS->f0b, z0, z1);
-            if constexpr (MIS) {
-                noise_vec<MIS>(P, C, z0, z1, LS->f0y, n0x, n0y);  // n0 itself only feeds the fp32 fallback test
-                rhs_value<MIS>(P, C, z0, z1, LS->f0y, f0x, f0y);
-            } else {
-                noise_vec<MIS>(P, C, 0.f, z0, z1, n0x, n0y);
-                rhs_value<MIS>(P, C, 0.f, z0, z1, f0x, f0y);
-            }
+            float za, zx, zy;
+            f0_normals<NZ, MIS>(LS->f0a, LS->f0b, LS->f0y, za, zx, zy);
+            noise_vec<MIS>(P, C, za, zx, zy, n0x, n0y);  // n0 itself only feeds the fp32 fallback test
+            rhs_value<MIS>(P, C, za, zx, zy, f0x, f0y);
             have1 = need_f1;
             if (have1) eval_f1();
         }
@@ -673,9 +686,21 @@ constexpr float kB2f = (float)(500.0 / 1113), kB3f = (float)(125.0 / 192), kB4f 
                 kB5f = (float)(11.0 / 84);
 constexpr float kE2f = (float)(71.0 / 16695), kE3f = (float)(-71.0 / 1920), kE4f = (float)(17253.0 / 339200),
                 kE5f = (float)(-22.0 / 525), kE6f = (float)(1.0 / 40);
+// ---- collapsed law (nz_coll(NZ); oracle/mrsim_oracle.c: COL_*).  The stage normals N_2..N_5 of an rk_step attempt reach a result
+// only through S_B = sum B_i N_i (position) and S_E = sum E_i N_i (error estimate); per noise component these are jointly
+// Gaussian with the tableau's fixed covariance, so the law draws  S_B = cB z1,  S_E = cE1 z1 + cE2 z2  (z1, z2 iid N(0,1))
+// directly.  K6, F0, F1 keep their own draws.  Equal in law to the per-stage noise of MR_simulator.py:73-83 for everything a
+// step returns or carries (tests/test_noise_law_cpu.py), not draw for draw.  Philox layout of block DYN(attempt):
+//   nominal:     call 0 = [policy words | z1],  call 1 = [F0 | z2],  call 2 = [K6 | F1]          (eager: calls 0, 1; 2 pairs)
+//   mismatched:  call 0 = [policy | z1a z1x],  call 1 = [z1y F0a | F0x F0y],  call 2 = [z2a z2x | z2y K6a],
+//                call 3 = [F1a F1x | F1y -],  call 4 = [K6x K6y | - -]                          (eager: calls 0..2; 5 pairs)
+constexpr float kCBf = 0.8641431770614779f;     // sqrt(sum_{2..5} B_i^2)
+constexpr float kCE1f = -0.05097452091652899f;  // sum_{2..5} B_i E_i / cB
+constexpr float kCE2f = 0.05594888714408681f;   // sqrt(sum_{2..5} E_i^2 - cE1^2)
 constexpr int kMaxAttempts = 4096;  // every lane leaves the loop: bounded spin
 // |z| of this generator never exceeds sqrt(-2 ln 2^-33) = 6.763 (u >= 2^-33); bound with margin
 constexpr double kZmaxE6 = 6.78 * (1.0 / 40);  // Zmax * E6
+constexpr double kZmaxE6C = 6.78 * (1.0 / 40 + 0.05594888714408681);  // collapsed law: Zmax * (E6 + cE2), z2 bounded like K6
 
 // weighted noise sums of one rk_step attempt:  nb = sum_{2..5} B_i N_i,  ne = sum_{2..6} E_i N_i,
 // n6 = N_6 (f_new's noise; only matters when another sub-step follows)
@@ -697,6 +722,8 @@ struct AttemptNoise {
     // nominal law: the E-weighted sums (ex32, ey32) are formed lazily (finish_e) from the kept stage normals kz; the
     // level-0 accept test only needs R32 = Zmax E6 + sum_{2..5} |E_i| r_i >= |sum_{2..6} E_i z_i| (r_i = the Box-Muller
     // radius of stage i: |z| = r |cos| <= r)
+    // collapsed law: kz[0..1] = z1 (x, y), (k6a, k6b) = the words of z2's pair (nominal; finish_e evaluates it),
+    // R32 = Zmax (E6 + cE2) + |cE1| r1
     float kz[8], R32;
     bool lazyE;
 };
@@ -711,6 +738,68 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         A.ex32 = A.ey32 = A.ea32 = 0.f; A.lazy6 = false;
         A.f0a = A.f0b = A.k6a = A.k6b = 0u; A.f0y = 0.f;
         A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u; A.have3 = false;
+        A.R32 = 0.f; A.lazyE = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) A.kz[j] = 0.f;
+        return A;
+    } else if constexpr (nz_coll(NZ) && !MIS) {
+        // collapsed nominal law: call 0 = [policy | z1], call 1 = [F0 | z2]; call 2 = [K6 | F1] is only fetched if K6 or F1 is
+        // ever needed.  TWO Philox calls and two Box-Muller pairs (z1 here, F0 in the constructor) per step in the common case.
+        uint32_t wl[3][4];
+        const uint32_t (*w)[4];
+        if constexpr (FIRST) {
+            w = reinterpret_cast<const uint32_t (*)[4]>(d0);
+            A.have3 = false;
+            A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u;
+        } else {
+            const uint32_t c0s[3] = {c0_of(kStreamDyn, attempt, 0), c0_of(kStreamDyn, attempt, 1), c0_of(kStreamDyn, attempt, 2)};
+            philox_multi<3>(R, c0s, wl);
+            w = wl;
+            A.have3 = true;
+            A.w3[0] = wl[2][0]; A.w3[1] = wl[2][1]; A.w3[2] = wl[2][2]; A.w3[3] = wl[2][3];
+        }
+        A.f0a = w[1][0]; A.f0b = w[1][1];
+        A.k6a = w[1][2]; A.k6b = w[1][3];   // z2's pair, evaluated by finish_e
+        A.f0y = 0.f; A.ea32 = 0.f;
+        float z1x, z1y, r1;
+        box_muller<NZ>(w[0][2], w[0][3], z1x, z1y, &r1);
+        A.bx32 = kCBf * z1x; A.by32 = kCBf * z1y; A.ba32 = 0.f;
+        // |S_E / sigma + E6 z6| <= |cE1| r1 + cE2 Zmax + E6 Zmax  (|z1| <= r1: the pair's radius)
+        A.R32 = __builtin_fmaf(-kCE1f, r1, (float)kZmaxE6C) * 1.0001f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) A.kz[j] = 0.f;
+        A.kz[0] = z1x; A.kz[1] = z1y;
+        A.lazyE = true;
+        A.ex32 = A.ey32 = 0.f;
+        A.nex = A.ney = 0.0; A.z6a = A.z6x = A.z6y = 0.f;
+        A.lazy6 = true;
+        return A;
+    } else if constexpr (nz_coll(NZ)) {
+        // collapsed mismatched law: calls 0..2 eager (five pairs: z1a z1x | z1y F0a | z2a z2x | z2y K6a here, F0x F0y in the
+        // constructor); K6's (x, y) pair (call 4) and F1 (call 3) stay lazy
+        uint32_t wl[3][4];
+        const uint32_t (*w)[4];
+        if constexpr (FIRST) {
+            w = reinterpret_cast<const uint32_t (*)[4]>(d0);
+        } else {
+            const uint32_t c0s[3] = {c0_of(kStreamDyn, attempt, 0), c0_of(kStreamDyn, attempt, 1), c0_of(kStreamDyn, attempt, 2)};
+            philox_multi<3>(R, c0s, wl);
+            w = wl;
+        }
+        A.have3 = false;
+        A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u;
+        A.f0a = w[1][2]; A.f0b = w[1][3]; A.k6a = A.k6b = 0u;
+        float z1a, z1x, z1y, z2a, z2x, z2y;
+        box_muller<NZ>(w[0][2], w[0][3], z1a, z1x);
+        box_muller<NZ>(w[1][0], w[1][1], z1y, A.f0y);      // f0y := F0's z_a (f0_normals)
+        box_muller<NZ>(w[2][0], w[2][1], z2a, z2x);
+        box_muller<NZ>(w[2][2], w[2][3], z2y, A.z6a);
+        A.ba32 = kCBf * z1a; A.bx32 = kCBf * z1x; A.by32 = kCBf * z1y;
+        A.ea32 = __builtin_fmaf(kE6f, A.z6a, __builtin_fmaf(kCE2f, z2a, kCE1f * z1a));
+        A.ex32 = __builtin_fmaf(kCE2f, z2x, kCE1f * z1x);
+        A.ey32 = __builtin_fmaf(kCE2f, z2y, kCE1f * z1y);
+        A.nex = A.ney = 0.0; A.z6x = A.z6y = 0.f;
+        A.lazy6 = true;
         A.R32 = 0.f; A.lazyE = false;
 #pragma unroll
         for (int j = 0; j < 8; ++j) A.kz[j] = 0.f;
@@ -808,8 +897,17 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
 
 
 // the E-weighted sums of stages 2..5 from the kept normals (same fp32 chain as the eager form had)
+template <int NZ>
 __device__ __forceinline__ void finish_e(AttemptNoise& A) {
     if (!A.lazyE) return;
+    if constexpr (nz_coll(NZ)) {  // S_E = cE1 z1 + cE2 z2: evaluate z2's pair
+        float z2x, z2y;
+        box_muller<NZ>(A.k6a, A.k6b, z2x, z2y);
+        A.ex32 = __builtin_fmaf(kCE2f, z2x, kCE1f * A.kz[0]);
+        A.ey32 = __builtin_fmaf(kCE2f, z2y, kCE1f * A.kz[1]);
+        A.lazyE = false;
+        return;
+    }
     float ex = kE2f * A.kz[0], ey = kE2f * A.kz[1];
     ex = __builtin_fmaf(kE3f, A.kz[2], ex); ey = __builtin_fmaf(kE3f, A.kz[3], ey);
     ex = __builtin_fmaf(kE4f, A.kz[4], ex); ey = __builtin_fmaf(kE4f, A.kz[5], ey);
@@ -823,11 +921,16 @@ template <int NZ, bool MIS>
 __device__ __forceinline__ void finish_k6(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, uint32_t attempt,
                                           AttemptNoise& A) {
     if constexpr (MIS) {
+        if constexpr (nz_coll(NZ)) {  // K6's (x, y) pair lives in call 4 of the block
+            uint32_t w4[4];
+            philox_call(R, c0_of(kStreamDyn, attempt, 4), w4);
+            A.k6a = w4[0]; A.k6b = w4[1];
+        }
         box_muller<NZ>(A.k6a, A.k6b, A.z6x, A.z6y);
         A.nex = __builtin_fma(C.gx, (double)A.ea32, P.sigma * (double)__builtin_fmaf(kE6f, A.z6x, A.ex32));
         A.ney = __builtin_fma(C.gy, (double)A.ea32, P.sigma * (double)__builtin_fmaf(kE6f, A.z6y, A.ey32));
     } else {
-        if (!A.have3) { philox_call(R, c0_of(kStreamDyn, attempt, 3), A.w3); A.have3 = true; }
+        if (!A.have3) { philox_call(R, c0_of(kStreamDyn, attempt, nz_coll(NZ) ? 2u : 3u), A.w3); A.have3 = true; }
         box_muller<NZ>(A.w3[0], A.w3[1], A.z6x, A.z6y);
         A.nex = P.sigma * (double)__builtin_fmaf(kE6f, A.z6x, A.ex32);
         A.ney = P.sigma * (double)__builtin_fmaf(kE6f, A.z6y, A.ey32);
@@ -904,11 +1007,11 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
                     if (__builtin_expect(accept_level0(P, A, dfx, dfy, h, l0, l1), 1)) { accepted = true; decided = true; }
                 }
                 if (!decided) {
-                    finish_e(A);
+                    finish_e<NZ>(A);
                     if (accept_level1<MIS>(P, C, A, dfx, dfy, h, l0, l1)) { accepted = true; decided = true; }
                 }
             }
-            if (!decided) finish_e(A);
+            if (!decided) finish_e<NZ>(A);
             if (!decided) finish_k6<NZ, MIS>(P, C, R, S.attempt - 1, A);
         }
     }
@@ -1024,11 +1127,10 @@ __device__ __forceinline__ bool rk45_fast_step(const KParams& P, const RhsCtx<MI
         acc = accept_level1<MIS>(P, C, A, dfx, dfy, h, l0, l1);  // the mismatched attempt forms its E sums eagerly
     }
     // RungeKutta.__init__ of the next step: f0 = simulate() with the F0 draws of this attempt's block
-    float z0, z1;
-    box_muller<NZ>(A.f0a, A.f0b, z0, z1);
+    float za, zx, zy;
+    f0_normals<NZ, MIS>(A.f0a, A.f0b, A.f0y, za, zx, zy);
     double f0x, f0y;
-    if constexpr (MIS) rhs_value<MIS>(P, C, z0, z1, A.f0y, f0x, f0y);
-    else rhs_value<MIS>(P, C, 0.f, z0, z1, f0x, f0y);
+    rhs_value<MIS>(P, C, za, zx, zy, f0x, f0y);
     const double sc0 = __builtin_fma(__builtin_fabs(xn), P.rtol, P.atol);
     const double sc1 = __builtin_fma(__builtin_fabs(yn), P.rtol, P.atol);
     const bool pass = construct_level0<MIS>(P, xn, yn, sc0, sc1, f0x, f0y, construct_gd_bound<MIS>(P, C));
@@ -1201,7 +1303,7 @@ __device__ __forceinline__ void action_from_words(const KParams& P, const uint32
 // carries the exploration policy's two words.  Later attempts (rare) and resets draw their own.
 template <bool RK45, int NZ, bool MIS>
 struct StepWords {
-    static constexpr int NDYN = (RK45 && NZ != kNoNoise) ? (MIS ? 5 : 3) : 0;
+    static constexpr int NDYN = (RK45 && NZ != kNoNoise) ? (nz_coll(NZ) ? (MIS ? 3 : 2) : (MIS ? 5 : 3)) : 0;
     static constexpr int N = NDYN > 0 ? NDYN : 1;  // the constructor's F0/F1 live in the DYN block too
     uint32_t w[N][4];
 };
@@ -1287,7 +1389,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     if constexpr (RK45) {
         bool fast = false;
         // (noise_math = spec is the test-oriented bit-exact mode: its long Box-Muller would only be duplicated)
-        if constexpr (NZ == kNoiseFast && MRSIM_FAST_STEP != 0) {
+        if constexpr (nz_fast(NZ) && MRSIM_FAST_STEP != 0) {
             if (!(fl & kFOutStatePrime)) fast = rk45_fast_step<NZ, MIS>(P, C, R, &W.w[0][0], e);
         }
 #ifdef MRSIM_BUDGET_BUILD  // tools/isa_budget.py only: drop the general path so that the time loop is the common path alone

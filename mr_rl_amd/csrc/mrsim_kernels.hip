@@ -31,7 +31,7 @@ struct ActorArgs {
 
 // Box-Muller flavour of the OU pair: the launch's own (fast / spec); sigma = 0 launches carry no noise code: spec
 template <int NZ>
-constexpr int ou_nz() { return NZ == kNoiseFast ? kNoiseFast : kNoiseSpec; }
+constexpr int ou_nz() { return nz_fast(NZ) ? kNoiseFast : kNoiseSpec; }
 
 // current observation of an env from its state: what the last step / reset returned (same expressions: equal bits)
 __device__ __forceinline__ void obs_from_state(const KParams& P, uint32_t fl, const float* __restrict__ goal_table,
@@ -333,6 +333,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     EnvRegs e;
 #ifdef MRSIM_WAVE_PROBE
     const unsigned long long clk0 = wall_clock64();
+    const unsigned long long cyc0 = __builtin_readcyclecounter();   // s_memtime: shader-clock cycles
 #endif
     load_env(st.pos, st.aux, st.ep_ret, i, P, e);
     // Consume the loaded state HERE.  Otherwise its first uses sit inside the time loop and so does their
@@ -342,6 +343,33 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     int fail = 0;
     const unsigned slot = hw_wave_slot();
     float* obs_lane = ra.obs_T != nullptr ? ra.obs_T + (blk0 + tid) * 5 : nullptr;  // row t = 0 of this lane's [N][5] record
+    // [N][5] observation rows leave a FULL wave as 16-byte stores of whole 128-byte lines: the wave's 64 rows (1280 contiguous
+    // bytes) are transposed through a wave-private LDS strip (row stride 5 dwords is coprime with the 32 banks: conflict-free
+    // ds_write_b32) and written by one dwordx4 store of all lanes + one of lanes 0..15.  Five dword stores per lane at a
+    // 20-byte lane stride write every line in five partial pieces; under load the pieces of a line do not always meet in L2
+    // before it is evicted, and the kernel then falls into a state ~1.5 x slower that lasts for hundreds of launches
+    // (profiles/r04/NOTES.md: bistable 93 / 145 us per launch with the collapsed noise law, never with [5][N] rows).
+    // Ragged last waves and rows that are not 16-byte aligned (a sub-shard that starts at an env id not divisible by 4) keep
+    // the per-lane dword stores.
+#ifndef MRSIM_OBS_STRIP   // A/B switch (tools/ab_rollout.py): 0 = five dword stores per lane for every wave
+#define MRSIM_OBS_STRIP 1
+#endif
+    constexpr bool kObsStrip = MRSIM_OBS_STRIP != 0 && (FL == 0 || ((FL & kFObsAos) != 0 && (FL & kFOutObs) != 0));
+    __shared__ __attribute__((aligned(16))) float s_obs_strip[kObsStrip ? BLOCK * 5 : 4];
+    const unsigned lane_id = tid & 63u;
+    float* const strip = s_obs_strip + (kObsStrip ? (tid & ~63u) * 5 : 0);
+    float* obs_wide = nullptr;   // this lane's 16-byte slot in row t of the wave's strip of [N][5] rows
+    bool wide = false;
+    if constexpr (kObsStrip) {
+        const uint32_t fl0 = FL != 0 ? FL : P.flags;
+        if ((fl0 & kFOutObs) && (fl0 & kFObsAos)) {
+            float* const wave_row0 = ra.obs_T + (blk0 + (tid & ~63u)) * 5;
+            wide = (blk0 + (long long)(tid | 63u)) < P.n && (reinterpret_cast<uintptr_t>(wave_row0) & 15u) == 0 &&
+                   (ra.row_stride & 3) == 0;
+            wide = __builtin_amdgcn_readfirstlane((int)wide) != 0;   // wave-uniform by construction: keep it in an SGPR
+            obs_wide = wave_row0 + lane_id * 4;
+        }
+    }
     // this lane's row of the goal table: two registers instead of an integer multiply-add and two 64-bit shifts per step
     const float2* goal_row = goal_row_of(P, FL != 0 ? FL : P.flags, ra.goal_table, P.env_id0 + (uint32_t)i);
     if constexpr (FL != 0 && (FL & kFGoalTable) != 0) __builtin_assume(goal_row != nullptr);   // (validated by the launcher)
@@ -476,9 +504,27 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
             if (fl & kFObsAos) {
                 // per-lane running pointer (one 64-bit add per step): `obs_T + (t * stride + blk0) * 5` would be a 64-bit
                 // multiply by 20 on the vector unit every step (two v_mad_u64_u32 + moves)
+                if (kObsStrip && wide) {
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                for (int j = 0; j < 5; ++j) __builtin_nontemporal_store(o.obs[j], &obs_lane[j]);
-                obs_lane += ra.row_stride * 5;
+                    for (int j = 0; j < 5; ++j) strip[lane_id * 5 + j] = o.obs[j];
+                    // same wave writes and reads: LDS executes a wave's instructions in order; the fence keeps the compiler
+                    // from moving the reads above the writes (different lanes' data: no dependence it can see)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(strip + lane_id * 4);
+                    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(obs_wide));
+                    if (lane_id < 16u) {
+                        const f32x4 v1 = *reinterpret_cast<const f32x4*>(strip + 256 + lane_id * 4);
+                        __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(obs_wide + 256));
+                    }
+                    obs_wide += ra.row_stride * 5;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) __builtin_nontemporal_store(o.obs[j], &obs_lane[j]);
+                    obs_lane += ra.row_stride * 5;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 5; ++j)
@@ -511,6 +557,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         ra.final_len[i + 1] = (int)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | ((32 - 1) << 11));
         ra.final_len[i + 2] = (int)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | ((32 - 1) << 11));
         ra.final_len[i + 3] = (int)(clk0 & 0x7fffffff);
+        ra.final_len[i + 4] = (int)(__builtin_readcyclecounter() - cyc0);   // / duration = the clock the wave really ran at
     }
 #endif
 }
@@ -677,6 +724,7 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
     if (p->sigma < 0.0 || std::isnan(p->sigma)) return MRSIM_EINVAL;
     std::memset(&K, 0, sizeof(K));
     if (p->noise_math != MRSIM_NOISE_FAST && p->noise_math != MRSIM_NOISE_SPEC) return MRSIM_EINVAL;
+    if (p->noise_law != MRSIM_LAW_PER_STAGE && p->noise_law != MRSIM_LAW_COLLAPSED) return MRSIM_EINVAL;
     K.dt = p->time_span; K.inv_dt = 1.0 / p->time_span; K.rtol = p->rtol; K.atol = p->atol; K.a0 = p->a0;
     K.sigma = p->sigma; K.sigma4 = p->sigma / 4;
     K.min_dist2 = p->min_dist2goal * p->min_dist2goal;
@@ -769,8 +817,13 @@ static int launch(const LaunchCfg& lc, Kern kern, long long n, Args... args) {
 // runtime (integrator, noise variant, mismatch) -> template instantiation
 static int noise_variant(const MrsimParams* p) {
     if (p->sigma == 0.0) return kNoNoise;
+    // the collapsed law re-defines the stage noise of an RK45 attempt; the fixed-step modes have no such attempt
+    if (p->noise_law == MRSIM_LAW_COLLAPSED && p->integrator == MRSIM_INT_RK45)
+        return p->noise_math == MRSIM_NOISE_SPEC ? kNoiseSpecC : kNoiseFastC;
     return p->noise_math == MRSIM_NOISE_SPEC ? kNoiseSpec : kNoiseFast;
 }
+// what the policy / OU / reset-only kernels need of it: the Box-Muller flavour
+static bool noise_fast(const MrsimParams* p) { return nz_fast(noise_variant(p)); }
 
 template <typename F>
 static int dispatch(bool rk45, int nz, bool mis, F&& f) {
@@ -784,7 +837,12 @@ static int dispatch(bool rk45, int nz, bool mis, F&& f) {
             default: return with_mis(RK, std::integral_constant<int, kNoiseFast>{});
         }
     };
-    return rk45 ? with_nz(std::true_type{}) : with_nz(std::false_type{});
+    if (!rk45) return with_nz(std::false_type{});
+    switch (nz) {   // the collapsed-law variants exist for the RK45 integrator only
+        case kNoiseSpecC: return with_mis(std::true_type{}, std::integral_constant<int, kNoiseSpecC>{});
+        case kNoiseFastC: return with_mis(std::true_type{}, std::integral_constant<int, kNoiseFastC>{});
+        default: return with_nz(std::true_type{});
+    }
 }
 
 // the gym loop's launch pattern: actions from a policy, [N][5] observations, auto-reset with terminal outputs
@@ -815,6 +873,9 @@ static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams&
     if ((K.flags & ~kFStepBase) == kFlGym && p->integrator == MRSIM_INT_RK45 && noise_variant(p) == kNoiseFast)
         return p->mismatched ? launch(lc, mr_step_kernel<true, kNoiseFast, true, true, kFlGym>, K.n, K, S, IO, AC)
                              : launch(lc, mr_step_kernel<true, kNoiseFast, false, true, kFlGym>, K.n, K, S, IO, AC);
+    if ((K.flags & ~kFStepBase) == kFlGym && p->integrator == MRSIM_INT_RK45 && noise_variant(p) == kNoiseFastC)
+        return p->mismatched ? launch(lc, mr_step_kernel<true, kNoiseFastC, true, true, kFlGym>, K.n, K, S, IO, AC)
+                             : launch(lc, mr_step_kernel<true, kNoiseFastC, false, true, kFlGym>, K.n, K, S, IO, AC);
     return dispatch(p->integrator == MRSIM_INT_RK45, noise_variant(p), p->mismatched != 0, [&](auto RK, auto NZ, auto MIS) {
         constexpr bool rk = decltype(RK)::value, mis = decltype(MIS)::value;
         constexpr int nz = decltype(NZ)::value;
@@ -865,6 +926,9 @@ static int launch_rollout_fl(const LaunchCfg& lc, int nz, bool mis, const KParam
     if (nz == kNoiseFast)
         return mis ? launch(lc, mr_rollout_kernel<true, kNoiseFast, true, FL>, K.n, K, S, ra)
                    : launch(lc, mr_rollout_kernel<true, kNoiseFast, false, FL>, K.n, K, S, ra);
+    if (nz == kNoiseFastC)
+        return mis ? launch(lc, mr_rollout_kernel<true, kNoiseFastC, true, FL>, K.n, K, S, ra)
+                   : launch(lc, mr_rollout_kernel<true, kNoiseFastC, false, FL>, K.n, K, S, ra);
     handled = false;  // sigma == 0 / noise_math = spec: generic kernel
     return MRSIM_OK;
 }
@@ -877,6 +941,9 @@ static int launch_rollout_actor_fl(const LaunchCfg& lc, int nz, bool mis, const 
     if (nz == kNoiseFast)
         return mis ? launch_b<B>(lc, mr_rollout_actor_fl_kernel<true, kNoiseFast, true, FL, ACT>, K.n, K, S, ra, AC)
                    : launch_b<B>(lc, mr_rollout_actor_fl_kernel<true, kNoiseFast, false, FL, ACT>, K.n, K, S, ra, AC);
+    if (nz == kNoiseFastC)
+        return mis ? launch_b<B>(lc, mr_rollout_actor_fl_kernel<true, kNoiseFastC, true, FL, ACT>, K.n, K, S, ra, AC)
+                   : launch_b<B>(lc, mr_rollout_actor_fl_kernel<true, kNoiseFastC, false, FL, ACT>, K.n, K, S, ra, AC);
     handled = false;
     return MRSIM_OK;
 }
@@ -964,7 +1031,7 @@ int mrsim_default_params(MrsimParams* p) {
     p->obs_layout = MRSIM_OBS_AOS;
     p->noise_math = MRSIM_NOISE_FAST;
     p->auto_reset_fresh_env = 0;            // auto-reset = the same env object re-used (RL/MR_ddpg.py:270)
-    p->reserved0 = 0;
+    p->noise_law = MRSIM_LAW_PER_STAGE;     // one draw per RHS evaluation, as MR_simulator.py:73-83
     p->step_base = nullptr;
     return MRSIM_OK;
 }
@@ -1258,7 +1325,7 @@ int mrsim_actor_forward(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     if ((rc = check_device())) return rc;
     K.flags |= abits;
     const LaunchCfg lc{static_cast<hipStream_t>(stream), nullptr, nullptr};
-    const bool fastnz = noise_variant(p) == kNoiseFast;
+    const bool fastnz = noise_fast(p);
     if (abits & kFActorBf16s) {
         if (fastnz) return launch(lc, mr_actor_kernel<kNoiseFast, kActBf16>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
         return launch(lc, mr_actor_kernel<kNoiseSpec, kActBf16>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);

@@ -266,6 +266,60 @@ static const double RK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 172
 #define MIS_POS_K6 17
 #define MIS_POS_F1 20
 
+/* ---- COLLAPSED noise law (OrcParams.noise_law = ORC_LAW_COLLAPSED; build extension, Philox source only).
+ * Per rk_step attempt the per-stage normals N_2..N_5 reach a result only through two weighted sums,
+ *   S_B = sum_{2..5} B_i N_i (the position)   and   S_E = sum_{2..5} E_i N_i (the error estimate),
+ * which per noise component (x, y and, under the mismatched law, the a0 draw) are jointly Gaussian with the
+ * fixed covariance of the tableau: var S_B = cB^2, var S_E = cE^2, corr = rho.  The collapsed law draws them
+ * directly:  S_B = cB z1,  S_E = cE1 z1 + cE2 z2  (cE1 = rho cE, cE2 = sqrt(1 - rho^2) cE), z1, z2 iid N(0,1)
+ * per component.  K6 (= f_new), F0 and F1 (the constructor's two RHS evaluations) keep their own draws.  Equal in
+ * law to MR_simulator.py:73-83's per-evaluation noise for everything a step returns or carries (positions,
+ * error_norm, accept/reject, step-size factors, integrator.f, h_abs, state_prime); NOT draw for draw: 6 (nominal)
+ * / 11 (mismatched) eager normals per attempt instead of 10 / 16.  A tape replay (the reference pin) ignores it.
+ *   NOMINAL, block DYN(attempt a), draw = 4*call + lane, Box-Muller pairs = consecutive even/odd draws:
+ *     0,1 policy words (dead as normals)   2,3 z1 (x, y)   4,5 F0   6,7 z2   8,9 K6   10,11 F1
+ *   MISMATCHED (z_a, z_x, z_y per evaluation):
+ *     0,1 policy   2,3,4 z1 (a, x, y)   5,6,7 F0   8,9,10 z2   11 K6a   12,13,14 F1   16,17 K6 (x, y)          */
+#define COL_CB  0.8641431770614779      /* sqrt(sum_{2..5} B_i^2)                         */
+#define COL_CE1 (-0.05097452091652899)  /* sum_{2..5} B_i E_i / cB                        */
+#define COL_CE2 0.05594888714408681     /* sqrt(sum_{2..5} E_i^2 - cE1^2)                 */
+#define CNOM_POS_Z1 2
+#define CNOM_POS_F0 4
+#define CNOM_POS_Z2 6
+#define CNOM_POS_K6 8
+#define CNOM_POS_F1 10
+#define CMIS_POS_Z1 2
+#define CMIS_POS_F0 5
+#define CMIS_POS_Z2 8
+#define CMIS_POS_K6A 11
+#define CMIS_POS_F1 12
+#define CMIS_POS_K6XY 16
+
+void orc_collapsed_constants(double out[3]) {
+    /* from the tableau, for the test that pins the literals above */
+    double sb = 0, se = 0, be = 0;
+    for (int i = 2; i < 6; ++i) { sb += RK_B[i] * RK_B[i]; se += RK_E[i] * RK_E[i]; be += RK_B[i] * RK_E[i]; }
+    const double cb = sqrt(sb), ce1 = be / cb;
+    out[0] = cb; out[1] = ce1; out[2] = sqrt(se - ce1 * ce1);
+}
+
+/* noise-free part V of simulate() and, under the mismatched law, the gain g of the a0 draw:
+ * K = V + (g z_a + sigma z_x, g' z_a + sigma z_y)   (MR_simulator.py:55-56,77-83) */
+static void rhs_mean(const OrcParams* p, int mismatched, const double act[2], double V[2], double G[2]) {
+    const double f_t = act[0], alpha_t = act[1];
+    if (mismatched) {
+        const double a0 = p->a0 + (f_t / 4) * 0.8;
+        V[0] = a0 * f_t * cos(alpha_t + 0.1) + 0.2;
+        V[1] = a0 * f_t * sin(alpha_t - 0.15) - 0.1;
+        G[0] = (p->sigma / 4) * f_t * cos(alpha_t + 0.1);
+        G[1] = (p->sigma / 4) * f_t * sin(alpha_t - 0.15);
+    } else {
+        V[0] = p->a0 * f_t * cos(alpha_t);
+        V[1] = p->a0 * f_t * sin(alpha_t);
+        G[0] = G[1] = 0.0;
+    }
+}
+
 static void rk45_construct(const OrcParams* p, int mismatched, OrcEnv* e, const double act[2], OrcNoise* nz,
                            uint32_t env_id, int stream, uint32_t block, int pos_f0, int pos_f1, int stream_f1) {
     NStream ns;
@@ -314,6 +368,7 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
     const int mis = p->mismatched;
     e->n_rhs = 0; e->n_attempts = 0;
     e->err_margin = INFINITY;
+    e->err_norm0 = 0.0;
     NStream ns;
 
     if (p->integrator != ORC_INT_RK45) {
@@ -349,6 +404,8 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
      * OdeSolver.step (base.py) + RungeKutta._step_impl (rk.py), direction = +1, max_step = inf */
     const double t_bound = e->t + p->time_span; /* set when the integrator was built, :49 */
     uint32_t attempt = 0;
+    /* the collapsed law re-defines where the Philox-sourced normals enter; a tape is consumed draw for draw, sigma = 0 draws nothing */
+    const int collapsed = p->noise_law == ORC_LAW_COLLAPSED && nz->kind == ORC_NOISE_PHILOX && p->sigma != 0.0;
     for (;;) {
         if (e->t == t_bound) break; /* OdeSolver.step corner case */
         const double t = e->t;
@@ -367,27 +424,58 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
             h_abs = fabs(h);
             /* rk_step: K[0] = f; K[s] = fun(...), s = 1..5; y_new = y + h*dot(K[:-1].T, B); K[6] = f_new */
             double K[7][2];
+            double s0 = 0, s1 = 0, e0 = 0, e1 = 0;
             K[0][0] = e->f[0]; K[0][1] = e->f[1];
             ns_open(&ns, nz, env_id, STREAM_DYN, attempt);
-            for (int s = 1; s < 6; ++s) {
-                simulate(p, mis, e, act, &ns, K[s]);
-                if (mis && s == 1) ns_seek(&ns, MIS_POS_K2); /* K1 has weight 0 in B and E */
+            if (collapsed) {
+                /* the stage sums of rk_step drawn directly (see COL_* above): with K_i = V + N_i, sum B = 1, sum E = 0,
+                 * B1 = E1 = 0:  dot(K[:-1].T, B) = B0 K0 + (1 - B0) V + S_B,  dot(K.T, E) = E0 (K0 - V) + S_E + E6 N_6 */
+                double V[2], G[2], z1[3], z2[3], z6[3];
+                rhs_mean(p, mis, act, V, G);
+                ns_seek(&ns, mis ? CMIS_POS_Z1 : CNOM_POS_Z1);
+                z1[0] = mis ? ns_normal(&ns, 1.0) : 0.0; z1[1] = ns_normal(&ns, 1.0); z1[2] = ns_normal(&ns, 1.0);
+                ns_seek(&ns, mis ? CMIS_POS_Z2 : CNOM_POS_Z2);
+                z2[0] = mis ? ns_normal(&ns, 1.0) : 0.0; z2[1] = ns_normal(&ns, 1.0); z2[2] = ns_normal(&ns, 1.0);
+                if (mis) {
+                    ns_seek(&ns, CMIS_POS_K6A); z6[0] = ns_normal(&ns, 1.0);
+                    ns_seek(&ns, CMIS_POS_K6XY); z6[1] = ns_normal(&ns, 1.0); z6[2] = ns_normal(&ns, 1.0);
+                } else {
+                    ns_seek(&ns, CNOM_POS_K6); z6[0] = 0.0; z6[1] = ns_normal(&ns, 1.0); z6[2] = ns_normal(&ns, 1.0);
+                }
+                for (int c = 0; c < 2; ++c) {
+                    const double sb = G[c] * (COL_CB * z1[0]) + p->sigma * (COL_CB * z1[1 + c]);
+                    const double se = G[c] * (COL_CE1 * z1[0] + COL_CE2 * z2[0]) +
+                                      p->sigma * (COL_CE1 * z1[1 + c] + COL_CE2 * z2[1 + c]);
+                    const double n6 = G[c] * z6[0] + p->sigma * z6[1 + c];
+                    fn[c] = V[c] + n6;                                           /* K[6] = f_new */
+                    const double sB = RK_B[0] * K[0][c] + (1.0 - RK_B[0]) * V[c] + sb;
+                    const double sE = RK_E[0] * (K[0][c] - V[c]) + se + RK_E[6] * n6;
+                    if (c == 0) { s0 = sB; e0 = sE; } else { s1 = sB; e1 = sE; }
+                }
+                e->state_prime[0] = fn[0]; e->state_prime[1] = fn[1];            /* last RHS evaluation of rk_step */
+                e->n_rhs += 6;
+            } else {
+                for (int s = 1; s < 6; ++s) {
+                    simulate(p, mis, e, act, &ns, K[s]);
+                    if (mis && s == 1) ns_seek(&ns, MIS_POS_K2); /* K1 has weight 0 in B and E */
+                }
+                for (int i = 0; i < 6; ++i) { s0 += K[i][0] * RK_B[i]; s1 += K[i][1] * RK_B[i]; }
             }
-            double s0 = 0, s1 = 0;
-            for (int i = 0; i < 6; ++i) { s0 += K[i][0] * RK_B[i]; s1 += K[i][1] * RK_B[i]; }
             yn0 = y0 + h * s0;
             yn1 = y1 + h * s1;
-            ns_seek(&ns, mis ? MIS_POS_K6 : NOM_POS_K6);
-            simulate(p, mis, e, act, &ns, fn);
-            K[6][0] = fn[0]; K[6][1] = fn[1];
+            if (!collapsed) {
+                ns_seek(&ns, mis ? MIS_POS_K6 : NOM_POS_K6);
+                simulate(p, mis, e, act, &ns, fn);
+                K[6][0] = fn[0]; K[6][1] = fn[1];
+                for (int i = 0; i < 7; ++i) { e0 += K[i][0] * RK_E[i]; e1 += K[i][1] * RK_E[i]; }
+            }
             attempt++; e->n_attempts++;
             /* scale = atol + max(|y|,|y_new|)*rtol; error_norm = norm(dot(K.T,E)*h/scale) */
             const double sc0 = p->atol + fmax(fabs(y0), fabs(yn0)) * p->rtol;
             const double sc1 = p->atol + fmax(fabs(y1), fabs(yn1)) * p->rtol;
-            double e0 = 0, e1 = 0;
-            for (int i = 0; i < 7; ++i) { e0 += K[i][0] * RK_E[i]; e1 += K[i][1] * RK_E[i]; }
             const double error_norm = rms2(e0 * h / sc0, e1 * h / sc1);
             if (fabs(error_norm - 1.0) < e->err_margin) e->err_margin = fabs(error_norm - 1.0);
+            if (e->n_attempts == 1) e->err_norm0 = error_norm;
             if (error_norm < 1) {
                 double factor = (error_norm == 0) ? RK_MAX_FACTOR
                                                   : fmin(RK_MAX_FACTOR, RK_SAFETY * pow(error_norm, RK_ERR_EXP));
@@ -405,6 +493,10 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
         if (e->t - t_bound >= 0) break; /* status = 'finished' */
     }
     /* last_state = integrator.y (:45); new RK45 from (t, y) to t + time_span (:46-50) */
+    if (collapsed)
+        rk45_construct(p, mis, e, act, nz, env_id, STREAM_DYN, attempt ? attempt - 1 : 0,
+                       mis ? CMIS_POS_F0 : CNOM_POS_F0, mis ? CMIS_POS_F1 : CNOM_POS_F1, -1);
+    else
     rk45_construct(p, mis, e, act, nz, env_id, STREAM_DYN, attempt ? attempt - 1 : 0,
                    mis ? MIS_POS_F0 : NOM_POS_F0, mis ? MIS_POS_F1 : NOM_POS_F1, -1);
     return 0;

@@ -35,6 +35,10 @@ extern "C" {
 enum { ORC_INT_RK45 = 0, ORC_INT_EULER = 1, ORC_INT_RK4 = 2 };
 enum { ORC_REW_CONSTANT10 = 0, ORC_REW_GOAL = 1 };
 enum { ORC_NOISE_NONE = 0, ORC_NOISE_PHILOX = 1, ORC_NOISE_TAPE = 2 };
+/* where the Philox-sourced normals of an RK45 step enter (mrsim_oracle.c, COL_*): PER_STAGE = one draw per RHS evaluation as
+ * MR_simulator.py:73-83 does (the parity mode); COLLAPSED = the B- and E-weighted stage sums drawn directly from their joint
+ * Gaussian -- equal in law, fewer draws (build extension; RK45 + Philox only, a tape replay and sigma = 0 ignore it) */
+enum { ORC_LAW_PER_STAGE = 0, ORC_LAW_COLLAPSED = 1 };
 
 typedef struct {
     double time_span;      /* 0.030                      MR_simulator.py:12            */
@@ -58,7 +62,7 @@ typedef struct {
     int32_t auto_reset_fresh_env; /* 0: an auto-reset is reset() on the SAME env object (RL/MR_ddpg.py:270): the RK45   */
                            /*    constructor runs under the law the previous episode left (MR_env.py:181-183);     */
                            /*    1: a fresh MR_Env per episode (nominal-law constructor)                           */
-    int32_t reserved0;
+    int32_t noise_law;     /* ORC_LAW_*                                                  */
 } OrcParams;
 
 /* One environment = one MR_Env + its Simulator + its live RK45 object. */
@@ -69,6 +73,7 @@ typedef struct {
     double h_abs;          /* integrator.h_abs                                          */
     double state_prime[2]; /* Simulator.state_prime = last RHS value (MR_simulator.py:87) */
     double ep_ret;         /* sum of rewards this episode (build extension)             */
+    double err_norm0;      /* diagnostic: error_norm of the last step's FIRST rk_step attempt                  */
     double err_margin;     /* diagnostic: min over the last step's rk_step attempts of |error_norm - 1|, the   */
                            /*   distance of the accept / reject decision from its discontinuity (tests use it  */
                            /*   to tell a genuine decision flip from a kernel bug)                             */
@@ -89,6 +94,8 @@ typedef struct {
 } OrcNoise;
 
 void orc_default_params(OrcParams* p);
+/* {cB, cE1, cE2} of the collapsed law recomputed from the tableau (pins the literals in mrsim_oracle.c / mrsim_device.h) */
+void orc_collapsed_constants(double out[3]);
 
 /* RNG definition (build's own; shared by spec with the HIP kernel) */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

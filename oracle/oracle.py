@@ -16,6 +16,7 @@ _LIB_PATH = os.environ.get("MRSIM_ORACLE_LIB") or os.path.join(_HERE, "libmrsim_
 INT_RK45, INT_EULER, INT_RK4 = 0, 1, 2
 REW_CONSTANT10, REW_GOAL = 0, 1
 NOISE_NONE, NOISE_PHILOX, NOISE_TAPE = 0, 1, 2
+LAW_PER_STAGE, LAW_COLLAPSED = 0, 1
 STREAM_DYN, STREAM_CTOR, STREAM_RESET_POS, STREAM_RESET_CTOR, STREAM_POLICY = 0, 1, 2, 3, 4
 
 
@@ -27,21 +28,21 @@ class OrcParams(C.Structure):
         ("init_low", C.c_double * 2), ("init_high", C.c_double * 2),
         ("mismatched", C.c_int32), ("integrator", C.c_int32), ("substeps", C.c_int32),
         ("reward_mode", C.c_int32), ("max_timesteps", C.c_int32), ("auto_reset", C.c_int32),
-        ("goal_K", C.c_int32), ("goal_T", C.c_int32), ("auto_reset_fresh_env", C.c_int32), ("reserved0", C.c_int32),
+        ("goal_K", C.c_int32), ("goal_T", C.c_int32), ("auto_reset_fresh_env", C.c_int32), ("noise_law", C.c_int32),
     ]
 
 
 class OrcEnv(C.Structure):
     _fields_ = [
         ("y", C.c_double * 2), ("t", C.c_double), ("f", C.c_double * 2), ("h_abs", C.c_double),
-        ("state_prime", C.c_double * 2), ("ep_ret", C.c_double), ("err_margin", C.c_double),
+        ("state_prime", C.c_double * 2), ("ep_ret", C.c_double), ("err_norm0", C.c_double), ("err_margin", C.c_double),
         ("counter", C.c_int32), ("n_rhs", C.c_int32), ("n_attempts", C.c_int32), ("status", C.c_int32),
     ]
 
 
 ENV_DTYPE = np.dtype([
     ("y", "<f8", 2), ("t", "<f8"), ("f", "<f8", 2), ("h_abs", "<f8"), ("state_prime", "<f8", 2),
-    ("ep_ret", "<f8"), ("err_margin", "<f8"), ("counter", "<i4"), ("n_rhs", "<i4"), ("n_attempts", "<i4"), ("status", "<i4"),
+    ("ep_ret", "<f8"), ("err_norm0", "<f8"), ("err_margin", "<f8"), ("counter", "<i4"), ("n_rhs", "<i4"), ("n_attempts", "<i4"), ("status", "<i4"),
 ])
 
 

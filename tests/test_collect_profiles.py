@@ -7,9 +7,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRIPT = os.path.join(ROOT, "tools", "collect_profiles.py")
-EXPECTED = ["kt", "kt_s1", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
-                                             for p in ("pmc_f64", "pmc_f32", "pmc_step", "cal", "cal262k")] + \
-           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")] + \
+EXPECTED = ["kt", "kt_s1", "kt_s1_ps", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
+                                             for p in ("pmc_f64", "pmc_f32", "pmc_ps_f64", "pmc_step", "cal", "cal262k")] + \
+           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32", "ps")] + \
            ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed",
             "kt_actor_bf", "pmc_actor_bf_a", "kt_actor_b1", "pmc_actor_b1_a"]
 

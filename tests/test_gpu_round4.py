@@ -1,0 +1,217 @@
+"""GPU tests of round 4: the COLLAPSED noise law (MrsimParams.noise_law, include/mrsim.h) through the C ABI against the
+oracle's restatement of the same law (oracle/mrsim_oracle.c: COL_*) on identical seeds -- element-wise, like the per-stage
+law's tests in test_gpu_parity.py -- and against the reference's own increment samples (tests/golden/ref_increments.npz).
+
+Tolerances as in test_gpu_parity.py: positions 1e-6 (noise_math="spec": normals bit-identical to the oracle's) / 5e-6
+("fast"); observations within 2 ulp_f32; reward / done / counter exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import orc_params_from_cfg
+
+pytestmark = pytest.mark.gpu
+POS_TOL, POS_TOL_FAST = 1e-6, 5e-6
+
+
+def _mk(n, seed=0, goal_table=None, env_id0=0, threads=8, **cfg_kw):
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    cfg = MRConfig(**cfg_kw)
+    env = MRVecEnv(n, cfg=cfg, seed=seed, goal_table=goal_table, env_id0=env_id0, track_state_prime=True, track_actions=True)
+    gK, gT = (1, 1) if goal_table is None else (env._gK, env._gT)
+    orc = O.VecOracle(n, orc_params_from_cfg(cfg, gK, gT), seed=seed, env_id0=env_id0, threads=threads,
+                      goal_table=None if goal_table is None else np.asarray(goal_table, dtype=np.float32).reshape(gK, gT, 2))
+    return torch, env, orc
+
+
+def _f32_close(got, want64, extra=POS_TOL):
+    want = want64.astype(np.float32)
+    tol = 2 * np.spacing(np.abs(want).astype(np.float32)) + extra
+    assert np.all(np.abs(got.astype(np.float64) - want.astype(np.float64)) <= tol), f"max diff {np.abs(got - want).max()}"
+
+
+def _threads():
+    return max(1, min(64, len(os.sched_getaffinity(0))))
+
+
+# ---------------------------------------------------------------------------
+# collapsed law: kernel vs oracle, step by step
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("math", ["spec", "fast"])
+@pytest.mark.parametrize("mis", [False, True])
+def test_collapsed_step_vs_oracle_far(mis, math):
+    """sigma = 1 in the DDPG regime, one launch per step, state_prime tracked (the general path + F1's lazy call)."""
+    n, T = 2048 + 37, 60
+    tol = POS_TOL if math == "spec" else POS_TOL_FAST
+    torch, env, orc = _mk(n, seed=2024, noise_var=1.0, is_mismatched=mis, noise_math=math, noise_law="collapsed")
+    og = env.reset(); oo = orc.reset(0)
+    _f32_close(og.cpu().numpy(), oo, extra=0)
+    rng = np.random.default_rng(1)
+    for t in range(T):
+        a = np.stack([rng.uniform(-20, 20, n), rng.uniform(-2 * np.pi, 2 * np.pi, n)], 1).astype(np.float32)
+        env.step(a); orc.step(a, step_idx=t + 1)
+        np.testing.assert_allclose(env.pos.cpu().numpy(), orc.envs["y"], rtol=0, atol=tol)
+        _f32_close(env.obs.cpu().numpy(), orc.obs, extra=tol)
+        np.testing.assert_array_equal(env.done.cpu().numpy().astype(np.uint8), orc.done)
+        np.testing.assert_allclose(env.state_prime.cpu().numpy(), orc.envs["state_prime"], rtol=2e-6, atol=2e-5)
+        np.testing.assert_allclose(env.aux[:, :2].cpu().numpy(), orc.envs["f"], rtol=2e-6, atol=2e-5)
+    assert (orc.envs["n_attempts"] == 1).all()
+    env.check_status()
+
+
+def test_collapsed_law_differs_from_per_stage_law():
+    """same seed, different law: different numbers (the two are equal in distribution only), same exploration actions"""
+    n = 4096
+    torch, e1, _ = _mk(n, seed=3, noise_var=1.0, auto_reset=True)
+    _, e2, _ = _mk(n, seed=3, noise_var=1.0, auto_reset=True, noise_law="collapsed")
+    e1.reset(); e2.reset()
+    o1 = e1.rollout(20, want=("obs", "actions"))
+    o2 = e2.rollout(20, want=("obs", "actions"))
+    assert torch.equal(o1["actions"], o2["actions"])
+    assert not torch.equal(o1["obs"], o2["obs"])
+    assert float((o1["obs"][..., :2] - o2["obs"][..., :2]).abs().max()) < 1.0
+
+
+@pytest.mark.parametrize("mis", [False, True])
+def test_collapsed_step_vs_oracle_near_origin(mis):
+    """sigma > 0 near the origin under the collapsed law: tens of rk_step attempts per step (the later attempts draw their own
+    three calls, evaluate z2 and K6 eagerly).  Same acceptance rule as test_gpu_parity.py's per-stage twin: an env may only leave
+    the tolerance at a step where the oracle saw an accept / reject decision within 1e-6 of its discontinuity."""
+    n, T = 4096, 25
+    torch, env, orc = _mk(n, seed=7, noise_var=0.5, noise_math="spec", is_mismatched=mis, noise_law="collapsed")
+    rng = np.random.default_rng(3)
+    init = rng.uniform(-0.5, 0.5, (n, 2))
+    env.reset(init=init); orc.reset(0, init_xy=init)
+    alive = np.ones(n, bool)
+    unexplained, multi = [], 0
+    for t in range(T):
+        a = np.stack([rng.uniform(0, 20, n), rng.uniform(0, 2 * np.pi, n)], 1).astype(np.float32)
+        env.step(a); orc.step(a, step_idx=t + 1)
+        pos = env.pos.cpu().numpy()
+        assert np.isfinite(pos).all()
+        bad = alive & (np.abs(pos - orc.envs["y"]).max(axis=1) > POS_TOL)
+        for i in np.nonzero(bad)[0]:
+            if not (orc.envs["err_margin"][i] < 1e-6):
+                unexplained.append((t, int(i), float(orc.envs["err_margin"][i]), int(orc.envs["n_attempts"][i])))
+        alive &= ~bad
+        multi += int((orc.envs["n_attempts"][alive] > 1).sum())
+        np.testing.assert_array_equal(env.counter.cpu().numpy()[alive], orc.envs["counter"][alive])
+        sp = env.state_prime.cpu().numpy()
+        np.testing.assert_allclose(sp[alive], orc.envs["state_prime"][alive], rtol=2e-6, atol=2e-5)
+    assert not unexplained, f"(step, env, margin, attempts): {unexplained[:8]}"
+    assert alive.mean() >= 0.99, alive.mean()
+    assert multi > 1000
+    env.check_status()
+
+
+@pytest.mark.parametrize("mis", [False, True])
+@pytest.mark.parametrize("carry", ["f32", "f64"])
+def test_collapsed_rollout_equals_steps(mis, carry):
+    """fused rollout (flag-specialised and generic kernels) vs single steps under the collapsed law: bitwise with the fp32
+    carry, 1e-6 with the fp64 carry"""
+    n, T = 3000, 60
+    torch, e1, _ = _mk(n, seed=5, noise_var=1.0, auto_reset=True, is_mismatched=mis, noise_law="collapsed")
+    from mr_rl_amd import MRConfig, MRVecEnv
+    e2 = MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True, is_mismatched=mis, noise_law="collapsed"), seed=5)
+    e1.reset(); e2.reset()
+    out = e2.rollout(T, want=("obs", "rew", "done", "actions"), carry=carry)
+    for t in range(T):
+        o, r, d, _ = e1.step(out["actions"][t])
+        if carry == "f32":
+            assert torch.equal(o, out["obs"][t]) and torch.equal(d, out["done"][t].bool())
+        else:
+            assert float((o - out["obs"][t]).abs().max()) < 2e-5
+    if carry == "f32":
+        assert torch.equal(e1.pos, e2.pos) and torch.equal(e1.aux, e2.aux)
+    else:
+        assert float((e1.pos - e2.pos).abs().max()) < 1e-6
+
+
+# ---------------------------------------------------------------------------
+# collapsed law at BASELINE's full sizes, element-wise against the oracle
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("math,mis,carry", [("fast", False, "f64"), ("spec", False, "f32"), ("fast", True, "f64"),
+                                            ("fast", False, "f32")])
+def test_full_size_rollout_vs_oracle_config4_collapsed(math, mis, carry):
+    """BASELINE config 4 (262 144 envs, sigma = 1, exploration policy on device, one episode + the auto-reset step) through
+    the flag-specialised rollout kernel with noise_law = collapsed against the oracle with the same law: every action
+    bit-equal, every observation / reward / done of all 52 steps, final state."""
+    n, T = 262144, 52
+    tol = POS_TOL if math == "spec" else POS_TOL_FAST
+    torch, env, orc = _mk(n, seed=7, threads=_threads(), noise_var=1.0, auto_reset=True, noise_math=math, is_mismatched=mis,
+                          noise_law="collapsed")
+    og = env.reset(); oo = orc.reset(0)
+    _f32_close(og.cpu().numpy(), oo, extra=0)
+    out = env.rollout(T, actions=None, want=("obs", "rew", "done", "actions"), carry=carry)
+    obs, rew, done, act = (out[k].cpu().numpy() for k in ("obs", "rew", "done", "actions"))
+    for t in range(T):
+        a = orc.random_policy(t + 1, env.cfg.policy_low, env.cfg.policy_high)
+        np.testing.assert_array_equal(act[t], a)
+        orc.step(a, step_idx=t + 1)
+        np.testing.assert_array_equal(done[t].astype(np.uint8), orc.done)
+        np.testing.assert_array_equal(rew[t], orc.rew.astype(np.float32))
+        _f32_close(obs[t], orc.obs, extra=tol)
+    assert done[50].all() and not done[:50].any() and not done[51].any()
+    np.testing.assert_allclose(env.pos.cpu().numpy(), orc.envs["y"], rtol=0, atol=tol)
+    np.testing.assert_array_equal(env.counter.cpu().numpy(), orc.envs["counter"])
+    np.testing.assert_array_equal(env.final_len.cpu().numpy(), orc.final_len)
+    np.testing.assert_allclose(env.final_ret.cpu().numpy(), orc.final_ret, rtol=1e-6)
+    assert (orc.envs["n_attempts"] == 1).mean() > 0.999
+    env.check_status()
+
+
+@pytest.mark.parametrize("mis", [False, True])
+def test_full_size_config5_shard_collapsed(mis):
+    """one rank's shard of BASELINE config 5 (mixed trajectory set, goal reward, offset env ids: the reset cache of the
+    goal-table rollout kernel) under the collapsed law, element-wise against the oracle"""
+    n, T, id0 = 262144, 52, 3 * 262144
+    k = np.arange(52)
+    tab = np.zeros((3, 52, 2), dtype=np.float32)
+    tab[0, :, 0] = 110 + 0.3 * k; tab[0, :, 1] = 110 + 0.3 * k
+    th = 2 * np.pi * k / 52
+    tab[1, :, 0] = 110 + 8 * np.sin(th); tab[1, :, 1] = 110 + 8 * np.sin(th) * np.cos(th)
+    tab[2] = np.random.default_rng(7).uniform(100, 120, (52, 2))
+    torch, env, orc = _mk(n, seed=7, goal_table=tab, env_id0=id0, threads=_threads(), noise_var=1.0, auto_reset=True,
+                          reward_mode="goal", min_dist2goal=1.0, noise_law="collapsed", is_mismatched=mis)
+    og = env.reset(); oo = orc.reset(0)
+    _f32_close(og.cpu().numpy(), oo, extra=0)
+    out = env.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
+    obs, rew, done, act = (out[q].cpu().numpy() for q in ("obs", "rew", "done", "actions"))
+    for t in range(T):
+        a = orc.random_policy(t + 1, env.cfg.policy_low, env.cfg.policy_high)
+        np.testing.assert_array_equal(act[t], a)
+        orc.step(a, step_idx=t + 1)
+        np.testing.assert_array_equal(done[t].astype(np.uint8), orc.done)
+        np.testing.assert_array_equal(rew[t], orc.rew.astype(np.float32))
+        _f32_close(obs[t], orc.obs, extra=POS_TOL_FAST)
+    np.testing.assert_allclose(env.pos.cpu().numpy(), orc.envs["y"], rtol=0, atol=POS_TOL_FAST)
+    np.testing.assert_array_equal(env.final_len.cpu().numpy(), orc.final_len)
+    assert done.sum() > n      # episodes end at different steps on this set
+    env.check_status()
+
+
+def test_collapsed_increment_law_full_size():
+    """N = 262 144 under the collapsed law through a size-independent property: per-step noise increment
+    Delta - dt (b1 K0 + (1 - b1) V) ~ N(0, (dt sigma cB)^2) per axis (SURVEY 3.3 with b1's share carried in K0)."""
+    from scipy import stats
+    n, T, sigma = 262144, 8, 1.0
+    torch, env, _ = _mk(n, seed=99, noise_var=sigma, noise_law="collapsed")
+    env.reset()
+    dt, b1, cB = 0.030, 35.0 / 384, 0.8641431770614779
+    rng = np.random.default_rng(0)
+    for t in range(T):
+        a = np.stack([rng.uniform(-20, 20, n), rng.uniform(-2 * np.pi, 2 * np.pi, n)], 1).astype(np.float32)
+        prev, k0 = env.pos.cpu().numpy().copy(), env.aux[:, :2].cpu().numpy().astype(np.float64)
+        env.step(a)
+        a64 = a.astype(np.float64)
+        V = np.stack([a64[:, 0] * np.cos(a64[:, 1]), a64[:, 0] * np.sin(a64[:, 1])], 1)
+        r = (env.pos.cpu().numpy() - prev - dt * (b1 * k0 + (1 - b1) * V)) / (dt * sigma * cB)
+        for j in range(2):
+            assert abs(r[:, j].mean()) < 0.01 and abs(r[:, j].std() - 1.0) < 0.01
+            assert stats.kstest(r[::8, j], "norm").pvalue > 1e-4
+        assert abs(np.corrcoef(r[:, 0], r[:, 1])[0, 1]) < 0.01
+    env.check_status()

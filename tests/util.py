@@ -26,7 +26,8 @@ def orc_params_from_cfg(cfg, goal_K=1, goal_T=1):
         init_low=cfg.init_low, init_high=cfg.init_high, mismatched=int(cfg.is_mismatched),
         integrator=INTEGRATORS[cfg.integrator], substeps=cfg.substeps, reward_mode=REWARD_MODES[cfg.reward_mode],
         max_timesteps=cfg.max_timesteps, auto_reset=int(cfg.auto_reset), goal_K=goal_K, goal_T=goal_T,
-        auto_reset_fresh_env=int(cfg.auto_reset_env == "fresh"))
+        auto_reset_fresh_env=int(cfg.auto_reset_env == "fresh"),
+        noise_law=int(getattr(cfg, "noise_law", "per_stage") == "collapsed"))
 
 
 def actions_figure8(T=1000):

@@ -22,12 +22,13 @@ ap.add_argument("--discard", type=int, default=100, help="leading launches of ev
 ap.add_argument("--envs", type=int, default=262144)
 ap.add_argument("--workload", default="ddpg")
 ap.add_argument("--mismatched", action="store_true")
+ap.add_argument("--noise-law", default="per_stage")
 a = ap.parse_args()
 T, WANT = 51, ("obs", "rew", "done", "actions")
 envs = []
 for v in a.variants:
     tag, _, carry = v.partition(":")
-    cfg = MRConfig(noise_var=1.0, auto_reset=True, seed=7, is_mismatched=a.mismatched, rollout_carry=carry or "f32")
+    cfg = MRConfig(noise_var=1.0, auto_reset=True, seed=7, is_mismatched=a.mismatched, rollout_carry=carry or "f32", noise_law=a.noise_law)
     tab = None
     if a.workload == "mixed":
         sys.path.insert(0, ROOT)

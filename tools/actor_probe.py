@@ -20,13 +20,14 @@ ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16"])
 ap.add_argument("--power", type=float, default=0.0, help="also run back to back for this many seconds and report package power / clock (hwmon)")
 ap.add_argument("--streams", type=int, nargs="*", default=[], help="also time the RolloutCollector (wall clock) with these stream counts")
 ap.add_argument("--mismatched", action="store_true")
+ap.add_argument("--noise-law", default="collapsed", choices=["collapsed", "per_stage"], help="bench.py's default law is collapsed")
 a = ap.parse_args()
 T, WANT = 51, ("obs", "rew", "done", "actions")
 torch.manual_seed(0)
 module = Actor().eval()
 flop = 2 * (5 * 64 + 64 * 64 + 64 * 2)
 for tag in (a.variants or [None]):
-    cfg = MRConfig(noise_var=1.0, auto_reset=True, seed=7, is_mismatched=a.mismatched)
+    cfg = MRConfig(noise_var=1.0, auto_reset=True, seed=7, is_mismatched=a.mismatched, noise_law=a.noise_law)
     e = MRVecEnv(a.envs, cfg=cfg, seed=7)
     if tag is not None:
         e._L = _lib.load(os.path.join(ROOT, "mr_rl_amd", "variants", f"libmrsim_{tag}.so"))
@@ -66,7 +67,7 @@ for tag in (a.variants or [None]):
     for S in a.streams:
         import time
         from mr_rl_amd.collector import RolloutCollector
-        col = RolloutCollector(a.envs, cfg=MRConfig(noise_var=1.0, auto_reset=True, seed=7, is_mismatched=a.mismatched), seed=7,
+        col = RolloutCollector(a.envs, cfg=MRConfig(noise_var=1.0, auto_reset=True, seed=7, is_mismatched=a.mismatched, noise_law=a.noise_law), seed=7,
                                streams=S, policy=act)
         col.env._L = e._L
         col.reset()

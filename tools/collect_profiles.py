@@ -33,9 +33,11 @@ def sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
-EXPECTED = ["kt", "kt_s1", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
-                                             for p in ("pmc_f64", "pmc_f32", "pmc_step", "cal", "cal262k")] + \
-           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32")] + \
+# bench.py's default noise law is "collapsed" (kernel template argument NZ = 4); "_ps" passes = the per-stage law (NZ = 2)
+LAW_NZ = {"collapsed": 4, "per_stage": 2}
+EXPECTED = ["kt", "kt_s1", "kt_s1_ps", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
+                                             for p in ("pmc_f64", "pmc_f32", "pmc_ps_f64", "pmc_step", "cal", "cal262k")] + \
+           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32", "ps")] + \
            ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed",
             "kt_actor_bf", "pmc_actor_bf_a", "kt_actor_b1", "pmc_actor_b1_a"]
 if not os.path.exists(f"{src}/status.txt"):
@@ -87,6 +89,11 @@ stamp = {"bench_py_sha16": here["bench.py"], "libmrsim_so_sha16": here["libmrsim
 files = {}
 files["kernel_stats_bench_rollout.csv"] = open(the_csv("kt", "kernel_stats.csv")).read()
 files["kernel_stats_bench_rollout_streams1.csv"] = open(the_csv("kt_s1", "kernel_stats.csv")).read()
+files["kernel_stats_bench_rollout_streams1_per_stage.csv"] = open(the_csv("kt_s1_ps", "kernel_stats.csv")).read()
+line_ps = [l for l in open(f"{src}/kt_s1_ps.out").read().splitlines() if l.startswith("{")]
+if not line_ps:
+    die("kt_s1_ps.out holds no bench JSON line")
+files["bench_under_rocprof_rollout_streams1_per_stage.json"] = line_ps[-1] + "\n"
 files["kernel_stats_bench_step.csv"] = open(the_csv("kt_step", "kernel_stats.csv")).read()
 line1 = [l for l in open(f"{src}/kt_s1.out").read().splitlines() if l.startswith("{")]
 if not line1:
@@ -102,7 +109,7 @@ inst = json.load(open(f"{src}/instbench.out"))
 kt1 = the_csv("kt_s1", "kernel_trace.csv")
 d1 = json.loads(line1[-1])
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt1))
-       if "mr_rollout_kernel<true, 2, false, 7" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == N]
+       if "mr_rollout_kernel<true, 4, false, 7" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == N]
 seq = [("settle", 400), ("warm-up", d1["warmup"] // T), ("timed (the contract's region)", d1["steps"] // T),
        ("pre-roll of the sustained leg", d1["sustained"].get("preroll_episodes", 0)), ("sustained", d1["sustained"]["steps"] // T)]
 if sum(n for _, n in seq) != len(dur):
@@ -139,10 +146,11 @@ for label, d, n in (("membench pattern<256> n=16777216", "cal", 16777216), ("mem
     traffic["calibration"][label] = {"known_read_KiB": n * 44 / 1024, "FETCH_SIZE_raw_KiB": fr["FETCH_SIZE"],
                                      "FETCH_SIZE_x2_KiB": 2 * fr["FETCH_SIZE"], "known_write_KiB": n * 61 / 1024,
                                      "WRITE_SIZE_KiB": wr["WRITE_SIZE"], "source": [prov(f1), prov(f2)]}
-for label, pre, sub, units, carry in (
-        (f"mr_rollout_kernel<RK45,fast,nominal,carry=f64> T={T} N={N}", "pmc_f64", "mr_rollout_kernel<true, 2, false", N * T, "f64"),
-        (f"mr_rollout_kernel<RK45,fast,nominal,carry=f32> T={T} N={N}", "pmc_f32", "mr_rollout_kernel<true, 2, false", N * T, "f32"),
-        (f"mr_step_kernel<RK45,fast,nominal,aos> N={N}", "pmc_step", "mr_step_kernel<true, 2, false, true", N, None)):
+for label, pre, sub, units, carry, law in (
+        (f"mr_rollout_kernel<RK45,fast+collapsed,nominal,carry=f64> T={T} N={N}", "pmc_f64", "mr_rollout_kernel<true, 4, false", N * T, "f64", "collapsed"),
+        (f"mr_rollout_kernel<RK45,fast+collapsed,nominal,carry=f32> T={T} N={N}", "pmc_f32", "mr_rollout_kernel<true, 4, false", N * T, "f32", "collapsed"),
+        (f"mr_rollout_kernel<RK45,fast,nominal,carry=f64> T={T} N={N}", "pmc_ps_f64", "mr_rollout_kernel<true, 2, false", N * T, "f64", "per_stage"),
+        (f"mr_step_kernel<RK45,fast+collapsed,nominal,aos> N={N}", "pmc_step", "mr_step_kernel<true, 4, false, true", N, None, "collapsed")):
     fr, nf, _, f1 = counters(f"{pre}_FETCH_SIZE", sub)
     wr, nw, _, f2 = counters(f"{pre}_WRITE_SIZE", sub)
     b = (2 * fr["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024
@@ -151,6 +159,7 @@ for label, pre, sub, units, carry in (
          "traffic_over_algorithmic": b / (units * ALGO), "bytes_per_env_step": b / units, "source": [prov(f1), prov(f2)]}
     if carry:
         k["carry"] = carry
+    k["noise_law"] = law
     traffic["kernels"][label] = k
 files["pmc_traffic.json"] = json.dumps(traffic, indent=1) + "\n"
 
@@ -188,10 +197,10 @@ valu = {"what": "rocprofv3 --pmc SQ counters of the fused rollout kernel per wav
                         "w4": {op: {"cycles": cost[op][4]["cycles"], "ns": cost[op][4]["ns"]}
                                for op in sorted(set(CLASS_OP.values()) | {"v_xor_b32"})}},
         "kernels": {}}
-for carry in ("f64", "f32"):
+for carry, law, tagp in (("f64", "collapsed", "f64"), ("f32", "collapsed", "f32"), ("f64", "per_stage", "ps")):
     per, srcs = {}, []
     for g in "abc":
-        c, nd, grid, f = counters(f"valu_{g}_{carry}", "mr_rollout_kernel<true, 2, false")
+        c, nd, grid, f = counters(f"valu_{g}_{tagp}", f"mr_rollout_kernel<true, {LAW_NZ[law]}, false")
         srcs.append(prov(f))
         for k, v in c.items():
             per[k] = v / (grid / 64) / T
@@ -202,10 +211,11 @@ for carry in ("f64", "f32"):
         fl[unit] = sum(per[k] * cost[op][4][unit] for k, op in CLASS_OP.items()) + other * cost["v_xor_b32"][4][unit]
     wave_cycles = 4.0 * per["SQ_WAVE_CYCLES"]
     spec_floor = sum(per[k] * SPEC_CYCLES[k] for k in CLASS_OP) + other * SPEC_CYCLES["other"]
-    valu["kernels"]["rollout_" + carry] = {
+    valu["kernels"]["rollout_" + carry + ("" if law == "per_stage" else "_" + law)] = {
+        "noise_law": law,
         "issue_floor_cycles_per_wave_step_at_spec_rates": round(spec_floor, 1),
         "valu_issue_frac_at_spec_rates": round(WPS * spec_floor / wave_cycles, 4),
-        "kernel": f"mr_rollout_kernel<RK45,fast,nominal,carry={carry}>", "per_wave_step": {k: round(v, 2) for k, v in sorted(per.items())},
+        "kernel": f"mr_rollout_kernel<RK45,fast{'+collapsed' if law == 'collapsed' else ''},nominal,carry={carry}>", "per_wave_step": {k: round(v, 2) for k, v in sorted(per.items())},
         "insts_valu_per_wave_step": round(per["SQ_INSTS_VALU"], 2), "other_valu_per_wave_step": round(other, 2),
         "issue_floor_cycles_per_wave_step": round(fl["cycles"], 1), "wave_cycles_per_wave_step": round(wave_cycles, 1),
         "valu_issue_frac": round(WPS * fl["cycles"] / wave_cycles, 4),
@@ -214,7 +224,7 @@ for carry in ("f64", "f32"):
 files["pmc_valu.json"] = json.dumps(valu, indent=1) + "\n"
 
 # ---- the fused rollout with the actor as its policy source: f32-MFMA roofline from counters + trace
-ACT = "mr_rollout_actor_fl_kernel<true, 2, false"
+ACT = "mr_rollout_actor_fl_kernel<true, 4, false"   # tools/actor_probe.py runs bench.py's default law (collapsed)
 files["kernel_stats_actor_rollout.csv"] = open(the_csv("kt_actor", "kernel_stats.csv")).read()
 kta = the_csv("kt_actor", "kernel_trace.csv")
 adur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kta)) if ACT in r["Kernel_Name"]]
@@ -251,7 +261,7 @@ files["pmc_actor.json"] = json.dumps({
     "hbm_bytes_per_env_step": (2 * fr["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024 / (N * T),
     "raw": {"a": ca, "b": cb}, "source": [prov(kta), prov(fa), prov(fb), prov(f1), prov(f2)]}, indent=1) + "\n"
 # ---- ... and in bf16 x 3 arithmetic
-ACTB = "mr_rollout_actor_fl_kernel<true, 2, false, 40565893u"
+ACTB = "mr_rollout_actor_fl_kernel<true, 4, false, 40565893u"
 files["kernel_stats_actor_rollout_bf16x3.csv"] = open(the_csv("kt_actor_bf", "kernel_stats.csv")).read()
 ktb = the_csv("kt_actor_bf", "kernel_trace.csv")
 bdur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(ktb)) if ACTB in r["Kernel_Name"]]
@@ -276,7 +286,7 @@ files["pmc_actor_bf16x3.json"] = json.dumps({
     "per_wave_step": {k: round(v / wb / T, 2) for k, v in sorted(cba.items())},
     "source": [prov(ktb), prov(fba)]}, indent=1) + "\n"
 files["kernel_stats_actor_rollout_bf16.csv"] = open(the_csv("kt_actor_b1", "kernel_stats.csv")).read()   # plain bf16 arithmetic
-ACT1 = "mr_rollout_actor_fl_kernel<true, 2, false, 74120325u, 3>"
+ACT1 = "mr_rollout_actor_fl_kernel<true, 4, false, 74120325u, 3>"
 kt1 = the_csv("kt_actor_b1", "kernel_trace.csv")
 d1dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt1)) if ACT1 in r["Kernel_Name"]]
 if len(d1dur) < 100:
@@ -298,7 +308,7 @@ files["pmc_actor_bf16.json"] = json.dumps({
     "per_wave_step": {k: round(v / w1 / T, 2) for k, v in sorted(c1a.items())},
     "source": [prov(kt1), prov(f1a)]}, indent=1) + "\n"
 # ---- mixed trajectory set: VALU instructions per wave-step of the goal-table kernel
-cm, _, grid_m, fm = counters("valu_a_mixed", "mr_rollout_kernel<true, 2, false")
+cm, _, grid_m, fm = counters("valu_a_mixed", "mr_rollout_kernel<true, 4, false")
 files["pmc_mixed_set.json"] = json.dumps({
     "what": "SQ counters of the rollout kernel on BASELINE config 5's mixed trajectory set (bench.py --workload mixed, goal table, "
             "goal reward), per wave and env step",

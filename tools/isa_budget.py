@@ -10,7 +10,7 @@ Compare the hot total with SQ_INSTS_VALU per wave-step in profiles/rNN/pmc_valu.
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mr_rl_amd", "csrc")
-KERNEL = "_ZN5mrsim17mr_rollout_kernelILb1ELi2ELb0ELj720005EEEvNS_7KParamsENS_9StateArgsENS_11RolloutArgsE"
+KERNEL_FMT = "_ZN5mrsim17mr_rollout_kernelILb1ELi%dELb%dELj720005EEEvNS_7KParamsENS_9StateArgsENS_11RolloutArgsE"
 COLD = set()
 
 
@@ -41,6 +41,10 @@ def owner(ranges, line):
 
 
 def main():
+    # usage: isa_budget.py [per_stage|collapsed] [nominal|mismatched]
+    law = sys.argv[1] if len(sys.argv) > 1 else "per_stage"
+    mis = (sys.argv[2] if len(sys.argv) > 2 else "nominal") == "mismatched"
+    KERNEL = KERNEL_FMT % (4 if law == "collapsed" else 2, 1 if mis else 0)
     tmp = tempfile.mkdtemp(prefix="isa_budget_")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
            "-fno-slp-vectorize", "-gline-tables-only", "-DMRSIM_BUDGET_BUILD=1", "-shared", "-I../../include",
@@ -76,7 +80,7 @@ def main():
             name = "kernel body (loads, stores, loop)"
         (valu if op.startswith("v_") else other)[name] += 1
     hot = sum(v for k, v in valu.items() if k not in COLD)
-    print("VALU instructions inside the time loop of the DDPG rollout kernel, by source function (common path)")
+    print("VALU instructions inside the time loop of the DDPG rollout kernel, by source function (common path); noise law %s, %s model" % (law, "mismatched" if mis else "nominal"))
     for k, v in sorted(valu.items(), key=lambda kv: -kv[1]):
         print("  %-38s %4d%s   (+%d scalar / memory)" % (k, v, "  [cold: auto-reset]" if k in COLD else "", other.get(k, 0)))
     print("  %-38s %4d   (rocprofv3 SQ_INSTS_VALU per wave-step: see profiles/*/pmc_valu.json)" % ("hot total", hot))

@@ -18,14 +18,16 @@ pass() {  # pass <name> <cmd...>: run, record the exit code
   "$@" > $O/$name.out 2> $O/$name.log
   echo "$name $?" >> $O/status.txt
 }
-PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --no-actor-leg --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
+PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --no-actor-leg --no-learner-leg --no-other-law --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
 pass kt rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-power
-pass kt_s1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1 -- python3 $R/bench.py --no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set
+pass kt_s1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1 -- python3 $R/bench.py --no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg
+pass kt_s1_ps rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1_ps -- python3 $R/bench.py --no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg --noise-law per_stage
 pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --no-power --mode step
 for c in FETCH_SIZE WRITE_SIZE; do
   for carry in f64 f32; do
     pass pmc_${carry}_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_${carry}_$c -- python3 $R/bench.py $PMCARGS --carry $carry
   done
+  pass pmc_ps_f64_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_ps_f64_$c -- python3 $R/bench.py $PMCARGS --carry f64 --noise-law per_stage
   pass pmc_step_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_step_$c -- python3 $R/bench.py $PMCARGS --mode step --launch eager
   pass cal_$c rocprofv3 --pmc $c --output-format csv -d $O/cal_$c -- $R/tools/membench 16777216 20
   pass cal262k_$c rocprofv3 --pmc $c --output-format csv -d $O/cal262k_$c -- $R/tools/membench 262144 20
@@ -35,6 +37,10 @@ for carry in f64 f32; do
   pass valu_b_$carry rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VMEM_WR --output-format csv -d $O/valu_b_$carry -- python3 $R/bench.py $PMCARGS --carry $carry
   pass valu_c_$carry rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD --output-format csv -d $O/valu_c_$carry -- python3 $R/bench.py $PMCARGS --carry $carry
 done
+# the per-stage law (the library's default / parity mode) beside bench.py's default collapsed law
+pass valu_a_ps rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/valu_a_ps -- python3 $R/bench.py $PMCARGS --carry f64 --noise-law per_stage
+pass valu_b_ps rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VMEM_WR --output-format csv -d $O/valu_b_ps -- python3 $R/bench.py $PMCARGS --carry f64 --noise-law per_stage
+pass valu_c_ps rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD --output-format csv -d $O/valu_c_ps -- python3 $R/bench.py $PMCARGS --carry f64 --noise-law per_stage
 # ---- the fused rollout with the DDPG actor as its policy source (tools/actor_probe.py: 262 144 envs, 51 steps per launch)
 pass kt_actor rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_actor -- python3 $R/tools/actor_probe.py --launches 200
 pass pmc_actor_a rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/pmc_actor_a -- python3 $R/tools/actor_probe.py --launches 6 --discard 0
