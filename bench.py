@@ -671,6 +671,63 @@ def measure_actor_in_loop(args, n_local, dev, seed, streams, episodes=150, event
                                  "beside them"}}
 
 
+def measure_learner(args, n_local, dev, seed, streams):
+    """The learner half of the DDPG loop (RL/MR_ddpg.py:288-305: sample 64 -> critic target -> critic step -> actor step -> two
+    soft updates) and the loop as a whole.
+    updates_per_s: the update on a filled 10 000-slot ring, batch 64 -- eager PyTorch (no host sync any more), the same captured
+    as ONE hipGraph, and libmrsim's fused kernel (mrsim_ddpg_update: one launch, rows drawn in-kernel).
+    end_to_end: DDPG(fused=True).train_collected on n_local envs -- every episode one fused launch group of the rollout kernel
+    with the agent's actor (+ OU noise) in the kernel, 4096 of its transitions into the ring, U learner updates, parameters
+    folded / packed / uploaded on the device, collection of episode k + 1 beside the updates of episode k -- env-steps/s
+    INCLUDING the learner, at the stated update : transition ratio (the reference does 1 : 1 on one env; with N lockstep envs
+    the updates are the sequential part)."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.ddpg import DDPG
+    cfg = MRConfig(noise_var=args.sigma, auto_reset=True, obs_layout=args.obs_layout, noise_math=args.noise_math, seed=seed,
+                   is_mismatched=args.mismatched, noise_law=args.noise_law)
+    env = MRVecEnv(n_local, cfg=cfg, device=dev, seed=seed)
+    scale = [0.01] * 5
+
+    def filled(**kw):
+        ag = DDPG(env, seed=seed, obs_scale=scale, **kw)
+        g = torch.Generator(device=dev).manual_seed(1)
+        n = 10000
+        s = torch.randn(n, 5, device=dev, generator=g)
+        ag.buffer.add(s, torch.randn(n, 2, device=dev, generator=g), torch.randn(n, device=dev, generator=g),
+                      (torch.rand(n, device=dev, generator=g) < 0.02).float(), s + 0.01 * torch.randn(n, 5, device=dev, generator=g))
+        return ag
+
+    def rate(f, n):
+        f(10)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        f(n)
+        torch.cuda.synchronize(dev)
+        return n / (time.perf_counter() - t0)
+    ag = filled()
+    ups = {"eager_pytorch": rate(lambda n: [ag.update() for _ in range(n)], 100)}
+    ag = filled()
+    ups["hipgraph_replay"] = rate(lambda n: ag.update_graphed(n), 1000)
+    ag = filled(fused=True)
+    ups["fused_kernel"] = rate(lambda n: [ag.update() for _ in range(n)], 3000)
+    out = {"what": "the DDPG learner: updates/s on a filled ring (batch 64, the reference's) and env-steps/s of the whole loop "
+                   "(collection with the actor in the kernel + learner) at a stated update : transition ratio",
+           "batch": 64, "updates_per_s": {k: round(v, 1) for k, v in ups.items()},
+           "us_per_update": {k: round(1e6 / v, 1) for k, v in ups.items()}, "end_to_end": []}
+    ep = cfg.max_timesteps + 1
+    for math, U, episodes in (("f32", 8, 60), ("bf16", 4, 150), ("bf16", 0, 150)):
+        agent = DDPG(env, seed=seed, obs_scale=scale, fused=True)
+        st = {}
+        rets = agent.train_collected(episodes, updates_per_episode=U, sample=4096, streams=streams, math=math, stats=st, warm_episodes=10)
+        out["end_to_end"].append({
+            "actor_math": math, "updates_per_episode": U, "transitions_per_episode": n_local * ep,
+            "update_to_transition_ratio": U / float(n_local * ep), "value": st["env_steps_timed"] / st["seconds"], "unit": "env-steps/s",
+            "updates_per_s": st["updates_timed"] / st["seconds"], "episodes_timed": st["episodes_timed"],
+            "mean_return_last_episode": rets[-1] if rets else None})
+    return out
+
+
 def trajectory_rmse(dev, carry):
     """Second half of BASELINE's metric: trajectory RMSE vs the CPU reference, on the committed golden trajectories
     the reference itself produced (tests/golden/ref_sim.npz, sigma = 0, 1000-2000 steps each), through the same
@@ -1061,6 +1118,11 @@ def main():
         actor_leg = measure_actor_in_loop(args, n_local, dev, seed, streams)
         trace("actor-in-the-loop leg done")
 
+    learner_leg = None
+    if rank == 0 and world == 1 and args.mode == "rollout" and args.workload == "ddpg" and not args.no_learner_leg and not pmc:
+        learner_leg = measure_learner(args, n_local, dev, seed, streams)
+        trace("learner leg done")
+
     power = None
     if rank == 0 and world == 1 and args.mode == "rollout" and not args.no_power and not pmc:
         power = measure_power(reg, dev, total)
@@ -1114,6 +1176,8 @@ def main():
             out["other_noise_law"] = other_law
         if actor_leg is not None:
             out["actor_in_loop"] = actor_leg
+        if learner_leg is not None:
+            out["learner"] = learner_leg
         if power is not None:
             out["power"] = power
         if pmc:

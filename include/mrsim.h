@@ -199,6 +199,50 @@ typedef struct MrsimStepIO {
                              /*   must then be NULL and the integrator RK45                   */
 } MrsimStepIO;
 
+/* ---------------------------------------------------------------------------------------------------------
+ * The DDPG learner update as ONE launch (ABI 4) -- RL/MR_ddpg.py:288-305: for a batch of transitions
+ *     y = r + gamma Q'(s2, mu'(s2)) (1 - done);  critic: Adam step on mean (y - Q(s, a))^2  (CriticNetwork.train);
+ *     actor: Adam step along dQ/da at a = mu(s) against the UPDATED critic (critic.action_gradients -> ActorNetwork.train);
+ *     both target networks <- tau online + (1 - tau) target  (update_target_network)
+ * for the networks of :120-137 / :207-223.  Batch normalisation is the fixed affine map it is in the script (tflearn's
+ * training mode is never switched on): moving statistics as constants, trainable gamma / beta.  Adam follows
+ * torch.optim.Adam's formula (the parity target of the tests is the PyTorch twin mr_rl_amd/ddpg.py; TF1's AdamOptimizer
+ * differs only in where epsilon enters; the reference itself is unpinned, TF1 / tflearn being absent).
+ * Parameter vector layout (floats; online, target, Adam m, Adam v and the gradient scratch all use it): row-major tensors
+ *   actor : W1[64][5] @0, b1 @320, gamma1 @384, beta1 @448, W2[64][64] @512, b2 @4608, gamma2 @4672, beta2 @4736,
+ *           W3[2][64] @4800, b3[2] @4928;      (2 unused floats)
+ *   critic: W1[64][5] @4932, b1 @5252, gamma1 @5316, beta1 @5380, T1[32][64] @5444, T2[32][2] @7492, bt2[32] @7556,
+ *           Wo[32] @7588, bo @7620;            padded to MRSIM_DDPG_PARAMS floats.
+ * --------------------------------------------------------------------------------------------------------- */
+#define MRSIM_DDPG_PARAMS 7680
+#define MRSIM_DDPG_MAX_BATCH 4096
+typedef struct MrsimDdpgLearner {
+    float* online;           /* DEVICE [MRSIM_DDPG_PARAMS], 16-byte aligned: the online actor + critic, updated in place  */
+    float* target;           /* DEVICE: the target networks, soft-updated in place                                        */
+    float* adam_m;           /* DEVICE: Adam first moments                                                                */
+    float* adam_v;           /* DEVICE: Adam second moments                                                               */
+    float* grad_scratch;     /* DEVICE: gradient scratch (holds the update's gradients on return)                         */
+    int32_t* steps;          /* DEVICE [2]: Adam step counts of the critic and the actor; the kernel increments them      */
+    const float* bn_stats;   /* DEVICE [2][3][2][64]: {online, target} x {actor bn1, actor bn2, critic bn1} x {moving    */
+                             /*   mean, moving variance} -- constants of the update                                       */
+    float bn_eps;            /* 1e-5 (tflearn batch_normalization epsilon)                                                */
+    float gamma;             /* 0.99   RL/MR_ddpg.py:339                                                                  */
+    float tau;               /* 0.001  :338                                                                               */
+    float actor_lr;          /* 1e-3   :341                                                                               */
+    float critic_lr;         /* 1e-2   :342                                                                               */
+    float beta1, beta2, adam_eps; /* 0.9, 0.999, 1e-8 (Adam defaults)                                                     */
+    float action_bound[2];   /* :345 env.action_space.high                                                                */
+} MrsimDdpgLearner;
+/* One update on `batch` transitions (a multiple of 64, <= MRSIM_DDPG_MAX_BATCH; the reference uses 64).  s / s2 [.][5], a [.][2],
+ * r [.], done [.] are DEVICE arrays (e.g. the replay ring).  Which rows: idx (DEVICE [batch] int32) if given; else, with
+ * ring_count > 0, drawn IN the kernel from [0, ring_count) by Philox4x32-10 keyed by (seed, draw_counter) -- without
+ * repetition, the law of random.sample (RL/MR_ddpg.py:37-44), for batch <= 256 <= ring_count, with repetition otherwise;
+ * else rows 0 .. batch-1.  idx_out: optional DEVICE [batch] int32, the rows used.  losses_out: optional DEVICE [2] {critic
+ * loss, actor loss}.  Everything is enqueued on `stream`; no host synchronisation. */
+int mrsim_ddpg_update(const MrsimDdpgLearner* learner, int32_t batch, const float* s, const float* a, const float* r,
+                      const float* done, const float* s2, const int32_t* idx, int32_t ring_count, uint64_t seed,
+                      uint64_t draw_counter, int32_t* idx_out, float* losses_out, void* stream);
+
 int mrsim_abi_version(void);
 const char* mrsim_strerror(int code);
 

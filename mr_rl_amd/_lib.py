@@ -15,6 +15,7 @@ LAW_PER_STAGE, LAW_COLLAPSED = 0, 1
 ABI_VERSION = 4
 ACTOR_HIDDEN, ACTOR_BLOB_FLOATS = 64, 10888
 ACTOR_F32, ACTOR_BF16X3, ACTOR_BF16 = 0, 1, 2
+DDPG_PARAMS, DDPG_MAX_BATCH = 7680, 4096
 
 # every symbol include/mrsim.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
@@ -22,7 +23,7 @@ SYMBOLS = (
     "mrsim_step_timed", "mrsim_random_policy", "mrsim_random_policy_steps", "mrsim_rollout", "mrsim_rollout_timed", "mrsim_advance_step_base", "mrsim_velocity", "mrsim_debug_normals",
     "mrsim_device_count", "mrsim_device_name",
     "mrsim_event_create", "mrsim_event_destroy", "mrsim_event_elapsed_ms", "mrsim_rollout_events", "mrsim_step_events",
-    "mrsim_actor_fold_bn_host", "mrsim_actor_pack_host", "mrsim_actor_forward",
+    "mrsim_actor_fold_bn_host", "mrsim_actor_pack_host", "mrsim_actor_forward", "mrsim_ddpg_update",
 )
 
 
@@ -53,6 +54,13 @@ class MrsimActorWeights(C.Structure):
 class MrsimActor(C.Structure):
     _fields_ = [("blob", C.c_void_p), ("ou_state", C.c_void_p), ("ou_theta", C.c_float), ("ou_sigma", C.c_float),
                 ("ou_dt", C.c_float), ("ou_reset_on_done", C.c_int32), ("math", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class MrsimDdpgLearner(C.Structure):
+    _fields_ = [("online", C.c_void_p), ("target", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
+                ("grad_scratch", C.c_void_p), ("steps", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_eps", C.c_float),
+                ("gamma", C.c_float), ("tau", C.c_float), ("actor_lr", C.c_float), ("critic_lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("adam_eps", C.c_float), ("action_bound", C.c_float * 2)]
 
 
 class MrsimStepIO(C.Structure):
@@ -120,6 +128,7 @@ def load(path):
     L.mrsim_actor_fold_bn_host.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]
     L.mrsim_actor_pack_host.argtypes = [C.POINTER(MrsimActorWeights), vp]
     L.mrsim_actor_forward.argtypes = [PP, i64, u32, C.POINTER(MrsimActor), PS, vp, vp, u64, u64, vp]
+    L.mrsim_ddpg_update.argtypes = [C.POINTER(MrsimDdpgLearner), i32, vp, vp, vp, vp, vp, vp, i32, u64, u64, vp, vp, vp]
     L.mrsim_device_count.restype = C.c_int
     L.mrsim_device_name.argtypes = [C.c_int, C.c_char_p, i32]
     for name in SYMBOLS:

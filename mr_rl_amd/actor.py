@@ -78,7 +78,8 @@ class DeviceActor:
 
     MATH = {"f32": _lib.ACTOR_F32, "bf16x3": _lib.ACTOR_BF16X3, "bf16": _lib.ACTOR_BF16}
 
-    def __init__(self, weights, device="cuda", ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False, math="f32"):
+    def __init__(self, weights, device="cuda", ou=True, theta=0.15, sigma=0.3, dt=1e-2, reset_on_done=False, math="f32",
+                 slots=1):
         """math: arithmetic of the two hidden layers.  "f32" (default) = exact f32 MFMA, bit-for-bit the documented fmaf chain;
         "bf16x3" = every f32 operand as three bf16 terms, six bf16 MFMAs with f32 accumulation: f32-class accuracy (within
         5e-6 of the action bound of the f32 result; tests/test_gpu_actor.py), about 1.5 x the collection rate; "bf16" = plain
@@ -91,7 +92,11 @@ class DeviceActor:
         self.device = torch.device(device)
         self.ou, self.theta, self.sigma, self.dt = bool(ou), float(theta), float(sigma), float(dt)
         self.reset_on_done = bool(reset_on_done)
-        self.blob = torch.empty(_lib.ACTOR_BLOB_FLOATS, dtype=torch.float32, device=self.device)
+        # `slots` parameter blocks: a learner uploads the next parameters into the block no launch reads while the envs still
+        # collect with the current one (DDPG.train_collected: episode k reads block k % slots); load() fills all of them
+        self.blobs = [torch.empty(_lib.ACTOR_BLOB_FLOATS, dtype=torch.float32, device=self.device) for _ in range(max(1, int(slots)))]
+        self.blob = self.blobs[0]
+        self._perm = None      # device gather indices of the packed layout (load_module_device)
         self._ou = {}          # env count -> [n, 2] OU state (prepared launches hold raw pointers into these: never reallocated)
         self.ou_state = None   # the one used last
         self.weights = None
@@ -111,10 +116,83 @@ class DeviceActor:
         host = torch.from_numpy(pack_weights(self.weights))
         if sync:
             torch.cuda.synchronize(self.device)
-        self.blob.copy_(host, non_blocking=False)
+        for b in self.blobs:
+            b.copy_(host, non_blocking=False)
 
     def load_module(self, module, obs_scale=None, sync=True):
         self.load(fold_actor(module, self.weights["obs_scale"] if obs_scale is None else obs_scale), sync=sync)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # device-side upload: fold batch norm, pack into the kernels' operand layout and write a parameter block with torch ops on
+    # the CURRENT stream -- no host copy of the weights, no device-wide synchronisation.  Same bits as load_module() (tested).
+    def _layout(self):
+        """Gather indices of the packed block, derived once from the library's own packer (mrsim_actor_pack_host) by packing
+        index codes instead of weights: the layout stays private to the library."""
+        import torch
+        if self._perm is not None:
+            return self._perm
+        H = _lib.ACTOR_HIDDEN
+        sizes = [("w1", H * 5), ("b1", H), ("w2", H * H), ("b2", H), ("w3", 2 * H), ("b3", 2), ("action_bound", 2)]
+        off, codes, base = {}, {}, 1                       # code 0 = a padding zero of the block
+        for k, n in sizes:
+            off[k] = base
+            codes[k] = np.arange(base, base + n, dtype=np.float32)
+            base += n
+        shp = {"w1": (H, 5), "w2": (H, H), "w3": (2, H)}
+        w = {k: codes[k].reshape(shp.get(k, (-1,))) for k, _ in sizes}
+        w["obs_scale"] = np.ones(5, dtype=np.float32)
+        blob = pack_weights(w)
+        F32 = _lib.ACTOR_BLOB_FLOATS - (H * H * 3) // 2    # the bf16 x 3 section is the tail of the block: 3 bf16 terms per weight
+        perm_f32 = np.rint(blob[:F32]).astype(np.int64)    # index codes < 2^24 are exact in float32
+        # bf16 section: term 0 of a weight w2[i] sits where the packer puts bf16(w2[i]); integers <= 256 are exact in bf16, so two
+        # passes with the base-64 digits of i recover it.  Terms 1 and 2 of the same weight follow at +512 and +1024 halfwords.
+        digs = []
+        for d in (lambda i: i // 64, lambda i: i % 64):
+            w2c = dict(w)
+            w2c["w2"] = d(np.arange(H * H)).astype(np.float32).reshape(H, H)
+            hw = pack_weights(w2c)[F32:].view(np.uint16).astype(np.uint32) << 16
+            digs.append(np.rint(hw.view(np.float32)).astype(np.int64))
+        idx = digs[0] * 64 + digs[1]                       # per halfword; meaningful at term-0 positions
+        hw_n = idx.size
+        pos = np.arange(hw_n)
+        part = (pos // 512) % 3
+        idx0 = idx[pos - part * 512]                       # the weight whose term `part` lives at this halfword
+        dev = self.device
+        self._perm = {"f32": torch.from_numpy(perm_f32).to(dev), "bf_idx": torch.from_numpy(idx0).to(dev),
+                      "bf_part": torch.from_numpy(part.astype(np.int64)).to(dev), "off": off, "n_f32": F32}
+        return self._perm
+
+    def load_module_device(self, module, slot=None):
+        """(Re)write parameter block `slot` (default: all) from an mr_rl_amd.ddpg.Actor on the device, ordered on the current
+        stream.  The caller orders it against the launches that read the block (RolloutCollector.collect(after=stream))."""
+        import torch
+        L = self._layout()
+        dev = self.device
+        f64 = torch.float64
+
+        def fold(fc, bn):   # mrsim_actor_fold_bn_host's arithmetic: double, rounded once
+            eps = torch.tensor(bn.eps, dtype=torch.float32, device=dev).to(f64)
+            g = bn.weight.detach().to(f64) / torch.sqrt(bn.running_var.to(f64) + eps)
+            w = (fc.weight.detach().to(f64) * g[:, None]).float()
+            b = ((fc.bias.detach().to(f64) - bn.running_mean.to(f64)) * g + bn.bias.detach().to(f64)).float()
+            return w, b
+        w1, b1 = fold(module.fc1, module.bn1)
+        w2, b2 = fold(module.fc2, module.bn2)
+        scale = torch.as_tensor(self.weights["obs_scale"], dtype=torch.float32, device=dev)
+        flat = torch.cat([torch.zeros(1, device=dev), (w1 * scale[None, :]).reshape(-1), b1, w2.reshape(-1), b2,
+                          module.out.weight.detach().float().reshape(-1), module.out.bias.detach().float(),
+                          module.action_bound.float()])
+        f32 = flat[L["f32"]]
+        w2g = w2.reshape(-1)[L["bf_idx"]]
+        t0 = w2g.to(torch.bfloat16)
+        r1 = w2g - t0.float()
+        t1 = r1.to(torch.bfloat16)
+        t2 = (r1 - t1.float()).to(torch.bfloat16)
+        hw = torch.where(L["bf_part"] == 0, t0, torch.where(L["bf_part"] == 1, t1, t2))
+        block = torch.cat([f32, hw.view(torch.float32)])
+        for i, b in enumerate(self.blobs):
+            if slot is None or i == slot:
+                b.copy_(block)
 
     def ou_tensor(self, n):
         import torch
@@ -122,17 +200,38 @@ class DeviceActor:
             return None
         if n not in self._ou:
             self._ou[n] = torch.zeros((n, 2), dtype=torch.float32, device=self.device)
+            # The zero fill runs on the CURRENT stream and the kernels that read and write this state run on others (the
+            # collector's sub-shard streams): wait for it here, once per env count, so that no launch on any stream can see the
+            # buffer before the fill has landed (an unordered cross-stream initialisation).
+            torch.cuda.current_stream(self.device).synchronize()
         self.ou_state = self._ou[n]
         return self.ou_state
+
+    def state_dict(self):
+        """parameters (inference form) + every OU state tensor: an actor-in-the-loop run resumes bit for bit together with
+        MRVecEnv.state_dict()"""
+        return {"weights": {k: v.copy() for k, v in self.weights.items()}, "blob": self.blob.detach().cpu().clone(),
+                "ou": {int(n): t.detach().cpu().clone() for n, t in self._ou.items()}}
+
+    def load_state_dict(self, sd):
+        import torch
+        self.weights = {k: _f32(v) for k, v in sd["weights"].items()}
+        torch.cuda.synchronize(self.device)
+        for b in self.blobs:
+            b.copy_(sd["blob"])
+        for n, t in sd["ou"].items():
+            self.ou_tensor(int(n)).copy_(t)
+        torch.cuda.synchronize(self.device)
 
     def reset_noise(self):
         for t in self._ou.values():
             t.zero_()
 
-    def struct(self, n, first=0, count=None):
-        """MrsimActor for the envs [first, first + count) of an n-env set (the OU state pointer advanced to `first`)."""
+    def struct(self, n, first=0, count=None, slot=0):
+        """MrsimActor for the envs [first, first + count) of an n-env set (the OU state pointer advanced to `first`), reading
+        parameter block `slot`."""
         ou = self.ou_tensor(n)
-        return _lib.MrsimActor(self.blob.data_ptr(), None if ou is None else ou.data_ptr() + first * 8, self.theta,
+        return _lib.MrsimActor(self.blobs[slot % len(self.blobs)].data_ptr(), None if ou is None else ou.data_ptr() + first * 8, self.theta,
                                self.sigma, self.dt, int(self.reset_on_done), self.MATH[self.math], 0)
 
     def forward(self, env, obs=None, out=None):

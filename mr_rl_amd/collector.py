@@ -58,6 +58,8 @@ class RolloutCollector:
         self.want = tuple(want)
         self.policy = policy   # None: the uniform exploration policy drawn in-kernel; a DeviceActor: actor + OU noise in-kernel
         dev = env.device
+        if policy is not None:
+            policy.ou_tensor(env.num_envs)   # created (and its zero fill awaited) HERE, before any sub-shard stream can read it
         self.shards = [(a, n) for a, n in all_shards(self.N, self.S) if n > 0]
         self.streams = _sub_shard_streams(dev, len(self.shards))
         T_, N = self.T, self.N
@@ -95,11 +97,18 @@ class RolloutCollector:
     def _where(self, k):
         return k % self.depth, (k // self.E) % 2, k % self.E   # buffer set, returns block, row of the block
 
-    def collect(self, events=None, steps=None):
+    def collect(self, events=None, steps=None, after=None):
         """Enqueue the next launch group: `steps` (default T = one episode) steps per sub-shard, each sub-shard on its
         own stream, into buffer set episodes % depth (rows [0, steps)).  Nothing is synchronised.  events: optional
-        list of _lib.EventPair, one per sub-shard."""
+        list of _lib.EventPair, one per sub-shard.  after: a torch stream whose work enqueued so far (e.g. a parameter
+        upload of the in-kernel policy) the launches of this group must wait for.  With a DeviceActor of several parameter
+        blocks, launch group k reads block k % slots."""
+        import torch
         env, k = self.env, self.episodes
+        after_ev = None
+        if after is not None:
+            after_ev = torch.cuda.Event()
+            after_ev.record(after)
         assert self._synced_streams, "call reset() first"
         T = self.T if steps is None else int(steps)
         assert 1 <= T <= self.T
@@ -113,7 +122,9 @@ class RolloutCollector:
                 st.wait_event(free_set)         # the consumer has released this buffer set
             if free_blk is not None:
                 st.wait_event(free_blk)         # the collective that read this returns block has finished
-            launch = self._launch_for(s, b, blk, row, T)
+            if after_ev is not None:
+                st.wait_event(after_ev)
+            launch = self._launch_for(s, b, blk, row, T, k)
             launch(env.step_idx, events=None if events is None else events[s])
             self._done_ev[b][s].record(st)
         if row == 0:
@@ -122,10 +133,11 @@ class RolloutCollector:
         self.episodes += 1
         return k
 
-    def _launch_for(self, s, b, blk, row, T):
+    def _launch_for(self, s, b, blk, row, T, k=0):
         """The prepared launch (argument block built once, vec_env.launch_rollout(prepare_only=True)) of sub-shard s into
-        buffer set b / returns row (blk, row) for T steps."""
-        key = (s, b, blk, row, T)
+        buffer set b / returns row (blk, row) for T steps (launch group k: which parameter block an in-kernel policy reads)."""
+        slot = 0 if self.policy is None else k % len(self.policy.blobs)
+        key = (s, b, blk, row, T, slot)
         launch = self._prepared.get(key)
         if launch is None:
             bufs, (first, n) = self.sets[b], self.shards[s]
@@ -133,7 +145,7 @@ class RolloutCollector:
                 T, first, n, traj=bufs.get("traj"), sp_T=bufs.get("state_prime"), obs_T=bufs.get("obs"),
                 rew_T=bufs.get("rew"), done_T=bufs.get("done"), acts_T=bufs.get("actions"),
                 final_ret=self.ret_blocks[blk][row], final_len=self.len_blocks[blk][row], carry=self.carry,
-                stream=self.streams[s], prepare_only=True, actor=self.policy)
+                stream=self.streams[s], prepare_only=True, actor=self.policy, actor_slot=slot)
         return launch
 
     def prime(self, schedule):
@@ -146,7 +158,7 @@ class RolloutCollector:
         for i, T in enumerate(schedule):
             b, blk, row = self._where(self.episodes + i)
             for s in range(len(self.shards)):
-                self._launch_for(s, b, blk, row, int(T))
+                self._launch_for(s, b, blk, row, int(T), self.episodes + i)
 
     def wait_episode(self, k=None):
         """Make the current stream wait for the launches of episode k (default: the newest)."""

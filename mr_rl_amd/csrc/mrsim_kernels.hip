@@ -19,6 +19,7 @@
 #include "mrsim.h"
 #include "mrsim_device.h"
 #include "mrsim_actor.h"
+#include "mrsim_learner.h"
 
 namespace mrsim {
 
@@ -1336,6 +1337,36 @@ int mrsim_actor_forward(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     }
     if (fastnz) return launch(lc, mr_actor_kernel<kNoiseFast, kActF32>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
     return launch(lc, mr_actor_kernel<kNoiseSpec, kActF32>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
+}
+
+int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, const float* s, const float* a, const float* r, const float* done,
+                      const float* s2, const int32_t* idx, int32_t ring_count, uint64_t seed, uint64_t draw_counter,
+                      int32_t* idx_out, float* losses_out, void* stream) {
+    static_assert(MRSIM_DDPG_PARAMS == learner::kParams && MRSIM_DDPG_MAX_BATCH == learner::kMaxBatch, "mrsim.h / mrsim_learner.h");
+    if (Lr == nullptr || Lr->online == nullptr || Lr->target == nullptr || Lr->adam_m == nullptr || Lr->adam_v == nullptr ||
+        Lr->grad_scratch == nullptr || Lr->steps == nullptr || Lr->bn_stats == nullptr || s == nullptr || a == nullptr ||
+        r == nullptr || done == nullptr || s2 == nullptr)
+        return MRSIM_EINVAL;
+    if (batch < learner::kTile || batch > learner::kMaxBatch || batch % learner::kTile != 0) return MRSIM_EINVAL;
+    if (!aligned16(Lr->online) || !aligned16(Lr->target)) return MRSIM_EALIGN;
+    if (!(Lr->bn_eps > 0.0f) || !(Lr->beta1 >= 0.0f && Lr->beta1 < 1.0f) || !(Lr->beta2 >= 0.0f && Lr->beta2 < 1.0f)) return MRSIM_EINVAL;
+    int rc = check_device();
+    if (rc) return rc;
+    static bool attr_set = false;   // one-time: the kernel's LDS image (136 KB) is above the default dynamic limit
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(learner::mr_ddpg_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(learner::Lds)) != hipSuccess)
+            return MRSIM_ELAUNCH;
+        attr_set = true;
+    }
+    if (ring_count < 0) return MRSIM_EINVAL;
+    learner::Args A{Lr->online, Lr->target, Lr->adam_m, Lr->adam_v, Lr->grad_scratch, Lr->steps, Lr->bn_stats, s, a, r, done, s2, idx,
+                    idx_out, ring_count, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)draw_counter, (uint32_t)(draw_counter >> 32),
+                    losses_out, batch, Lr->bn_eps, Lr->gamma, Lr->tau, Lr->actor_lr, Lr->critic_lr, Lr->beta1, Lr->beta2, Lr->adam_eps,
+                    Lr->action_bound[0], Lr->action_bound[1]};
+    hipLaunchKernelGGL(learner::mr_ddpg_update_kernel, dim3(1), dim3(learner::kThreads), sizeof(learner::Lds),
+                       static_cast<hipStream_t>(stream), A);
+    return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 
 int mrsim_velocity(int64_t n, int32_t T, int32_t n_filter, const double* traj_xy, const double* time, double* v_xy,

@@ -1,0 +1,567 @@
+// mrsim_learner.h -- the DDPG learner update of RL/MR_ddpg.py:288-305 as ONE kernel for gfx950.
+//
+//   sample -> y = r + gamma Q'(s2, mu'(s2)) (1 - done)            :290-294   (target networks)
+//          -> critic: minimise mean (y - Q(s, a))^2, Adam          :297       CriticNetwork.train
+//          -> actor: ascend mean Q(s, mu(s)) through dQ/da, Adam   :300-302   action_gradients -> ActorNetwork.train
+//          -> both targets <- tau online + (1 - tau) target        :305-306
+// for the networks of :120-137 (actor 5-64-64-2) and :207-223 (critic 5-64-(32 + action)-1).  Batch normalisation is the
+// fixed affine map it is in the script (tflearn.is_training is never switched on: moving statistics, trainable gamma / beta).
+//
+// One workgroup of 256 threads does the whole update for a tile of 64 samples at a time (the reference's batch is 64; larger
+// batches loop over tiles and accumulate the gradients): weights and activations live in LDS, the 64 x 64 and 32 x 64 products
+// are register-tiled outer-product loops (4 x 4 / 2 x 4 outputs per thread, both operands read as 16-byte LDS vectors), the
+// narrow layers (5 inputs, 2 / 1 outputs) and the per-feature reductions are plain loops, Adam and the soft update of the target
+// are one pass over the parameter vector.  The update is latency-bound (6 MFLOP): what matters is that it is ONE launch
+// with no host round trip instead of ~150 (3.2 ms eager, 0.55 ms as a captured graph: tools/learner_probe.py).
+//
+// Parameter vector (floats), online / target / Adam m / Adam v all in this layout (= the nn.Module tensors of mr_rl_amd/ddpg.py,
+// row-major, so the host side can alias them):
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mrsim_device.h"   // philox4x32_10
+
+namespace mrsim {
+namespace learner {
+
+constexpr int A_W1 = 0, A_B1 = 320, A_G1 = 384, A_BE1 = 448, A_W2 = 512, A_B2 = 4608, A_G2 = 4672, A_BE2 = 4736, A_W3 = 4800,
+              A_B3 = 4928, A_END = 4930;
+constexpr int C_W1 = 4932, C_B1 = 5252, C_G1 = 5316, C_BE1 = 5380, C_T1 = 5444, C_T2 = 7492, C_BT2 = 7556, C_WO = 7588, C_BO = 7620,
+              C_END = 7621;
+constexpr int kParams = 7680;   // padded (two unused floats between the networks keep T1's rows 16-byte aligned)
+constexpr int kTile = 64;       // samples per pass
+constexpr int kThreads = 256;
+constexpr int kMaxBatch = 4096;
+static_assert(A_W2 % 4 == 0 && C_T1 % 4 == 0 && kParams % 4 == 0, "16-byte aligned rows");
+
+struct Args {
+    float* online; float* target; float* adam_m; float* adam_v; float* grad;   // [kParams] each (grad: scratch)
+    int32_t* steps;                 // [2] Adam step counts: critic, actor
+    const float* bn;                // [2 online/target][3 layers: actor bn1, actor bn2, critic bn1][2 mean/var][64]
+    const float* s; const float* a; const float* r; const float* d; const float* s2;   // ring arrays [.][5], [.][2], [.], [.], [.][5]
+    const int32_t* idx;             // [batch] rows of the ring arrays, or null: sampled in-kernel (ring_count > 0) / rows 0 .. batch-1
+    int32_t* idx_out;               // optional [batch]: the rows used
+    int32_t ring_count;             // > 0 and idx == null: draw the rows from [0, ring_count) here (Philox4x32-10, key = seed,
+    uint32_t seed_lo, seed_hi, ctr_lo, ctr_hi;   //   counter = (draw, round, update counter)): without replacement up to 256 rows
+    float* losses;                  // [2] critic loss, actor loss (device), or null
+    int32_t batch;
+    float bn_eps, gamma, tau, actor_lr, critic_lr, beta1, beta2, adam_eps;
+    float bound0, bound1;
+};
+
+// C[m0 .. m0+TM)[n0 .. n0+TN) = sum_k A(m, k) B(k, n).  B is k-major ([K][ldb], n contiguous).  A is k-major ([K][lda], m
+// contiguous) or, AT, m-major ([M][lda], k contiguous: the row-major weight matrices and sample-major activations as they are).
+template <int N>
+__device__ __forceinline__ void ldvec(const float* __restrict__ p, float (&v)[N]) {   // one 16- / 8-byte LDS read (p is so aligned)
+    if constexpr (N == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        static_assert(N == 2, "tile widths are 2 or 4");
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+}
+
+template <int TM, int TN, int K, bool AT>
+__device__ __forceinline__ void lgemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int m0, int n0,
+                                      float (&acc)[TM][TN]) {
+#pragma unroll
+    for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y) acc[x][y] = 0.f;
+    if constexpr (AT) {
+        for (int k = 0; k < K; k += 4) {
+            float av[TM][4];
+#pragma unroll
+            for (int x = 0; x < TM; ++x) ldvec<4>(A + (m0 + x) * lda + k, av[x]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float bv[TN];
+                ldvec<TN>(B + (k + kk) * ldb + n0, bv);
+#pragma unroll
+                for (int x = 0; x < TM; ++x)
+#pragma unroll
+                    for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_fmaf(av[x][kk], bv[y], acc[x][y]);
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            float av[TM], bv[TN];
+            ldvec<TM>(A + k * lda + m0, av);
+            ldvec<TN>(B + k * ldb + n0, bv);
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_fmaf(av[x], bv[y], acc[x][y]);
+        }
+    }
+}
+
+struct Lds {
+    float P[kParams];          // the staged network pair (target, then online)
+    float rstd[3][64], mean[3][64];
+    float s[kTile * 5], s2[kTile * 5], a[kTile * 2], ap[kTile * 2], th[kTile * 2], dz3[kTile * 2], r[kTile], d[kTile], dq[kTile];
+    float y[kMaxBatch];
+    float X[5][kTile * 64];
+    float loss[2];
+    float bc[4];               // Adam bias corrections: critic (1 - b1^t, sqrt(1 - b2^t)), actor
+    int rows[kTile];
+    int sel[kMaxBatch];        // rows drawn in-kernel
+};
+
+__device__ __forceinline__ void stage_params(Lds& L, const float* __restrict__ src, const float* __restrict__ bn, float eps, int tid) {
+    for (int p = tid * 4; p < kParams; p += kThreads * 4)
+        *reinterpret_cast<float4*>(&L.P[p]) = *reinterpret_cast<const float4*>(src + p);
+    for (int q = tid; q < 3 * 64; q += kThreads) {
+        const int l = q >> 6, k = q & 63;
+        L.mean[l][k] = bn[(l * 2 + 0) * 64 + k];
+        L.rstd[l][k] = 1.0f / sqrtf(bn[(l * 2 + 1) * 64 + k] + eps);
+    }
+}
+
+// hidden layer 1 (5 inputs) of either network for this tile: h[f][i] = relu(g (W x_i + b - mean) rstd + be).
+// FM: feature-major [64][64 samples] (the B operand of the next layer's product); SM: sample-major [64 samples][64].
+__device__ __forceinline__ void layer1(const Lds& L, const float* __restrict__ x, int W, int Bb, int G, int BE, int bn_l,
+                                       float* __restrict__ FM, float* __restrict__ SM, int tid) {
+    const int tx = tid & 15, ty = tid >> 4, f0 = ty * 4, i0 = tx * 4;
+    float h[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int f = f0 + u;
+        const float* w = &L.P[W + f * 5];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float* xi = x + (i0 + v) * 5;
+            float z = L.P[Bb + f];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) z = __builtin_fmaf(w[j], xi[j], z);
+            const float n = __builtin_fmaf(L.P[G + f], (z - L.mean[bn_l][f]) * L.rstd[bn_l][f], L.P[BE + f]);
+            h[u][v] = n > 0.f ? n : 0.f;
+        }
+    }
+    if (FM != nullptr)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(FM + (f0 + u) * 64 + i0) = make_float4(h[u][0], h[u][1], h[u][2], h[u][3]);
+    if (SM != nullptr)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) *reinterpret_cast<float4*>(SM + (i0 + v) * 64 + f0) = make_float4(h[0][v], h[1][v], h[2][v], h[3][v]);
+}
+
+// backward of hidden layer 1 from DN = dL/dn (sample-major [i][k], zero where the unit was off): gamma, beta, W, b gradients
+__device__ __forceinline__ void layer1_backward(Lds& L, const float* __restrict__ DN, const float* __restrict__ x, int W, int Bb, int G,
+                                                int BE, int bn_l, float* __restrict__ red, float* __restrict__ grad, bool first,
+                                                int tid) {
+    const int k = tid & 63, part = tid >> 6;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dg, dbe, db, dW[5]
+    const float g_r = L.P[G + k] * L.rstd[bn_l][k];
+    for (int i = part * 16; i < part * 16 + 16; ++i) {
+        const float dn = DN[i * 64 + k];
+        const float* xi = x + i * 5;
+        float z = L.P[Bb + k];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) z = __builtin_fmaf(L.P[W + k * 5 + j], xi[j], z);
+        const float zh = (z - L.mean[bn_l][k]) * L.rstd[bn_l][k];
+        acc[0] = __builtin_fmaf(dn, zh, acc[0]);
+        acc[1] += dn;
+        const float dz = dn * g_r;
+        acc[2] += dz;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[3 + j] = __builtin_fmaf(dz, xi[j], acc[3 + j]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[(part * 64 + k) * 8 + q] = acc[q];
+    __syncthreads();
+    for (int o = tid; o < 64 * 8; o += kThreads) {
+        const int kk = o >> 3, q = o & 7;
+        const float v = red[(0 * 64 + kk) * 8 + q] + red[(1 * 64 + kk) * 8 + q] + red[(2 * 64 + kk) * 8 + q] + red[(3 * 64 + kk) * 8 + q];
+        const int p = q == 0 ? G + kk : q == 1 ? BE + kk : q == 2 ? Bb + kk : W + kk * 5 + (q - 3);
+        grad[p] = first ? v : grad[p] + v;
+    }
+    __syncthreads();
+}
+
+// Adam (torch.optim.Adam's formula: theta -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)) + soft update of the target,
+// four parameters per thread and pass (16-byte accesses; [p0, p1) is 16-byte aligned -- the padding floats carry zero gradients)
+__device__ __forceinline__ void adam_soft(const Args& A, int p0, int p1, float lr, float bc1, float bc2s, int tid) {
+    const float c1 = 1.0f - A.beta1, c2 = 1.0f - A.beta2, step = lr / bc1, omt = 1.0f - A.tau;
+    for (int p = p0 + tid * 4; p < p1; p += kThreads * 4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(A.grad + p), m4 = *reinterpret_cast<const float4*>(A.adam_m + p),
+                     v4 = *reinterpret_cast<const float4*>(A.adam_v + p), o4 = *reinterpret_cast<const float4*>(A.online + p),
+                     t4 = *reinterpret_cast<const float4*>(A.target + p);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w},
+                    oo[4] = {o4.x, o4.y, o4.z, o4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+        float mo[4], vo[4], th[4], tg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mo[q] = __builtin_fmaf(A.beta1, mm[q], c1 * g[q]);
+            vo[q] = __builtin_fmaf(A.beta2, vv[q], c2 * g[q] * g[q]);
+            th[q] = oo[q] - step * (mo[q] / (sqrtf(vo[q]) / bc2s + A.adam_eps));
+            tg[q] = __builtin_fmaf(A.tau, th[q], omt * tt[q]);
+        }
+        *reinterpret_cast<float4*>(A.adam_m + p) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+        *reinterpret_cast<float4*>(A.adam_v + p) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+        *reinterpret_cast<float4*>(A.online + p) = make_float4(th[0], th[1], th[2], th[3]);
+        *reinterpret_cast<float4*>(A.target + p) = make_float4(tg[0], tg[1], tg[2], tg[3]);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Lds& L = *reinterpret_cast<Lds*>(lds_raw);
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int ntiles = A.batch / kTile;
+    const float invB = 1.0f / (float)A.batch;
+    float* X0 = L.X[0]; float* X1 = L.X[1]; float* X2 = L.X[2]; float* X3 = L.X[3]; float* X4 = L.X[4];
+
+    // rows of the ring this update trains on: given, drawn here, or the first `batch` rows
+    auto draw = [&](int q, uint32_t round) -> int {   // uniform row in [0, ring_count): one Philox word per (draw, round)
+        uint32_t o[4];
+        philox4x32_10((uint32_t)q, round, A.ctr_lo, A.ctr_hi, A.seed_lo, A.seed_hi, o);
+        return (int)(((unsigned long long)o[0] * (unsigned long long)(uint32_t)A.ring_count) >> 32);
+    };
+    if (A.idx == nullptr && A.ring_count > 0) {
+        for (int q = tid; q < A.batch; q += kThreads) L.sel[q] = draw(q, 0u);
+        __syncthreads();
+        if (A.batch <= 256 && A.ring_count >= A.batch) {
+            // random.sample's law (RL/MR_ddpg.py:37-44): no row twice.  A draw that repeats an EARLIER one is redrawn until the set
+            // is distinct (rejection keeps the joint law uniform over ordered samples without repetition); bounded rounds.
+            for (uint32_t round = 1; round < 64u; ++round) {
+                int dup = 0;
+                if (tid < A.batch) {
+                    const int mine = L.sel[tid];
+                    for (int j = 0; j < tid; ++j) dup |= (L.sel[j] == mine);
+                }
+                const int any = __syncthreads_or(dup);
+                if (!any) break;
+                if (dup) L.sel[tid] = draw(tid, round);
+                __syncthreads();
+            }
+        }
+    }
+    const bool sampled = A.idx == nullptr && A.ring_count > 0;
+    const bool one_tile = ntiles == 1;
+    auto load_tile = [&](int tile, bool force) {   // gather the tile's transitions
+        if (one_tile && !force) return;            // a single tile stays in LDS for all three phases
+        if (tid < kTile) {
+            const int q = tile * kTile + tid;
+            L.rows[tid] = A.idx != nullptr ? A.idx[q] : (sampled ? L.sel[q] : q);
+            if (A.idx_out != nullptr) A.idx_out[q] = L.rows[tid];
+        }
+        __syncthreads();
+        for (int q = tid; q < kTile * 5; q += kThreads) {
+            const int i = q / 5, j = q - 5 * i;
+            L.s[q] = A.s[(long long)L.rows[i] * 5 + j];
+            L.s2[q] = A.s2[(long long)L.rows[i] * 5 + j];
+        }
+        if (tid < kTile * 2) L.a[tid] = A.a[(long long)L.rows[tid >> 1] * 2 + (tid & 1)];
+        if (tid < kTile) { L.r[tid] = A.r[L.rows[tid]]; L.d[tid] = A.d[L.rows[tid]]; }
+        __syncthreads();
+    };
+    // critic hidden layer 2 + output for the tile: z2[f][i] = T1 hc1 + T2 act + bt2 over the staged critic; returns this thread's
+    // 2 x 4 tile (features 2 ty .., samples 4 tx ..) of z2
+    auto critic_l2 = [&](const float* HC1_FM, const float* act, float (&z)[2][4]) {
+        lgemm<2, 4, 64, true>(&L.P[C_T1], 64, HC1_FM, 64, ty * 2, tx * 4, z);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f = ty * 2 + u;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = tx * 4 + v;
+                z[u][v] += __builtin_fmaf(L.P[C_T2 + f * 2], act[i * 2], __builtin_fmaf(L.P[C_T2 + f * 2 + 1], act[i * 2 + 1], L.P[C_BT2 + f]));
+            }
+        }
+    };
+
+    if (tid == 0) { L.loss[0] = 0.f; L.loss[1] = 0.f; }
+    if (tid < 2) {      // Adam bias corrections of this update (the step counters live on the device: graph replays advance them)
+        const int t = A.steps[tid] + 1;
+        L.bc[tid * 2 + 0] = (float)(1.0 - pow((double)A.beta1, (double)t));
+        L.bc[tid * 2 + 1] = (float)sqrt(1.0 - pow((double)A.beta2, (double)t));
+    }
+    // ------------------------------------------------------------------------------------------------ targets y
+    stage_params(L, A.target, A.bn + 3 * 2 * 64, A.bn_eps, tid);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        load_tile(tile, true);
+        layer1(L, L.s2, A_W1, A_B1, A_G1, A_BE1, 0, X0, nullptr, tid);                      // mu'(s2): layer 1
+        __syncthreads();
+        {
+            float z[4][4];
+            lgemm<4, 4, 64, true>(&L.P[A_W2], 64, X0, 64, ty * 4, tx * 4, z);                // layer 2: z[f][i]
+            float pz[4][2] = {};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = ty * 4 + u;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float n = __builtin_fmaf(L.P[A_G2 + f], (z[u][v] + L.P[A_B2 + f] - L.mean[1][f]) * L.rstd[1][f], L.P[A_BE2 + f]);
+                    const float h = n > 0.f ? n : 0.f;
+                    pz[v][0] = __builtin_fmaf(L.P[A_W3 + f], h, pz[v][0]);
+                    pz[v][1] = __builtin_fmaf(L.P[A_W3 + 64 + f], h, pz[v][1]);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { X1[(ty * 64 + tx * 4 + v) * 2] = pz[v][0]; X1[(ty * 64 + tx * 4 + v) * 2 + 1] = pz[v][1]; }
+        }
+        __syncthreads();
+        if (tid < kTile * 2) {                                                              // output layer + tanh: a2 = mu'(s2)
+            float z3 = L.P[A_B3 + (tid & 1)];
+            for (int q = 0; q < 16; ++q) z3 += X1[q * 128 + tid];
+            L.ap[tid] = tanhf(z3) * ((tid & 1) ? A.bound1 : A.bound0);
+        }
+        layer1(L, L.s2, C_W1, C_B1, C_G1, C_BE1, 2, X0, nullptr, tid);                      // Q'(s2, a2): layer 1 (X0 free: its readers passed the barrier)
+        __syncthreads();
+        {
+            float z[2][4];
+            critic_l2(X0, L.ap, z);
+            float pq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) pq[v] = __builtin_fmaf(L.P[C_WO + ty * 2 + u], z[u][v] > 0.f ? z[u][v] : 0.f, pq[v]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) X2[ty * 64 + tx * 4 + v] = pq[v];
+        }
+        __syncthreads();
+        if (tid < kTile) {
+            float q2 = L.P[C_BO];
+            for (int q = 0; q < 16; ++q) q2 += X2[q * 64 + tid];
+            L.y[tile * kTile + tid] = __builtin_fmaf(A.gamma * q2, 1.0f - L.d[tid], L.r[tid]);   // :294
+        }
+        __syncthreads();
+    }
+    // ------------------------------------------------------------------------------------------------ critic step
+    stage_params(L, A.online, A.bn, A.bn_eps, tid);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const bool first = tile == 0;
+        load_tile(tile, false);
+        layer1(L, L.s, C_W1, C_B1, C_G1, C_BE1, 2, X0, X1, tid);                            // hc1: feature-major X0, sample-major X1
+        __syncthreads();
+        {
+            float z[2][4];
+            critic_l2(X0, L.a, z);
+            float pq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float h = z[u][v] > 0.f ? z[u][v] : 0.f;
+                    X2[(tx * 4 + v) * 32 + ty * 2 + u] = h;                                  // hc2 sample-major [i][32]
+                    pq[v] = __builtin_fmaf(L.P[C_WO + ty * 2 + u], h, pq[v]);
+                }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) X3[ty * 64 + tx * 4 + v] = pq[v];
+        }
+        __syncthreads();
+        if (tid < kTile) {
+            float q = L.P[C_BO];
+            for (int w = 0; w < 16; ++w) q += X3[w * 64 + tid];
+            const float e = q - L.y[tile * kTile + tid];
+            L.dq[tid] = 2.0f * e * invB;                                                    // d mean (y - q)^2 / dq
+            atomicAdd(&L.loss[0], e * e * invB);
+        }
+        __syncthreads();
+        {   // output layer and T2 / bt2 gradients; delta of hidden layer 2 in place of hc2
+            const int f = tid & 31, part = tid >> 5;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};   // dWo, dbt2, dT2[0], dT2[1]
+            const float wo = L.P[C_WO + f];
+            for (int i = part * 8; i < part * 8 + 8; ++i) {
+                const float h = X2[i * 32 + f], dq = L.dq[i];
+                acc[0] = __builtin_fmaf(dq, h, acc[0]);
+                const float dl = h > 0.f ? dq * wo : 0.f;
+                X2[i * 32 + f] = dl;
+                acc[1] += dl;
+                acc[2] = __builtin_fmaf(dl, L.a[i * 2], acc[2]);
+                acc[3] = __builtin_fmaf(dl, L.a[i * 2 + 1], acc[3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) X3[4096 / 2 + (part * 32 + f) * 4 + q] = acc[q];     // upper half of X3: the q partials below are consumed
+        }
+        __syncthreads();
+        if (tid < 32 * 4) {
+            const int f = tid >> 2, q = tid & 3;
+            float v = 0.f;
+            for (int part = 0; part < 8; ++part) v += X3[2048 + (part * 32 + f) * 4 + q];
+            const int p = q == 0 ? C_WO + f : q == 1 ? C_BT2 + f : C_T2 + f * 2 + (q - 2);
+            A.grad[p] = first ? v : A.grad[p] + v;
+        }
+        if (tid == 128) {
+            float v = 0.f;
+            for (int i = 0; i < kTile; ++i) v += L.dq[i];
+            A.grad[C_BO] = first ? v : A.grad[C_BO] + v;
+        }
+        {   // dT1[f][k] = sum_i delta2[i][f] hc1[i][k]
+            float g[2][4];
+            lgemm<2, 4, 64, false>(X2, 32, X1, 64, ty * 2, tx * 4, g);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int p = C_T1 + (ty * 2 + u) * 64 + tx * 4 + v;
+                    A.grad[p] = first ? g[u][v] : A.grad[p] + g[u][v];
+                }
+        }
+        {   // d hc1[i][k] = sum_f delta2[i][f] T1[f][k]  ->  dL/dn of layer 1 (sample-major, X4)
+            float e[4][4];
+            lgemm<4, 4, 32, true>(X2, 32, &L.P[C_T1], 64, ty * 4, tx * 4, e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int o = (ty * 4 + u) * 64 + tx * 4 + v;
+                    X4[o] = X1[o] > 0.f ? e[u][v] : 0.f;
+                }
+        }
+        __syncthreads();
+        layer1_backward(L, X4, L.s, C_W1, C_B1, C_G1, C_BE1, 2, X3, A.grad, first, tid);
+    }
+    __threadfence_block();
+    __syncthreads();
+    adam_soft(A, C_W1, kParams, A.critic_lr, L.bc[0], L.bc[1], tid);
+    __threadfence_block();
+    __syncthreads();
+    // ------------------------------------------------------------------------------------------------ actor step (against the UPDATED critic)
+    for (int p = C_W1 + tid * 4; p < kParams; p += kThreads * 4)
+        *reinterpret_cast<float4*>(&L.P[p]) = *reinterpret_cast<const float4*>(A.online + p);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const bool first = tile == 0;
+        load_tile(tile, false);
+        layer1(L, L.s, A_W1, A_B1, A_G1, A_BE1, 0, X0, X1, tid);                            // h1: X0 feature-major, X1 sample-major
+        __syncthreads();
+        {
+            float z[4][4];
+            lgemm<4, 4, 64, true>(&L.P[A_W2], 64, X0, 64, ty * 4, tx * 4, z);
+            float pz[4][2] = {};
+            float hh[4][4], zz[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = ty * 4 + u;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float zh = (z[u][v] + L.P[A_B2 + f] - L.mean[1][f]) * L.rstd[1][f];
+                    const float n = __builtin_fmaf(L.P[A_G2 + f], zh, L.P[A_BE2 + f]);
+                    const float h = n > 0.f ? n : 0.f;
+                    hh[u][v] = h; zz[u][v] = zh;
+                    pz[v][0] = __builtin_fmaf(L.P[A_W3 + f], h, pz[v][0]);
+                    pz[v][1] = __builtin_fmaf(L.P[A_W3 + 64 + f], h, pz[v][1]);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {                                                    // h2 (X2) and z-hat 2 (X3), sample-major
+                *reinterpret_cast<float4*>(X2 + (tx * 4 + v) * 64 + ty * 4) = make_float4(hh[0][v], hh[1][v], hh[2][v], hh[3][v]);
+                *reinterpret_cast<float4*>(X3 + (tx * 4 + v) * 64 + ty * 4) = make_float4(zz[0][v], zz[1][v], zz[2][v], zz[3][v]);
+                X4[(ty * 64 + tx * 4 + v) * 2] = pz[v][0]; X4[(ty * 64 + tx * 4 + v) * 2 + 1] = pz[v][1];
+            }
+        }
+        __syncthreads();
+        if (tid < kTile * 2) {
+            float z3 = L.P[A_B3 + (tid & 1)];
+            for (int q = 0; q < 16; ++q) z3 += X4[q * 128 + tid];
+            const float t = tanhf(z3);
+            L.th[tid] = t;
+            L.ap[tid] = t * ((tid & 1) ? A.bound1 : A.bound0);                               // a' = mu(s)
+        }
+        __syncthreads();
+        layer1(L, L.s, C_W1, C_B1, C_G1, C_BE1, 2, X4, nullptr, tid);                       // Q(s, a') with the new critic: layer 1 -> X4
+        __syncthreads();
+        {
+            float z[2][4];
+            critic_l2(X4, L.ap, z);
+            float pq[4][3] = {};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = ty * 2 + u;
+                const float wo = L.P[C_WO + f];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const bool on = z[u][v] > 0.f;
+                    pq[v][0] = __builtin_fmaf(wo, on ? z[u][v] : 0.f, pq[v][0]);
+                    pq[v][1] = __builtin_fmaf(on ? wo : 0.f, L.P[C_T2 + f * 2], pq[v][1]);     // dQ/da'_0
+                    pq[v][2] = __builtin_fmaf(on ? wo : 0.f, L.P[C_T2 + f * 2 + 1], pq[v][2]); // dQ/da'_1
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) X0[(ty * 64 + tx * 4 + v) * 3 + c] = pq[v][c];   // X0 (h1 feature-major) is free
+        }
+        __syncthreads();
+        if (tid < kTile) {
+            float q = L.P[C_BO], d0 = 0.f, d1 = 0.f;
+            for (int w = 0; w < 16; ++w) { q += X0[(w * 64 + tid) * 3]; d0 += X0[(w * 64 + tid) * 3 + 1]; d1 += X0[(w * 64 + tid) * 3 + 2]; }
+            atomicAdd(&L.loss[1], -q * invB);
+            const float t0 = L.th[tid * 2], t1 = L.th[tid * 2 + 1];                          // loss = -mean Q: dL/dz3 = -dQ/da' bound (1 - tanh^2) / B
+            L.dz3[tid * 2] = -d0 * invB * A.bound0 * (1.0f - t0 * t0);
+            L.dz3[tid * 2 + 1] = -d1 * invB * A.bound1 * (1.0f - t1 * t1);
+        }
+        __syncthreads();
+        {   // output layer gradients, delta of hidden layer 2 (in place of z-hat 2, X3), gamma / beta / bias 2 gradients
+            const int k = tid & 63, part = tid >> 6;
+            float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // dg2, dbe2, db2, dW3[0][k], dW3[1][k]
+            const float w30 = L.P[A_W3 + k], w31 = L.P[A_W3 + 64 + k], g_r = L.P[A_G2 + k] * L.rstd[1][k];
+            for (int i = part * 16; i < part * 16 + 16; ++i) {
+                const float h = X2[i * 64 + k], d0 = L.dz3[i * 2], d1 = L.dz3[i * 2 + 1];
+                const float dn = h > 0.f ? __builtin_fmaf(d0, w30, d1 * w31) : 0.f;
+                acc[0] = __builtin_fmaf(dn, X3[i * 64 + k], acc[0]);
+                acc[1] += dn;
+                const float dz = dn * g_r;
+                acc[2] += dz;
+                acc[3] = __builtin_fmaf(d0, h, acc[3]);
+                acc[4] = __builtin_fmaf(d1, h, acc[4]);
+                X3[i * 64 + k] = dz;
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) X4[(part * 64 + k) * 5 + q] = acc[q];               // X4: its reader (critic_l2) passed two barriers
+        }
+        __syncthreads();
+        for (int o = tid; o < 64 * 5; o += kThreads) {
+            const int k = o / 5, q = o - 5 * k;
+            const float v = X4[(0 * 64 + k) * 5 + q] + X4[(1 * 64 + k) * 5 + q] + X4[(2 * 64 + k) * 5 + q] + X4[(3 * 64 + k) * 5 + q];
+            const int p = q == 0 ? A_G2 + k : q == 1 ? A_BE2 + k : q == 2 ? A_B2 + k : A_W3 + (q - 3) * 64 + k;
+            A.grad[p] = first ? v : A.grad[p] + v;
+        }
+        if (tid < 2) {
+            float v = 0.f;
+            for (int i = 0; i < kTile; ++i) v += L.dz3[i * 2 + tid];
+            A.grad[A_B3 + tid] = first ? v : A.grad[A_B3 + tid] + v;
+        }
+        {   // dW2[f][k] = sum_i dz2[i][f] h1[i][k]
+            float g[4][4];
+            lgemm<4, 4, 64, false>(X3, 64, X1, 64, ty * 4, tx * 4, g);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int p = A_W2 + (ty * 4 + u) * 64 + tx * 4 + v;
+                    A.grad[p] = first ? g[u][v] : A.grad[p] + g[u][v];
+                }
+        }
+        __syncthreads();                                                                    // X2 (h2) was read above by other threads
+        {   // d h1[i][k] = sum_f dz2[i][f] W2[f][k]  ->  dL/dn of layer 1 (sample-major, X2)
+            float e[4][4];
+            lgemm<4, 4, 64, true>(X3, 64, &L.P[A_W2], 64, ty * 4, tx * 4, e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int o = (ty * 4 + u) * 64 + tx * 4 + v;
+                    X2[o] = X1[o] > 0.f ? e[u][v] : 0.f;
+                }
+        }
+        __syncthreads();
+        layer1_backward(L, X2, L.s, A_W1, A_B1, A_G1, A_BE1, 0, X4, A.grad, first, tid);
+    }
+    __threadfence_block();
+    __syncthreads();
+    adam_soft(A, A_W1, C_W1, A.actor_lr, L.bc[2], L.bc[3], tid);
+    if (tid < 2) A.steps[tid] += 1;
+    if (A.losses != nullptr && tid < 2) A.losses[tid] = L.loss[tid];
+}
+
+}  // namespace learner
+}  // namespace mrsim

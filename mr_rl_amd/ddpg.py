@@ -12,10 +12,28 @@ its components with the same architecture and hyper-parameters, keeping every te
   train             :251-323               gamma=0.99, tau=0.001, Adam 1e-3 / 1e-2, batch 64
 
 Parity: UNPINNED (TensorFlow 1.x / tflearn are absent and training is stochastic); the tests check the
-pieces' mathematics (OU statistics, soft update, ring semantics, critic target) and that the loop runs on
-the device env.  Deliberate differences from the reference loop: N envs step in lockstep (one policy
-forward for all), and the warm-up quirk of :283-286,307 (`state = next_state` skipped while the buffer
-fills) is NOT reproduced.
+pieces' mathematics (OU statistics, soft update, ring semantics, critic target, initialisation moments, the
+batch-norm mode) and that the loop runs on the device env.
+
+What the script does and the twin follows by default (each one switchable):
+  * batch norm (`bn_mode="reference"`): the script never calls tflearn.is_training(True), so tflearn's
+    batch_normalization runs on its moving statistics -- initialised to mean 0 / variance 1 and never updated -- in
+    predict() AND during the gradient steps: a per-feature affine map gamma x / sqrt(1 + eps) + beta with trainable
+    gamma, beta.  `bn_mode="train"` = batch statistics during update() (what a PyTorch user would write).
+  * initialisation (`init="tflearn"`): fully_connected defaults to truncated_normal(stddev=0.02) weights and zero
+    biases (:122,125,207,213-214); batch_normalization to gamma ~ N(1, 0.002), beta = 0; the output layers to
+    U[-3e-3, 3e-3] weights (:131-134,222-223) and zero biases.  `init="torch"` keeps nn.Linear's defaults.
+  * target networks (`target_init="reference"`): the script builds the targets as independently initialised networks
+    and "initialises" them with ONE soft update at tau = 0.001 (:255-257), not a copy.  `"copy"` = hard copy.
+  * warm-up (`DDPG.train(warmup_quirk=True)`): `state = next_state` sits after the `continue` of the warm-up branch
+    (:283-286,307), so while the ring holds fewer than min_batch transitions the policy keeps seeing the episode's
+    reset observation.  With N >= min_batch lockstep envs the ring is full after the first step and the quirk is
+    inert; it matters for small N.  Off by default (N envs in lockstep is already a different loop).
+Deliberate difference: N envs step in lockstep (one policy forward for all).
+
+The learner is device-resident: update() returns tensors (no host sync), `update_graphed()` replays the whole update
+(sample -> critic target -> critic step -> actor step -> two soft updates) as ONE captured hipGraph, and the behaviour
+policy's parameter block is folded / packed / uploaded on the device (actor.DeviceActor.load_module_device).
 """
 import math
 
@@ -83,19 +101,44 @@ class OUNoise:
             self.x_prev[mask] = 0.0
 
 
-def _uniform_(layer, lim):
+def _uniform_(layer, lim, bias_too=True):
     nn.init.uniform_(layer.weight, -lim, lim)
     if layer.bias is not None:
-        nn.init.uniform_(layer.bias, -lim, lim)
+        if bias_too:
+            nn.init.uniform_(layer.bias, -lim, lim)
+        else:
+            nn.init.zeros_(layer.bias)
+
+
+def _tflearn_fc_(layer):
+    """tflearn.fully_connected defaults: weights_init='truncated_normal' (stddev 0.02, cut at two sigma), bias_init='zeros'"""
+    nn.init.trunc_normal_(layer.weight, mean=0.0, std=0.02, a=-0.04, b=0.04)
+    if layer.bias is not None:
+        nn.init.zeros_(layer.bias)
+
+
+def _tflearn_bn_(bn):
+    """tflearn batch_normalization defaults: gamma ~ N(1, 0.002), beta = 0, moving mean 0 / variance 1, epsilon 1e-5"""
+    nn.init.normal_(bn.weight, mean=1.0, std=0.002)
+    nn.init.zeros_(bn.bias)
+    bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+    bn.eps = 1e-5
 
 
 class Actor(nn.Module):
-    def __init__(self, state_dim=5, action_dim=2, action_bound=(20.0, 2 * math.pi)):
+    def __init__(self, state_dim=5, action_dim=2, action_bound=(20.0, 2 * math.pi), init="tflearn"):
         super().__init__()
         self.fc1, self.bn1 = nn.Linear(state_dim, 64), nn.BatchNorm1d(64)
         self.fc2, self.bn2 = nn.Linear(64, 64), nn.BatchNorm1d(64)
         self.out = nn.Linear(64, action_dim)
-        _uniform_(self.out, 3e-3)  # "Final layer weights are init to Uniform[-3e-3, 3e-3]" (:131-132)
+        if init == "tflearn":
+            with torch.no_grad():
+                _tflearn_fc_(self.fc1); _tflearn_fc_(self.fc2); _tflearn_bn_(self.bn1); _tflearn_bn_(self.bn2)
+            _uniform_(self.out, 3e-3, bias_too=False)  # "Final layer weights are init to Uniform[-3e-3, 3e-3]" (:131-134)
+        elif init == "torch":
+            _uniform_(self.out, 3e-3)
+        else:
+            raise ValueError("init must be 'tflearn' or 'torch'")
         self.register_buffer("action_bound", torch.as_tensor(action_bound, dtype=torch.float32))
 
     def forward(self, s):
@@ -105,13 +148,20 @@ class Actor(nn.Module):
 
 
 class Critic(nn.Module):
-    def __init__(self, state_dim=5, action_dim=2):
+    def __init__(self, state_dim=5, action_dim=2, init="tflearn"):
         super().__init__()
         self.fc1, self.bn1 = nn.Linear(state_dim, 64), nn.BatchNorm1d(64)
         self.t1 = nn.Linear(64, 32, bias=False)   # t1.b exists in the reference but is never used (:218-219)
         self.t2 = nn.Linear(action_dim, 32)
         self.out = nn.Linear(32, 1)
-        _uniform_(self.out, 3e-3)
+        if init == "tflearn":
+            with torch.no_grad():
+                _tflearn_fc_(self.fc1); _tflearn_fc_(self.t1); _tflearn_fc_(self.t2); _tflearn_bn_(self.bn1)
+            _uniform_(self.out, 3e-3, bias_too=False)   # :222-223
+        elif init == "torch":
+            _uniform_(self.out, 3e-3)
+        else:
+            raise ValueError("init must be 'tflearn' or 'torch'")
 
     def forward(self, s, a):
         h = torch.relu(self.bn1(self.fc1(s)))
@@ -120,90 +170,221 @@ class Critic(nn.Module):
 
 
 @torch.no_grad()
-def soft_update(target, online, tau):
-    """target <- tau * online + (1 - tau) * target (RL/MR_ddpg.py:101-104,190-193); BN statistics are copied."""
-    for pt, po in zip(target.parameters(), online.parameters()):
-        pt.mul_(1.0 - tau).add_(po, alpha=tau)
-    for bt, bo in zip(target.buffers(), online.buffers()):
-        bt.copy_(bo)
+def soft_update(target, online, tau, copy_buffers=True):
+    """target <- tau * online + (1 - tau) * target over the trainable variables (RL/MR_ddpg.py:101-104,190-193: weights,
+    biases, batch-norm gamma / beta).  copy_buffers: also copy the batch-norm statistics (they are not trainable variables
+    in the reference and never change there; with bn_mode="train" the target must follow the online network's)."""
+    tp, op = list(target.parameters()), list(online.parameters())
+    torch._foreach_mul_(tp, 1.0 - tau)
+    torch._foreach_add_(tp, op, alpha=tau)
+    if copy_buffers:
+        for bt, bo in zip(target.buffers(), online.buffers()):
+            bt.copy_(bo)
 
 
 class DDPG:
     """The training loop of RL/MR_ddpg.py:251-323 for N envs in lockstep."""
 
     def __init__(self, env, gamma=0.99, tau=0.001, actor_lr=1e-3, critic_lr=1e-2, min_batch=64, buffer_size=10000,
-                 seed=0, obs_scale=None, device_actor=False, refresh_every=1):
+                 seed=0, obs_scale=None, device_actor=False, refresh_every=1, bn_mode="reference", init="tflearn",
+                 target_init="reference", sample="auto", fused=False):
         """device_actor=True: the behaviour policy of train() is evaluated INSIDE the env's step kernel
         (mr_rl_amd.actor.DeviceActor: folded eval-mode network + OU noise in libmrsim.so) instead of as eager PyTorch
-        between two launches; its parameters are re-uploaded from the learner's actor every `refresh_every` updates."""
+        between two launches; its parameters are re-uploaded from the learner's actor every `refresh_every` updates
+        (sync_policy() does it on demand).
+        bn_mode / init / target_init: see the module docstring ("reference" = what the script does).
+        sample: "without_replacement" = random.sample's law (RL/MR_ddpg.py:37-44) drawn on the device with fixed shapes
+        (uniform keys + top-k, graph-capturable), "with_replacement" = randint (rings too large for a top-k per update),
+        "auto" = the former up to 65 536 slots.
+        fused=True: update() is ONE hand-written kernel of libmrsim.so (mrsim_ddpg_update: both networks' forward and
+        backward passes, both Adam steps and both soft updates in a single launch; needs bn_mode="reference")."""
         self.env, self.gamma, self.tau, self.min_batch = env, gamma, tau, min_batch
+        if bn_mode not in ("reference", "train"):
+            raise ValueError("bn_mode must be 'reference' or 'train'")
+        if target_init not in ("reference", "copy"):
+            raise ValueError("target_init must be 'reference' or 'copy'")
+        self.bn_mode = bn_mode
         dev = env.device
         torch.manual_seed(seed)
         bound = torch.as_tensor(env.action_space.high, dtype=torch.float32)  # RL/MR_ddpg.py:345
-        self.actor, self.actor_t = Actor(5, 2, bound).to(dev), Actor(5, 2, bound).to(dev)
-        self.critic, self.critic_t = Critic().to(dev), Critic().to(dev)
-        self.actor_t.load_state_dict(self.actor.state_dict())
-        self.critic_t.load_state_dict(self.critic.state_dict())
-        self.opt_a = torch.optim.Adam(self.actor.parameters(), lr=actor_lr)
-        self.opt_c = torch.optim.Adam(self.critic.parameters(), lr=critic_lr)
+        self.actor, self.actor_t = Actor(5, 2, bound, init=init).to(dev), Actor(5, 2, bound, init=init).to(dev)
+        self.critic, self.critic_t = Critic(init=init).to(dev), Critic(init=init).to(dev)
+        if target_init == "copy":
+            self.actor_t.load_state_dict(self.actor.state_dict())
+            self.critic_t.load_state_dict(self.critic.state_dict())
+        else:   # "Initialize target network weights": one soft update of independently initialised targets (:255-257)
+            soft_update(self.actor_t, self.actor, tau, copy_buffers=False)
+            soft_update(self.critic_t, self.critic, tau, copy_buffers=False)
+        self._set_mode(training=False)
+        capt = dev.type == "cuda"
+        self.opt_a = torch.optim.Adam(self.actor.parameters(), lr=actor_lr, capturable=capt, foreach=True)
+        self.opt_c = torch.optim.Adam(self.critic.parameters(), lr=critic_lr, capturable=capt, foreach=True)
+        self.actor_lr, self.critic_lr = actor_lr, critic_lr
         self.buffer = ReplayBuffer(buffer_size, device=dev)
+        if sample == "auto":
+            sample = "without_replacement" if buffer_size <= 65536 else "with_replacement"
+        if sample not in ("without_replacement", "with_replacement"):
+            raise ValueError("sample must be 'auto', 'without_replacement' or 'with_replacement'")
+        self.sample_mode = sample
         self.noise = OUNoise((env.num_envs, 2), device=dev, seed=seed)
         # optional fixed observation scaling (the reference feeds raw observations; obs are O(100))
         self.obs_scale = None if obs_scale is None else torch.as_tensor(obs_scale, dtype=torch.float32, device=dev)
         self.device_actor, self.refresh_every, self._updates = None, max(1, int(refresh_every)), 0
+        self._graph = None
+        self._count_t = torch.zeros((), dtype=torch.float32, device=dev)    # ring fill, as the captured sampler reads it
+        self.last_losses = None
+        self.fused = None
+        if fused:
+            if bn_mode != "reference":
+                raise ValueError("fused=True needs bn_mode='reference'")
+            from .learner import FusedLearner
+            self.fused = FusedLearner(self)
         if device_actor:
             from .actor import DeviceActor
             self.actor.eval()
             self.device_actor = DeviceActor.from_module(self.actor, obs_scale=obs_scale, device=dev, ou=True,
                                                         theta=self.noise.theta, sigma=self.noise.sigma, dt=self.noise.dt,
                                                         reset_on_done=True)   # as train() does with its own OUNoise
-            self.actor.train()
+            self._set_mode(training=False)
+
+    # ------------------------------------------------------------------------------------------------ batch-norm mode
+    def _set_mode(self, training):
+        """bn_mode="reference": every network stays in inference mode for good (tflearn's training mode is never switched
+        on in the script); bn_mode="train": the online networks use batch statistics inside update()."""
+        on = bool(training) and self.bn_mode == "train"
+        self.actor.train(on); self.critic.train(on)
+        self.actor_t.eval(); self.critic_t.eval()
 
     def _prep(self, obs):
         return obs if self.obs_scale is None else obs * self.obs_scale
 
     @torch.no_grad()
     def act(self, obs, explore=True):
-        self.actor.eval()
+        self._set_mode(training=False)
         a = self.actor(self._prep(obs))
-        self.actor.train()
         return a + self.noise() if explore else a
 
-    def update(self):
-        if self.buffer.size() < self.min_batch:
-            return None
-        s, a, r, t, s2 = self.buffer.sample_batch(self.min_batch)
+    # ------------------------------------------------------------------------------------------------ the update
+    def _sample(self, n):
+        """n ring indices on the device with fixed shapes (graph-capturable); reads the fill count from _count_t"""
+        buf = self.buffer
+        if self.sample_mode == "without_replacement":
+            keys = torch.rand(buf.buffer_size, device=buf.s.device)
+            keys = keys + (torch.arange(buf.buffer_size, device=buf.s.device) >= self._count_t).float() * 2.0  # empty slots last
+            return torch.topk(keys, n, largest=False, sorted=False).indices
+        return (torch.rand(n, device=buf.s.device) * self._count_t).long().clamp_(max=buf.buffer_size - 1)
+
+    def _update_body(self, batch=None):
+        """sample -> critic target -> critic step -> actor step -> two soft updates (RL/MR_ddpg.py:288-305); no host sync"""
+        buf = self.buffer
+        if batch is None:
+            idx = self._sample(self.min_batch)
+            s, a, r, t, s2 = buf.s[idx], buf.a[idx], buf.r[idx], buf.t[idx], buf.s2[idx]
+        else:
+            s, a, r, t, s2 = batch
         with torch.no_grad():
-            y = r[:, None] + self.gamma * self.critic_t(s2, self.actor_t(s2)) * (1.0 - t[:, None])  # :295-297
-        loss_c = torch.mean((y - self.critic(s, a)) ** 2)
+            y = r[:, None] + self.gamma * self.critic_t(s2, self.actor_t(s2)) * (1.0 - t[:, None])  # :290-294
+        self._set_mode(training=True)
+        loss_c = torch.mean((y - self.critic(s, a)) ** 2)                                            # :297
         self.opt_c.zero_grad(set_to_none=True); loss_c.backward(); self.opt_c.step()
-        loss_a = -self.critic(s, self.actor(s)).mean()  # ascent along dQ/da (:303-305)
+        loss_a = -self.critic(s, self.actor(s)).mean()  # ascent along dQ/da (:300-302)
         self.opt_a.zero_grad(set_to_none=True); loss_a.backward(); self.opt_a.step()
-        soft_update(self.actor_t, self.actor, self.tau)
-        soft_update(self.critic_t, self.critic, self.tau)
+        self._set_mode(training=False)
+        cb = self.bn_mode == "train"
+        soft_update(self.actor_t, self.actor, self.tau, copy_buffers=cb)                              # :305-306
+        soft_update(self.critic_t, self.critic, self.tau, copy_buffers=cb)
+        return loss_c.detach(), loss_a.detach()
+
+    def update(self, batch=None):
+        """One learner update.  Returns (critic loss, actor loss) as device TENSORS -- nothing is synchronised -- or None
+        while the ring holds fewer than min_batch transitions (RL/MR_ddpg.py:283-286).  batch: optional explicit
+        (s, a, r, done, s2) instead of a ring sample (tests)."""
+        if batch is None and self.buffer.size() < self.min_batch:
+            return None
+        if self.fused is not None:
+            self.last_losses = self.fused.update(batch)     # one launch: the rows are drawn in the kernel
+        else:
+            self._count_t.fill_(float(self.buffer.size()))
+            self.last_losses = self._update_body(batch)
+        self._after_update()
+        return self.last_losses
+
+    def _after_update(self):
         self._updates += 1
         if self.device_actor is not None and self._updates % self.refresh_every == 0:
-            self.actor.eval()
-            self.device_actor.load_module(self.actor)    # fold batch norm, pack, upload (19 KB)
-            self.actor.train()
-        return float(loss_c.detach()), float(loss_a.detach())
+            self.sync_policy()
 
-    def train_collected(self, episodes, updates_per_episode=4, sample=4096, streams=2, math="f32"):
+    def sync_policy(self, policy=None, slot=None):
+        """Upload the learner's current actor into the behaviour policy's parameter block(s) (fold batch norm, pack, copy:
+        all on the device, ordered on the current stream -- no host synchronisation)."""
+        pol = self.device_actor if policy is None else policy
+        if pol is not None:
+            if self.fused is not None:
+                self.fused.export_to_modules()
+            pol.load_module_device(self.actor, slot=slot)
+
+    def capture_update(self):
+        """Capture one whole update as a hipGraph (torch.cuda.CUDAGraph is the capture plumbing; Adam runs with
+        capturable=True, the sampler reads the ring's fill count from a device word).  update_graphed() replays it."""
+        if self.fused is not None:
+            return None     # the fused learner is one launch already
+        if self._graph is not None:
+            return self._graph
+        if self.buffer.size() < self.min_batch:
+            raise RuntimeError("capture_update: the ring holds fewer than min_batch transitions")
+        dev = self.buffer.s.device
+        self._count_t.fill_(float(self.buffer.size()))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):          # warm-up on a side stream, as torch's graph recipe asks (allocator, Adam state)
+            for _ in range(3):
+                self._update_body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_losses = self._update_body()
+        return self._graph
+
+    def update_graphed(self, n=1):
+        """n learner updates, each ONE graph replay.  Returns the loss tensors of the last one (device, no sync)."""
+        if self.fused is not None:
+            for _ in range(n):
+                self.update()
+            return self.last_losses
+        if self.buffer.size() < self.min_batch:
+            return None                       # RL/MR_ddpg.py:283-286: no update while the ring fills
+        if self._graph is None:
+            self.capture_update()
+        self._count_t.fill_(float(self.buffer.size()))
+        for _ in range(n):
+            self._graph.replay()
+        self._updates += n
+        self.last_losses = self._graph_losses
+        return self.last_losses
+
+    def train_collected(self, episodes, updates_per_episode=4, sample=4096, streams=2, math="f32", graphed=True,
+                        on_episode=None, stats=None, warm_episodes=0):
         """The loop of RL/MR_ddpg.py:251-323 at collection speed: every episode of all N envs is ONE fused launch group of
         the rollout kernel with this agent's actor (+ OU noise) as its in-kernel policy (RolloutCollector(policy=DeviceActor)),
-        `sample` of its N x 51 transitions go into the replay ring, `updates_per_episode` learner updates follow, and the new
-        parameters are uploaded before the next episode starts (the upload waits for the launches that still read the old
-        block).  Needs an env config with auto_reset=True.  Returns the mean return of every episode."""
+        `sample` of its N x 51 transitions go into the replay ring, `updates_per_episode` learner updates follow (graph
+        replays / fused launches: no host sync anywhere in the loop), and the new parameters are folded, packed and uploaded
+        ON THE DEVICE before the next episode starts.  The learner's updates of episode k run while the envs collect
+        episode k + 1 with the parameters of the end of episode k - 1 (the collector double-buffers; one episode of policy lag,
+        as any actor/learner split has); graphed=False runs the eager update instead.
+        The reference does one update per transition (RL/MR_ddpg.py:288-305); with N lockstep envs that ratio is
+        updates_per_episode / (N x 51) -- say which one you ran.  Needs an env config with auto_reset=True.
+        Returns the mean return of every episode (device tensors gathered once at the end: one host sync).
+        stats: optional dict that receives the wall-clock seconds of episodes [warm_episodes, episodes) (the device is
+        synchronised at both ends of that span -- a measurement aid, two host syncs)."""
         from .actor import DeviceActor
         from .collector import RolloutCollector
         env = self.env
         if not env.cfg.auto_reset:
             raise ValueError("train_collected needs MRConfig(auto_reset=True)")
         scale = None if self.obs_scale is None else self.obs_scale.cpu().numpy()
-        self.actor.eval()
+        self._set_mode(training=False)
         pol = DeviceActor.from_module(self.actor, obs_scale=scale, device=env.device, ou=True, theta=self.noise.theta,
-                                      sigma=self.noise.sigma, dt=self.noise.dt, reset_on_done=True, math=math)
-        self.actor.train()
+                                      sigma=self.noise.sigma, dt=self.noise.dt, reset_on_done=True, math=math, slots=2)
         col = RolloutCollector(env.num_envs, cfg=env.cfg, device=env.device, seed=env.seed_value, env_id0=env.env_id0,
                                goal_table=env.goal_table, streams=streams, policy=pol)
         prev_obs = col.reset().clone()                      # the observation the first action of the episode is computed from
@@ -211,9 +392,20 @@ class DDPG:
         gen = torch.Generator(device=env.device)
         gen.manual_seed(12345)
         returns = []
-        for k in range(episodes):
+        cur = torch.cuda.current_stream(env.device)
+        # Two episodes in flight, two parameter blocks: episode k reads block k % 2.  The learner's updates of episode k run
+        # while the envs collect episode k + 1; their result is uploaded into block k % 2 -- episode k, its last reader, has
+        # finished -- and episode k + 2 starts behind that upload.  Nothing on this path waits on the host.
+        col.collect()
+        if episodes > 1:
             col.collect()
-            b = col.ready(k)
+        import time
+        t_start = None
+        for k in range(episodes):
+            if stats is not None and k == warm_episodes:
+                torch.cuda.synchronize(env.device)
+                t_start = time.perf_counter()
+            b = col.ready(k)                                 # the current stream waits for episode k
             obs_T = b["obs"]
             n_s = min(int(sample), T * N)
             ti = torch.randint(0, T, (n_s,), device=env.device, generator=gen)
@@ -222,29 +414,46 @@ class DDPG:
             # s2 of a terminal transition is the next episode's reset observation here; its target is r alone (1 - done = 0)
             self.buffer.add(self._prep(s), b["actions"][ti, ei], b["rew"][ti, ei], b["done"][ti, ei].float(),
                             self._prep(obs_T[ti, ei]))
-            ended = b["final_len"] > 0
-            returns.append(float(b["final_ret"][ended].mean()) if bool(ended.any()) else float("nan"))
+            ended = (b["final_len"] > 0).float()
+            returns.append((b["final_ret"] * ended).sum() / ended.sum().clamp(min=1.0))
             prev_obs = obs_T[T - 1].clone()
             col.release(k)
-            for _ in range(updates_per_episode):
-                self.update()
-            col.join()                                       # no launch reads the parameter block any more
-            self.actor.eval()
-            pol.load_module(self.actor)
-            self.actor.train()
+            if graphed and env.device.type == "cuda":
+                self.update_graphed(updates_per_episode)
+            else:
+                for _ in range(updates_per_episode):
+                    self.update()
+            if k + 2 < episodes:
+                self.sync_policy(pol, slot=k % 2)
+                col.collect(after=cur)                       # episode k + 2: behind the upload, beside episode k + 1's tail
+            if on_episode is not None:
+                on_episode(k, returns[-1])
+        col.join()
+        if stats is not None and t_start is not None:
+            torch.cuda.synchronize(env.device)
+            stats.update({"seconds": time.perf_counter() - t_start, "episodes_timed": episodes - warm_episodes,
+                          "env_steps_timed": (episodes - warm_episodes) * T * N, "updates_timed": (episodes - warm_episodes) * updates_per_episode})
         col.check_status()
+        self.sync_policy(pol)
         self.collector, self.device_actor = col, pol
-        return returns
+        return [float(x) for x in torch.stack(returns).cpu()] if returns else []
 
-    def train(self, total_steps, updates_per_step=1, log_every=0):
-        """Runs `total_steps` lockstep env steps (N transitions each); returns per-episode returns seen."""
+    def train(self, total_steps, updates_per_step=1, log_every=0, warmup_quirk=False, observe=None):
+        """Runs `total_steps` lockstep env steps (N transitions each); returns per-episode returns seen.
+        warmup_quirk=True reproduces RL/MR_ddpg.py:283-286,307: while the ring holds fewer than min_batch transitions
+        after a step, `state = next_state` is skipped -- the policy keeps seeing (and the ring keeps storing as `state`)
+        the observation the episode was reset to.  observe: optional callback(step, obs_fed_to_the_policy) (tests)."""
         env = self.env
         obs = env.reset().clone()
         returns = []
         if self.device_actor is not None and env._actions_out is None:
             raise ValueError("DDPG(device_actor=True) needs MRVecEnv(track_actions=True): the replay ring stores the applied actions")
         for k in range(total_steps):
+            if observe is not None:
+                observe(k, obs)
             if self.device_actor is not None:   # policy + exploration noise + MR_Env.step in ONE kernel
+                if warmup_quirk:
+                    raise ValueError("warmup_quirk needs the eager policy: the in-kernel actor reads the env's own observation")
                 obs2, rew, done, info = env.step(actor=self.device_actor)
                 a = env._actions_out.clone()
             else:
@@ -254,10 +463,14 @@ class DDPG:
             s2 = torch.where(done[:, None], info["final_obs"], obs2) if env.cfg.auto_reset else obs2
             self.buffer.add(self._prep(obs), a, rew, done.float(), self._prep(s2))
             if env.cfg.auto_reset and bool(done.any()):
-                returns.append(float(info["final_ret"][done].mean()))
+                returns.append(float(info["final_ret"][done].mean()))   # (one host read per episode end)
                 if self.device_actor is None:
                     self.noise.reset(done)      # (the device actor zeroes its OU state in-kernel: reset_on_done)
-            obs = obs2.clone()
+            warming = warmup_quirk and self.buffer.size() < self.min_batch
+            if not warming:
+                obs = obs2.clone()                  # :307 (skipped by the `continue` of :283-286 while the ring fills)
+            elif env.cfg.auto_reset and bool(done.any()):
+                obs = torch.where(done[:, None], obs2, obs)   # `if done: break` -> the next episode's state = env.reset()
             for _ in range(updates_per_step):
                 self.update()
             if log_every and (k + 1) % log_every == 0 and returns:

@@ -360,7 +360,7 @@ class MRVecEnv:
 
     def launch_rollout(self, T, first, n, act_t=None, shared_actions=False, act64=False, traj=None, sp_T=None, obs_T=None,
                        rew_T=None, done_T=None, acts_T=None, final_ret=None, final_len=None, carry="f32", step_idx=None,
-                       stream=None, timed_into=None, events=None, prepare_only=False, actor=None):
+                       stream=None, timed_into=None, events=None, prepare_only=False, actor=None, actor_slot=0):
         """One mrsim_rollout launch over the envs [first, first + n) of this env set (a sub-shard when n < num_envs):
         state, final_* and every [T, N, ...] buffer are passed advanced to env `first`, the buffers keep their row
         length N (MrsimRolloutIO.row_stride), the RNG keys stay the GLOBAL env ids.  Does not advance step_idx (the
@@ -396,7 +396,7 @@ class MRVecEnv:
         if actor is not None:
             if act_t is not None:
                 raise ValueError("launch_rollout: pass actions or actor, not both")
-            actor_struct = actor.struct(N, first, n)   # OU state advanced to env `first`; kept alive by the closure
+            actor_struct = actor.struct(N, first, n, slot=actor_slot)   # OU state advanced to env `first`; kept alive by the closure
             io.actor = C.pointer(actor_struct)
         strm = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
         head = (C.byref(self._params), n, self.env_id0 + first, C.byref(st), C.byref(io), self.seed_value)

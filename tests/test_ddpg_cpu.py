@@ -65,3 +65,133 @@ def test_soft_update():
     soft_update(b, a, 0.001)
     for p in b.parameters():
         assert torch.allclose(p, torch.full_like(p, 0.001))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the twin follows what the script does (RL/MR_ddpg.py:120-137,207-223,255-257,283-286,307)
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeSpace:
+    high = np.array([20.0, 2 * math.pi], dtype=np.float32)
+
+
+class _FakeCfg:
+    auto_reset = False
+
+
+class _FakeEnv:
+    """the attributes DDPG reads of an MRVecEnv, on the CPU: obs = [step, env, 0, 0, 0], an episode ends every `ep` steps"""
+
+    def __init__(self, n=1, ep=1000):
+        self.num_envs, self.device, self.action_space, self.cfg = n, torch.device("cpu"), _FakeSpace(), _FakeCfg()
+        self._actions_out, self.t, self.ep = None, 0, ep
+
+    def _obs(self):
+        o = torch.zeros((self.num_envs, 5))
+        o[:, 0] = float(self.t)
+        o[:, 1] = torch.arange(self.num_envs, dtype=torch.float32)
+        return o
+
+    def reset(self):
+        self.t = 0
+        return self._obs()
+
+    def step(self, a):
+        self.t += 1
+        done = torch.full((self.num_envs,), self.t % self.ep == 0)
+        return self._obs(), torch.full((self.num_envs,), 10.0), done, {}
+
+
+def _fill(agent, n=256, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    s = torch.randn(n, 5, generator=g)
+    agent.buffer.add(s, torch.randn(n, 2, generator=g), torch.randn(n, generator=g), (torch.rand(n, generator=g) < 0.1).float(),
+                     s + 0.1 * torch.randn(n, 5, generator=g))
+
+
+def test_tflearn_initialisation_moments():
+    torch.manual_seed(3)
+    a, c = Actor(), Critic()
+    for lin in (a.fc1, a.fc2, c.fc1, c.t1, c.t2):       # fully_connected: truncated_normal(stddev 0.02) cut at two sigma, zero bias
+        w = lin.weight.detach()
+        assert w.abs().max() <= 0.04 + 1e-7
+        if w.numel() >= 2048:
+            assert abs(w.std().item() - 0.02 * 0.8796) < 1.5e-3 and abs(w.mean().item()) < 1.5e-3
+        assert lin.bias is None or float(lin.bias.abs().max()) == 0.0
+    for bn in (a.bn1, a.bn2, c.bn1):                     # batch_normalization: gamma ~ N(1, 0.002), beta 0, moving stats (0, 1)
+        assert abs(bn.weight.mean().item() - 1.0) < 1.5e-3 and 5e-4 < bn.weight.std().item() < 4e-3
+        assert float(bn.bias.abs().max()) == 0.0 and float(bn.running_mean.abs().max()) == 0.0
+        assert torch.equal(bn.running_var, torch.ones(64)) and bn.eps == 1e-5
+    for out in (a.out, c.out):                           # output layers: U[-3e-3, 3e-3] weights, zero bias
+        assert out.weight.abs().max() <= 3e-3 and float(out.bias.abs().max()) == 0.0
+    assert Actor(init="torch").fc1.bias.abs().max() > 0  # nn.Linear's defaults are still there on request
+
+
+def test_reference_bn_mode_is_a_fixed_affine_map_during_the_gradient_steps():
+    """tflearn.is_training is never switched on in the script: update() must not touch the batch-norm statistics, and the
+    networks' outputs for a sample must not depend on the rest of the batch"""
+    from mr_rl_amd.ddpg import DDPG
+    agent = DDPG(_FakeEnv(4), seed=1)
+    _fill(agent)
+    stats = [(bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone())
+             for bn in (agent.actor.bn1, agent.actor.bn2, agent.critic.bn1)]
+    w0 = agent.actor.fc2.weight.detach().clone()
+    for _ in range(5):
+        out = agent.update()
+        assert isinstance(out[0], torch.Tensor) and isinstance(out[1], torch.Tensor) and out[0].dim() == 0   # no float(): no host sync
+    for bn, (m, v, k) in zip((agent.actor.bn1, agent.actor.bn2, agent.critic.bn1), stats):
+        assert torch.equal(bn.running_mean, m) and torch.equal(bn.running_var, v) and torch.equal(bn.num_batches_tracked, k)
+    assert not torch.equal(agent.actor.fc2.weight, w0) and not agent.actor.training and not agent.critic.training
+    assert agent.actor.bn1.weight.grad is not None      # gamma / beta are trainable variables
+    s = torch.randn(8, 5)
+    assert torch.allclose(agent.actor(s)[:1], agent.actor(s[:1]), atol=1e-6)
+    # bn_mode="train": batch statistics in update(), running statistics move, targets follow them
+    agent2 = DDPG(_FakeEnv(4), seed=1, bn_mode="train")
+    _fill(agent2)
+    agent2.update()
+    assert agent2.actor.bn1.num_batches_tracked.item() > 0
+    assert torch.equal(agent2.actor_t.bn1.running_mean, agent2.actor.bn1.running_mean)
+
+
+def test_target_networks_start_one_soft_update_from_their_own_initialisation():
+    from mr_rl_amd.ddpg import DDPG
+    ref = DDPG(_FakeEnv(1), seed=5)
+    cp = DDPG(_FakeEnv(1), seed=5, target_init="copy")
+    assert torch.equal(cp.actor_t.fc2.weight, cp.actor.fc2.weight) and torch.equal(cp.critic_t.t1.weight, cp.critic.t1.weight)
+    d = (ref.actor_t.fc2.weight - ref.actor.fc2.weight).abs().mean().item()
+    assert d > 5e-3        # two independent truncated normals of stddev 0.02, moved 0.1 % towards each other (:255-257)
+    assert torch.equal(ref.actor.fc2.weight, cp.actor.fc2.weight)   # same seed, same online network
+
+
+def test_sampler_without_replacement_respects_the_fill_count():
+    from mr_rl_amd.ddpg import DDPG
+    agent = DDPG(_FakeEnv(1), seed=0, buffer_size=500)
+    _fill(agent, 100)
+    agent._count_t.fill_(100.0)
+    for _ in range(20):
+        idx = agent._sample(64)
+        assert idx.max().item() < 100 and len(set(idx.tolist())) == 64      # random.sample: distinct, only filled slots
+    agent.sample_mode = "with_replacement"
+    assert agent._sample(64).max().item() < 100
+
+
+def test_warmup_quirk_observation_sequence():
+    """RL/MR_ddpg.py:283-286,307: `state = next_state` is skipped while the ring holds fewer than min_batch transitions"""
+    from mr_rl_amd.ddpg import DDPG
+    seen = []
+    agent = DDPG(_FakeEnv(1), seed=0, min_batch=4)
+    agent.train(7, warmup_quirk=True, observe=lambda k, o: seen.append(float(o[0, 0])))
+    assert seen == [0.0, 0.0, 0.0, 0.0, 4.0, 5.0, 6.0]
+    assert agent.buffer.s[:4, 0].tolist() == [0.0, 0.0, 0.0, 0.0] and agent.buffer.s2[:4, 0].tolist() == [1.0, 2.0, 3.0, 4.0]
+    seen2 = []
+    DDPG(_FakeEnv(1), seed=0, min_batch=4).train(5, observe=lambda k, o: seen2.append(float(o[0, 0])))
+    assert seen2 == [0.0, 1.0, 2.0, 3.0, 4.0]           # default: the lockstep loop advances every step
+
+
+def test_soft_update_leaves_statistics_alone_in_reference_mode():
+    a, b = Actor(), Actor()
+    with torch.no_grad():
+        a.bn1.running_mean.fill_(3.0)
+    soft_update(b, a, 0.5, copy_buffers=False)
+    assert float(b.bn1.running_mean.abs().max()) == 0.0
+    soft_update(b, a, 0.5)
+    assert torch.equal(b.bn1.running_mean, a.bn1.running_mean)

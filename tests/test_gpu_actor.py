@@ -382,8 +382,9 @@ def test_ddpg_twin_trains_with_the_device_actor():
         want = agent.actor(env.obs * torch.tensor(SCALE, device="cuda"))
     bound = agent.actor.action_bound
     assert ((got - want).abs() / bound).max().item() < ACTOR_TOL
-    follow = DeviceActor(agent.device_actor.weights, device="cuda", ou=False)   # what train() uploaded last
-    assert torch.equal(follow.forward(env), got)
+    # what train() uploaded last (folded, packed and written ON THE DEVICE, DeviceActor.load_module_device) is bit for bit what the
+    # library's host packer makes of the same network
+    assert torch.equal(quiet.blob, agent.device_actor.blob)
 
 
 def test_ddpg_twin_trains_at_collection_speed():
@@ -405,6 +406,9 @@ def test_ddpg_twin_trains_at_collection_speed():
     with torch.no_grad():
         want = agent.actor(agent.collector.env.obs * torch.tensor(SCALE, device="cuda"))
     from mr_rl_amd.actor import DeviceActor
-    quiet = DeviceActor(agent.device_actor.weights, device="cuda", ou=False)
+    quiet = DeviceActor.from_module(agent.actor, obs_scale=SCALE, device="cuda", ou=False)
     got = quiet.forward(agent.collector.env)
     assert ((got - want).abs() / agent.actor.action_bound).max().item() < ACTOR_TOL
+    # both parameter blocks of the behaviour policy hold the learner's final network (uploaded on the device)
+    for b in agent.device_actor.blobs:
+        assert torch.equal(b, quiet.blob)

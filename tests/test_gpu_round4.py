@@ -215,3 +215,123 @@ def test_collapsed_increment_law_full_size():
             assert stats.kstest(r[::8, j], "norm").pvalue > 1e-4
         assert abs(np.corrcoef(r[:, 0], r[:, 1])[0, 1]) < 0.01
     env.check_status()
+
+
+# ---------------------------------------------------------------------------
+# the DDPG learner: device-resident update, hipGraph replay, fused kernel (RL/MR_ddpg.py:288-305)
+# ---------------------------------------------------------------------------
+def _randomise(agent, seed):
+    """the same non-trivial parameters in every agent built with this seed: O(1) pre-activations, gamma / beta off their
+    defaults, so that every gradient path carries signal"""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for net in (agent.actor, agent.critic, agent.actor_t, agent.critic_t):
+            for name, p in net.named_parameters():
+                if "bn" in name:
+                    v = torch.rand(p.shape, generator=g) + 0.5 if name.endswith("weight") else (torch.rand(p.shape, generator=g) - 0.5) * 0.4
+                elif name.endswith("bias"):
+                    v = (torch.rand(p.shape, generator=g) - 0.5) * 0.2
+                else:
+                    v = (torch.rand(p.shape, generator=g) * 2 - 1) / (p.shape[1] ** 0.5)
+                p.copy_(v.to(p.device))
+
+
+def _batch(n, seed):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    s = torch.randn(n, 5, generator=g)
+    return tuple(x.cuda() for x in (s, torch.randn(n, 2, generator=g) * 3, torch.randn(n, generator=g), (torch.rand(n, generator=g) < 0.2).float(),
+                                    s + 0.3 * torch.randn(n, 5, generator=g)))
+
+
+@pytest.mark.parametrize("B", [64, 256])
+def test_fused_ddpg_update_equals_the_eager_pytorch_update(B):
+    """mrsim_ddpg_update (one launch: target, critic step, actor step against the updated critic, Adam, soft updates) against the
+    eager PyTorch update of mr_rl_amd/ddpg.py on the same batch, three updates in a row: losses, actor gradients, online and target
+    parameters.  Parameters are compared where the first Adam steps are well conditioned (|g| well above Adam's epsilon; elsewhere
+    lr g / (|g| + eps) amplifies the summation-order noise of g and only a loose bound is meaningful)."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.ddpg import DDPG
+    from mr_rl_amd.learner import ACTOR_LAYOUT, CRITIC_LAYOUT
+    env = MRVecEnv(256, cfg=MRConfig(auto_reset=True), seed=0)
+    eager, fused = DDPG(env, seed=3, min_batch=B), DDPG(env, seed=3, min_batch=B, fused=True)
+    _randomise(eager, 5); _randomise(fused, 5)
+    for k in range(3):
+        batch = _batch(B, 100 + k)
+        le = eager.update(batch)
+        lf = fused.update(batch)
+        assert abs(float(le[0]) - float(lf[0])) <= 2e-5 * max(1.0, abs(float(le[0])))
+        assert abs(float(le[1]) - float(lf[1])) <= 2e-5 * max(1.0, abs(float(le[1])))
+        # actor gradients (the eager critic's .grad also holds the actor loss's contribution: not comparable)
+        gf = fused.fused.grad
+        for path, off in ACTOR_LAYOUT:
+            p = eager.actor.get_parameter(path)
+            ge = p.grad.reshape(-1)
+            # (sums over the batch with cancellation: the tolerance is relative to the tensor's largest gradient, with a floor for
+            # the two-element output bias whose 64 .. 256 terms nearly cancel)
+            assert float((gf[off:off + ge.numel()] - ge).abs().max()) <= 5e-5 * float(ge.abs().max()) + 2e-7, \
+                (k, path, gf[off:off + ge.numel()][:4].tolist(), ge[:4].tolist())
+    worst = []
+    for net_e, net_f, layout in ((eager.actor, fused.actor, ACTOR_LAYOUT), (eager.critic, fused.critic, CRITIC_LAYOUT),
+                                 (eager.actor_t, fused.actor_t, ACTOR_LAYOUT), (eager.critic_t, fused.critic_t, CRITIC_LAYOUT)):
+        for path, off in layout:
+            pe, pf = net_e.get_parameter(path).detach(), net_f.get_parameter(path).detach()
+            scale = float(pe.abs().max())
+            err = (pe - pf).abs()
+            # three Adam steps of lr 1e-3 / 1e-2 each.  At least 95 % of every tensor to 5e-6 of its scale (observed: 3e-6 worst),
+            # every element to 10 % of ONE step (an element whose gradient is ~1e-8 = Adam's epsilon takes a step of
+            # lr g / (|g| + eps), which turns the summation-order noise of g into a visible fraction of lr)
+            worst.append((float(err.max()) / scale, path))
+            assert float((err <= 5e-6 * scale + 5e-7).float().mean()) >= 0.95, (path, float(err.max()), scale)
+            assert float(err.max()) <= 1e-3, (path, float(err.max()))
+    print("worst |fused - eager| / max|theta| per tensor:", sorted(worst, reverse=True)[:6])
+    assert fused.fused.steps.tolist() == [3, 3]
+    # the modules alias the learner's vectors: no copy to see the new parameters
+    assert fused.actor.fc2.weight.data_ptr() == fused.fused.online.data_ptr() + 512 * 4
+
+
+def test_graphed_update_matches_eager_statistics_and_fused_learner_trains():
+    """update_graphed(): the whole update as one hipGraph replay -- parameters move, losses stay finite, no host sync needed;
+    the fused learner fits a fixed ring: the critic's TD loss falls by an order of magnitude."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.ddpg import DDPG
+    env = MRVecEnv(256, cfg=MRConfig(auto_reset=True), seed=0)
+    for kw in ({}, {"fused": True}):
+        ag = DDPG(env, seed=1, **kw)
+        s, a, r, d, s2 = _batch(8192, 7)
+        r = (s[:, 0] * a[:, 0]).tanh()                       # a learnable reward
+        ag.buffer.add(s, a, r, torch.zeros_like(d), s2)
+        w0 = ag.critic.t1.weight.detach().clone()
+        first = [float(ag.update_graphed(1)[0]) for _ in range(20)]
+        ag.update_graphed(1500)
+        last = [float(ag.update_graphed(1)[0]) for _ in range(20)]
+        assert np.isfinite(first + last).all() and not torch.equal(w0, ag.critic.t1.weight)
+        assert np.mean(last) < 0.25 * np.mean(first), (kw, np.mean(first), np.mean(last))
+        assert ag._updates == 1540
+
+
+def test_fused_learner_draws_its_batch_in_the_kernel():
+    """no idx given: the kernel draws the ring rows itself -- distinct rows (random.sample's law, RL/MR_ddpg.py:37-44) inside the
+    filled part of the ring, different rows every update, uniform over the ring"""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.ddpg import DDPG
+    env = MRVecEnv(256, cfg=MRConfig(auto_reset=True), seed=0)
+    ag = DDPG(env, seed=1, fused=True, buffer_size=1000)
+    s, a, r, d, s2 = _batch(300, 7)
+    ag.buffer.add(s, a, r, d, s2)                               # 300 of 1000 slots filled
+    ag.fused.idx_out = torch.full((64,), -1, dtype=torch.int32, device="cuda")
+    seen, prev = torch.zeros(300, device="cuda"), None
+    for k in range(400):
+        ag.update()
+        rows = ag.fused.idx_out.clone()
+        assert int(rows.min()) >= 0 and int(rows.max()) < 300 and len(set(rows.tolist())) == 64
+        assert prev is None or not torch.equal(rows, prev)
+        prev = rows
+        seen += torch.bincount(rows.long(), minlength=300).float()
+    expect = 400 * 64 / 300.0
+    assert float(seen.min()) > 0.6 * expect and float(seen.max()) < 1.4 * expect       # +- 4 sigma of a binomial
+    assert np.isfinite([float(x) for x in ag.last_losses]).all()
