@@ -237,11 +237,29 @@ typedef struct MrsimDdpgLearner {
  * r [.], done [.] are DEVICE arrays (e.g. the replay ring).  Which rows: idx (DEVICE [batch] int32) if given; else, with
  * ring_count > 0, drawn IN the kernel from [0, ring_count) by Philox4x32-10 keyed by (seed, draw_counter) -- without
  * repetition, the law of random.sample (RL/MR_ddpg.py:37-44), for batch <= 256 <= ring_count, with repetition otherwise;
- * else rows 0 .. batch-1.  idx_out: optional DEVICE [batch] int32, the rows used.  losses_out: optional DEVICE [2] {critic
- * loss, actor loss}.  Everything is enqueued on `stream`; no host synchronisation. */
-int mrsim_ddpg_update(const MrsimDdpgLearner* learner, int32_t batch, const float* s, const float* a, const float* r,
-                      const float* done, const float* s2, const int32_t* idx, int32_t ring_count, uint64_t seed,
+ * else rows 0 .. batch-1.  n_updates >= 1 consecutive updates run in this ONE launch (update i draws with draw_counter + i; with idx
+ * or fixed rows every update sees the same batch): the learner then occupies one compute unit for the whole burst instead of
+ * queueing n launches behind a device full of env kernels.  idx_out: optional DEVICE [batch] int32, the rows of the last update.
+ * losses_out: optional DEVICE [2] {critic loss, actor loss} of the last update.  Everything is enqueued on `stream`; no host
+ * synchronisation. */
+int mrsim_ddpg_update(const MrsimDdpgLearner* learner, int32_t batch, int32_t n_updates, const float* s, const float* a,
+                      const float* r, const float* done, const float* s2, const int32_t* idx, int32_t ring_count, uint64_t seed,
                       uint64_t draw_counter, int32_t* idx_out, float* losses_out, void* stream);
+
+/* Replay-ring feed for the learner (RL/MR_ddpg.py:279-281 replay_buffer.add, for a sampled subset of one collected launch group):
+ * n transitions (t, env) drawn by Philox keyed by (seed, draw_counter) from the resident [T][N][.] outputs of mrsim_rollout are
+ * written to ring rows head .. head + n - 1 (mod capacity).  state = the observation the action was computed from (prev_obs [N][5]
+ * for t = 0, obs_T[t-1] otherwise) x obs_scale, next state = obs_T[t] x obs_scale.  [N][5] observation layout.  All DEVICE. */
+int mrsim_replay_push(int64_t n_envs, int32_t T, const float* obs_T, const float* actions_T, const float* rew_T,
+                      const uint8_t* done_T, const float* prev_obs, const float* obs_scale5_host, int32_t n, float* ring_s,
+                      float* ring_a, float* ring_r, float* ring_done, float* ring_s2, int32_t capacity, int32_t head,
+                      uint64_t seed, uint64_t draw_counter, void* stream);
+/* The learner's online actor (MrsimDdpgLearner.online) -> the packed block of MrsimActor.blob, on the device: batch norm folded
+ * with the given moving statistics (bn_stats: the learner's, its online actor's two layers), weights permuted and split exactly
+ * as mrsim_actor_fold_bn_host + mrsim_actor_pack_host do (bit-identical block).  One launch on `stream`; order it before the
+ * launches that read the block. */
+int mrsim_actor_pack_device(const float* learner_online, const float* bn_stats, float bn_eps, const float* obs_scale5_host,
+                            const float* action_bound2_host, float* blob, void* stream);
 
 int mrsim_abi_version(void);
 const char* mrsim_strerror(int code);

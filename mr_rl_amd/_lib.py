@@ -24,6 +24,7 @@ SYMBOLS = (
     "mrsim_device_count", "mrsim_device_name",
     "mrsim_event_create", "mrsim_event_destroy", "mrsim_event_elapsed_ms", "mrsim_rollout_events", "mrsim_step_events",
     "mrsim_actor_fold_bn_host", "mrsim_actor_pack_host", "mrsim_actor_forward", "mrsim_ddpg_update",
+    "mrsim_replay_push", "mrsim_actor_pack_device",
 )
 
 
@@ -128,7 +129,9 @@ def load(path):
     L.mrsim_actor_fold_bn_host.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp]
     L.mrsim_actor_pack_host.argtypes = [C.POINTER(MrsimActorWeights), vp]
     L.mrsim_actor_forward.argtypes = [PP, i64, u32, C.POINTER(MrsimActor), PS, vp, vp, u64, u64, vp]
-    L.mrsim_ddpg_update.argtypes = [C.POINTER(MrsimDdpgLearner), i32, vp, vp, vp, vp, vp, vp, i32, u64, u64, vp, vp, vp]
+    L.mrsim_ddpg_update.argtypes = [C.POINTER(MrsimDdpgLearner), i32, i32, vp, vp, vp, vp, vp, vp, i32, u64, u64, vp, vp, vp]
+    L.mrsim_replay_push.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, u64, u64, vp]
+    L.mrsim_actor_pack_device.argtypes = [vp, vp, C.c_float, vp, vp, vp, vp]
     L.mrsim_device_count.restype = C.c_int
     L.mrsim_device_name.argtypes = [C.c_int, C.c_char_p, i32]
     for name in SYMBOLS:

@@ -194,6 +194,20 @@ class DeviceActor:
             if slot is None or i == slot:
                 b.copy_(block)
 
+    def load_from_learner(self, fused, slot=None):
+        """(Re)write parameter block `slot` (default: all) from a FusedLearner's online actor: ONE launch of the library's
+        device-side fold + pack (mrsim_actor_pack_device), ordered on the current stream."""
+        import torch
+        L = _lib.lib()
+        scale = (C.c_float * 5)(*[float(x) for x in self.weights["obs_scale"]])
+        bound = (C.c_float * 2)(*[float(x) for x in self.weights["action_bound"]])
+        strm = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        for i, b in enumerate(self.blobs):
+            if slot is None or i == slot:
+                _lib.check(L.mrsim_actor_pack_device(C.c_void_p(fused.online.data_ptr()), C.c_void_p(fused.bn_stats.data_ptr()),
+                                                     float(fused.struct.bn_eps), scale, bound, C.c_void_p(b.data_ptr()), strm),
+                           "mrsim_actor_pack_device")
+
     def ou_tensor(self, n):
         import torch
         if not self.ou:

@@ -1339,7 +1339,7 @@ int mrsim_actor_forward(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     return launch(lc, mr_actor_kernel<kNoiseSpec, kActF32>, K.n, K, AC, obs, (int)p->obs_layout, aux, actions);
 }
 
-int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, const float* s, const float* a, const float* r, const float* done,
+int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, int32_t n_updates, const float* s, const float* a, const float* r, const float* done,
                       const float* s2, const int32_t* idx, int32_t ring_count, uint64_t seed, uint64_t draw_counter,
                       int32_t* idx_out, float* losses_out, void* stream) {
     static_assert(MRSIM_DDPG_PARAMS == learner::kParams && MRSIM_DDPG_MAX_BATCH == learner::kMaxBatch, "mrsim.h / mrsim_learner.h");
@@ -1359,13 +1359,46 @@ int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, const float* s,
             return MRSIM_ELAUNCH;
         attr_set = true;
     }
-    if (ring_count < 0) return MRSIM_EINVAL;
+    if (ring_count < 0 || n_updates < 1 || n_updates > 65536) return MRSIM_EINVAL;
     learner::Args A{Lr->online, Lr->target, Lr->adam_m, Lr->adam_v, Lr->grad_scratch, Lr->steps, Lr->bn_stats, s, a, r, done, s2, idx,
                     idx_out, ring_count, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)draw_counter, (uint32_t)(draw_counter >> 32),
-                    losses_out, batch, Lr->bn_eps, Lr->gamma, Lr->tau, Lr->actor_lr, Lr->critic_lr, Lr->beta1, Lr->beta2, Lr->adam_eps,
+                    losses_out, batch, n_updates, Lr->bn_eps, Lr->gamma, Lr->tau, Lr->actor_lr, Lr->critic_lr, Lr->beta1, Lr->beta2, Lr->adam_eps,
                     Lr->action_bound[0], Lr->action_bound[1]};
     hipLaunchKernelGGL(learner::mr_ddpg_update_kernel, dim3(1), dim3(learner::kThreads), sizeof(learner::Lds),
                        static_cast<hipStream_t>(stream), A);
+    return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+}
+
+int mrsim_replay_push(int64_t n_envs, int32_t T, const float* obs_T, const float* actions_T, const float* rew_T, const uint8_t* done_T,
+                      const float* prev_obs, const float* obs_scale, int32_t n, float* ring_s, float* ring_a, float* ring_r,
+                      float* ring_done, float* ring_s2, int32_t capacity, int32_t head, uint64_t seed, uint64_t draw_counter,
+                      void* stream) {
+    if (n_envs < 1 || T < 1 || n < 0 || capacity < 1 || head < 0 || head >= capacity || n > capacity || obs_T == nullptr ||
+        actions_T == nullptr || rew_T == nullptr || done_T == nullptr || prev_obs == nullptr || obs_scale == nullptr ||
+        ring_s == nullptr || ring_a == nullptr || ring_r == nullptr || ring_done == nullptr || ring_s2 == nullptr)
+        return MRSIM_EINVAL;
+    if (n_envs > 0xFFFFFFFFll) return MRSIM_ERANGE;
+    if (n == 0) return MRSIM_OK;
+    int rc = check_device();
+    if (rc) return rc;
+    learner::PushArgs A{obs_T, actions_T, rew_T, done_T, prev_obs, ring_s, ring_a, ring_r, ring_done, ring_s2, (long long)n_envs, T, n,
+                        capacity, head, {obs_scale[0], obs_scale[1], obs_scale[2], obs_scale[3], obs_scale[4]},
+                        (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)draw_counter, (uint32_t)(draw_counter >> 32)};
+    hipLaunchKernelGGL(learner::mr_replay_push_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+    return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+}
+
+int mrsim_actor_pack_device(const float* learner_online, const float* bn_stats, float bn_eps, const float* obs_scale,
+                            const float* action_bound, float* blob, void* stream) {
+    if (learner_online == nullptr || bn_stats == nullptr || obs_scale == nullptr || action_bound == nullptr || blob == nullptr ||
+        !(bn_eps > 0.0f))
+        return MRSIM_EINVAL;
+    if (!aligned16(blob)) return MRSIM_EALIGN;
+    int rc = check_device();
+    if (rc) return rc;
+    learner::PackArgs A{learner_online, bn_stats, blob, bn_eps, action_bound[0], action_bound[1],
+                        {obs_scale[0], obs_scale[1], obs_scale[2], obs_scale[3], obs_scale[4]}};
+    hipLaunchKernelGGL(learner::mr_actor_pack_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), A);
     return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 

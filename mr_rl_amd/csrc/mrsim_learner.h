@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "mrsim_device.h"   // philox4x32_10
+#include "mrsim_actor.h"    // the packed actor block's layout
 
 namespace mrsim {
 namespace learner {
@@ -46,6 +47,7 @@ struct Args {
     uint32_t seed_lo, seed_hi, ctr_lo, ctr_hi;   //   counter = (draw, round, update counter)): without replacement up to 256 rows
     float* losses;                  // [2] critic loss, actor loss (device), or null
     int32_t batch;
+    int32_t n_updates;              // consecutive updates in this one launch (each draws its own rows: draw counter + i)
     float bn_eps, gamma, tau, actor_lr, critic_lr, beta1, beta2, adam_eps;
     float bound0, bound1;
 };
@@ -217,12 +219,20 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
     float* X0 = L.X[0]; float* X1 = L.X[1]; float* X2 = L.X[2]; float* X3 = L.X[3]; float* X4 = L.X[4];
 
     // rows of the ring this update trains on: given, drawn here, or the first `batch` rows
+    uint32_t c_lo = A.ctr_lo, c_hi = A.ctr_hi;    // draw counter of the current update
     auto draw = [&](int q, uint32_t round) -> int {   // uniform row in [0, ring_count): one Philox word per (draw, round)
         uint32_t o[4];
-        philox4x32_10((uint32_t)q, round, A.ctr_lo, A.ctr_hi, A.seed_lo, A.seed_hi, o);
+        philox4x32_10((uint32_t)q, round, c_lo, c_hi, A.seed_lo, A.seed_hi, o);
         return (int)(((unsigned long long)o[0] * (unsigned long long)(uint32_t)A.ring_count) >> 32);
     };
-    if (A.idx == nullptr && A.ring_count > 0) {
+    const bool sampled = A.idx == nullptr && A.ring_count > 0;
+    const bool one_tile = ntiles == 1;
+  for (int upd = 0; upd < A.n_updates; ++upd) {   // (body not re-indented: one update = everything down to the closing brace)
+    {
+        const unsigned long long c = (((unsigned long long)A.ctr_hi << 32) | A.ctr_lo) + (unsigned long long)upd;
+        c_lo = (uint32_t)c; c_hi = (uint32_t)(c >> 32);
+    }
+    if (sampled) {
         for (int q = tid; q < A.batch; q += kThreads) L.sel[q] = draw(q, 0u);
         __syncthreads();
         if (A.batch <= 256 && A.ring_count >= A.batch) {
@@ -241,8 +251,6 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             }
         }
     }
-    const bool sampled = A.idx == nullptr && A.ring_count > 0;
-    const bool one_tile = ntiles == 1;
     auto load_tile = [&](int tile, bool force) {   // gather the tile's transitions
         if (one_tile && !force) return;            // a single tile stays in LDS for all three phases
         if (tid < kTile) {
@@ -561,6 +569,104 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
     adam_soft(A, A_W1, C_W1, A.actor_lr, L.bc[2], L.bc[3], tid);
     if (tid < 2) A.steps[tid] += 1;
     if (A.losses != nullptr && tid < 2) A.losses[tid] = L.loss[tid];
+    __threadfence_block();
+    __syncthreads();    // the next update of this launch stages the parameters this one wrote
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Replay ring feed (RL/MR_ddpg.py:279-281 replay_buffer.add for a sampled subset of one collected launch group): n transitions
+// (t, env) drawn by Philox from a resident [T][N][.] rollout, written to ring rows head .. head + n - 1 (mod capacity):
+//   s = obs before step t (prev_obs for t = 0, else obs_T[t-1]) * obs_scale, a = actions_T[t], r = rew_T[t], done = done_T[t],
+//   s2 = obs_T[t] * obs_scale   (after an auto-reset that is the next episode's reset observation; its target is r alone)
+// ---------------------------------------------------------------------------------------------------------------------
+struct PushArgs {
+    const float* obs_T; const float* act_T; const float* rew_T; const uint8_t* done_T; const float* prev_obs;   // [T][N][5] ... [N][5]
+    float* s; float* a; float* r; float* d; float* s2;                                                           // the ring
+    long long N; int32_t T, n, capacity, head;
+    float scale[5];
+    uint32_t seed_lo, seed_hi, ctr_lo, ctr_hi;
+};
+__global__ __launch_bounds__(256) void mr_replay_push_kernel(const PushArgs A) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= A.n) return;
+    uint32_t o[4];
+    philox4x32_10((uint32_t)q, 0x52494E47u /* "RING" */, A.ctr_lo, A.ctr_hi, A.seed_lo, A.seed_hi, o);
+    const int t = (int)(((unsigned long long)o[0] * (unsigned long long)(uint32_t)A.T) >> 32);
+    const long long e = (long long)(((unsigned long long)o[1] * (unsigned long long)A.N) >> 32);
+    const int row = (A.head + q) % A.capacity;
+    const float* so = t == 0 ? A.prev_obs + e * 5 : A.obs_T + ((long long)(t - 1) * A.N + e) * 5;
+    const float* s2o = A.obs_T + ((long long)t * A.N + e) * 5;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { A.s[(long long)row * 5 + j] = so[j] * A.scale[j]; A.s2[(long long)row * 5 + j] = s2o[j] * A.scale[j]; }
+    const long long te = (long long)t * A.N + e;
+    A.a[(long long)row * 2] = A.act_T[te * 2]; A.a[(long long)row * 2 + 1] = A.act_T[te * 2 + 1];
+    A.r[row] = A.rew_T[te];
+    A.d[row] = A.done_T[te] ? 1.0f : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Behaviour-policy upload on the device: the learner's online actor (parameter vector above, offsets A_*) -> the packed block the
+// env kernels read (mrsim_actor.h layout).  Same arithmetic as the host pair mrsim_actor_fold_bn_host + mrsim_actor_pack_host
+// (batch norm folded in double and rounded once; bf16 terms by round-to-nearest-even): the block is bit-identical (tested).
+// ---------------------------------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* params;      // learner layout (actor part)
+    const float* bn;          // [2 layers][2 mean/var][64] of the actor
+    float* blob;              // [kActBlobFloats]
+    float eps, bound0, bound1;
+    float scale[5];
+};
+__device__ __forceinline__ uint16_t bf16_rne_bits(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__global__ __launch_bounds__(256) void mr_actor_pack_kernel(const PackArgs A) {
+    __shared__ float w1f[64 * 5], b1f[64], w2f[64 * 64], b2f[64];
+    const int tid = threadIdx.x;
+    constexpr int H = 64;
+    // fold: y = gamma (W x + b - mean) / sqrt(var + eps) + beta == W' x + b'   (double, rounded once)
+    for (int f = tid; f < H; f += 256) {
+        const double g1 = (double)A.params[A_G1 + f] / sqrt((double)A.bn[(0 * 2 + 1) * 64 + f] + (double)A.eps);
+        for (int k = 0; k < 5; ++k) w1f[f * 5 + k] = (float)((double)A.params[A_W1 + f * 5 + k] * g1);
+        b1f[f] = (float)(((double)A.params[A_B1 + f] - (double)A.bn[(0 * 2 + 0) * 64 + f]) * g1 + (double)A.params[A_BE1 + f]);
+        const double g2 = (double)A.params[A_G2 + f] / sqrt((double)A.bn[(1 * 2 + 1) * 64 + f] + (double)A.eps);
+        b2f[f] = (float)(((double)A.params[A_B2 + f] - (double)A.bn[(1 * 2 + 0) * 64 + f]) * g2 + (double)A.params[A_BE2 + f]);
+    }
+    for (int o = tid; o < H * H; o += 256) {
+        const int f = o >> 6;
+        const double g2 = (double)A.params[A_G2 + f] / sqrt((double)A.bn[(1 * 2 + 1) * 64 + f] + (double)A.eps);
+        w2f[o] = (float)((double)A.params[A_W2 + o] * g2);
+    }
+    for (int o = tid; o < kActBlobFloats; o += 256) A.blob[o] = 0.0f;
+    __syncthreads();
+    if (tid < 128) {
+        const int rt = tid >> 6, lane = tid & 63, f = 32 * rt + (lane & 31), h = lane >> 5;
+        for (int s = 0; s < 3; ++s) {
+            const int k = 2 * s + h;
+            A.blob[kActA1 + (rt * 3 + s) * 64 + lane] = k < 5 ? w1f[f * 5 + k] * A.scale[k] : 0.0f;
+        }
+        for (int q = 0; q < 32; ++q) A.blob[kActA2 + ((rt * 8 + q / 4) * 64 + lane) * 4 + (q % 4)] = w2f[f * H + act_kperm(q, h)];
+        uint16_t* bf = reinterpret_cast<uint16_t*>(A.blob + kActA2bf);
+        for (int s = 0; s < 4; ++s)
+            for (int jj = 0; jj < 8; ++jj) {
+                float r = w2f[f * H + act_kperm(8 * s + jj, h)];
+                for (int part = 0; part < 3; ++part) {
+                    const uint16_t t = bf16_rne_bits(r);
+                    bf[((((rt * 4 + s) * 3 + part) * 64 + lane) * 8) + jj] = t;
+                    r -= __uint_as_float((uint32_t)t << 16);
+                }
+            }
+    } else if (tid < 192) {
+        const int o = tid - 128, h = o >> 5, q = o & 31;
+        A.blob[kActC1 + h * 32 + q] = b1f[act_kperm(q, h)];
+        A.blob[kActC2 + h * 32 + q] = b2f[act_kperm(q, h)];
+        for (int oo = 0; oo < 2; ++oo) A.blob[kActW3 + (h * 2 + oo) * 32 + q] = A.params[A_W3 + oo * H + act_kperm(q, h)];
+    } else if (tid == 192) {
+        A.blob[kActTail + 0] = A.params[A_B3 + 0]; A.blob[kActTail + 1] = A.params[A_B3 + 1];
+        A.blob[kActTail + 2] = A.bound0; A.blob[kActTail + 3] = A.bound1;
+    }
 }
 
 }  // namespace learner

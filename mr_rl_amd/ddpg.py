@@ -70,6 +70,24 @@ class ReplayBuffer:
     def size(self):
         return self.count
 
+    def push_from_rollout(self, b, prev_obs, n, obs_scale, seed, counter):
+        """n transitions sampled (Philox, keyed by (seed, counter)) from one collected launch group `b` (RolloutCollector.ready():
+        [T, N, .] obs / actions / rew / done, [N][5] rows) into the ring -- ONE launch of libmrsim's mrsim_replay_push instead
+        of ~20 indexing kernels.  prev_obs: [N, 5] observations the group's first actions were computed from."""
+        import ctypes as C
+        from . import _lib
+        obs_T, act_T, rew_T, done_T = b["obs"], b["actions"], b["rew"], b["done"]
+        T, N = int(obs_T.shape[0]), int(obs_T.shape[1])
+        n = min(int(n), self.buffer_size)
+        sc = (C.c_float * 5)(*([1.0] * 5 if obs_scale is None else [float(x) for x in obs_scale]))
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        strm = C.c_void_p(torch.cuda.current_stream(self.s.device).cuda_stream)
+        _lib.check(_lib.lib().mrsim_replay_push(N, T, p(obs_T), p(act_T), p(rew_T), p(done_T.view(torch.uint8)), p(prev_obs), sc, n,
+                                                p(self.s), p(self.a), p(self.r), p(self.t), p(self.s2), self.buffer_size, self.head,
+                                                int(seed), int(counter), strm), "mrsim_replay_push")
+        self.head = (self.head + n) % self.buffer_size
+        self.count = min(self.count + n, self.buffer_size)
+
     def sample_batch(self, batch_size):
         n = min(batch_size, self.count)
         idx = torch.randperm(self.count, device=self.s.device, generator=self.gen)[:n]
@@ -320,8 +338,9 @@ class DDPG:
         pol = self.device_actor if policy is None else policy
         if pol is not None:
             if self.fused is not None:
-                self.fused.export_to_modules()
-            pol.load_module_device(self.actor, slot=slot)
+                pol.load_from_learner(self.fused, slot=slot)     # one launch of the library's device-side fold + pack
+            else:
+                pol.load_module_device(self.actor, slot=slot)
 
     def capture_update(self):
         """Capture one whole update as a hipGraph (torch.cuda.CUDAGraph is the capture plumbing; Adam runs with
@@ -346,10 +365,14 @@ class DDPG:
         return self._graph
 
     def update_graphed(self, n=1):
-        """n learner updates, each ONE graph replay.  Returns the loss tensors of the last one (device, no sync)."""
-        if self.fused is not None:
-            for _ in range(n):
-                self.update()
+        """n learner updates, each ONE graph replay (fused learner: all n in ONE launch).  Returns the loss tensors of the last
+        one (device, no sync).  Does not refresh a device-side behaviour policy: call sync_policy() when the envs should see the
+        new parameters."""
+        if self.fused is not None:                # n updates in ONE launch: the learner holds one compute unit for the burst
+            if self.buffer.size() < self.min_batch:
+                return None
+            self.last_losses = self.fused.update(None, n=n)
+            self._updates += n
             return self.last_losses
         if self.buffer.size() < self.min_batch:
             return None                       # RL/MR_ddpg.py:283-286: no update while the ring fills
@@ -393,9 +416,11 @@ class DDPG:
         gen.manual_seed(12345)
         returns = []
         cur = torch.cuda.current_stream(env.device)
-        # Two episodes in flight, two parameter blocks: episode k reads block k % 2.  The learner's updates of episode k run
-        # while the envs collect episode k + 1; their result is uploaded into block k % 2 -- episode k, its last reader, has
-        # finished -- and episode k + 2 starts behind that upload.  Nothing on this path waits on the host.
+        native_push = env.device.type == "cuda" and not col.env._soa      # mrsim_replay_push reads [N][5] observation rows
+        # Two episodes in flight, two parameter blocks: episode k reads block k % 2.  When episode k is ready its block is free:
+        # the learner's parameters as of then are uploaded into it and episode k + 2 starts behind that upload; the learner's
+        # burst on episode k's transitions runs beside episodes k + 1 / k + 2 (policy lag: up to three episodes, as in any
+        # actor / learner split).  Nothing on this path waits on the host.
         col.collect()
         if episodes > 1:
             col.collect()
@@ -406,26 +431,34 @@ class DDPG:
                 torch.cuda.synchronize(env.device)
                 t_start = time.perf_counter()
             b = col.ready(k)                                 # the current stream waits for episode k
+            if k + 2 < episodes:
+                # Block k % 2 was last read by episode k, which has finished: upload the parameters the learner has produced so far
+                # (its launches of the previous iterations precede this one on the current stream) and start episode k + 2 behind
+                # the upload alone.  The learner burst of THIS iteration is enqueued after it and runs beside the collection.
+                if k > 0:
+                    self.sync_policy(pol, slot=k % 2)
+                col.collect(after=cur)
             obs_T = b["obs"]
             n_s = min(int(sample), T * N)
-            ti = torch.randint(0, T, (n_s,), device=env.device, generator=gen)
-            ei = torch.randint(0, N, (n_s,), device=env.device, generator=gen)
-            s = torch.where((ti == 0)[:, None], prev_obs[ei], obs_T[(ti - 1).clamp(min=0), ei])
-            # s2 of a terminal transition is the next episode's reset observation here; its target is r alone (1 - done = 0)
-            self.buffer.add(self._prep(s), b["actions"][ti, ei], b["rew"][ti, ei], b["done"][ti, ei].float(),
-                            self._prep(obs_T[ti, ei]))
+            if native_push:
+                self.buffer.push_from_rollout(b, prev_obs, n_s, scale, 12345, k)
+            else:
+                ti = torch.randint(0, T, (n_s,), device=env.device, generator=gen)
+                ei = torch.randint(0, N, (n_s,), device=env.device, generator=gen)
+                s = torch.where((ti == 0)[:, None], prev_obs[ei], obs_T[(ti - 1).clamp(min=0), ei])
+                # s2 of a terminal transition is the next episode's reset observation here; its target is r alone (1 - done = 0)
+                self.buffer.add(self._prep(s), b["actions"][ti, ei], b["rew"][ti, ei], b["done"][ti, ei].float(),
+                                self._prep(obs_T[ti, ei]))
             ended = (b["final_len"] > 0).float()
             returns.append((b["final_ret"] * ended).sum() / ended.sum().clamp(min=1.0))
             prev_obs = obs_T[T - 1].clone()
             col.release(k)
-            if graphed and env.device.type == "cuda":
-                self.update_graphed(updates_per_episode)
-            else:
-                for _ in range(updates_per_episode):
-                    self.update()
-            if k + 2 < episodes:
-                self.sync_policy(pol, slot=k % 2)
-                col.collect(after=cur)                       # episode k + 2: behind the upload, beside episode k + 1's tail
+            if updates_per_episode > 0:
+                if graphed and env.device.type == "cuda":
+                    self.update_graphed(updates_per_episode)
+                else:
+                    for _ in range(updates_per_episode):
+                        self.update()
             if on_episode is not None:
                 on_episode(k, returns[-1])
         col.join()

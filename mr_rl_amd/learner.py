@@ -73,7 +73,8 @@ class FusedLearner:
     def export_to_modules(self):
         """nothing to do: the modules alias the learner's vectors"""
 
-    def update(self, batch=None):
+    def update(self, batch=None, n=1):
+        """n consecutive updates in ONE launch (each draws its own rows when batch is None)"""
         import torch
         ag = self.agent
         buf = ag.buffer
@@ -81,18 +82,18 @@ class FusedLearner:
         if batch is None:
             # the rows are drawn INSIDE the kernel (Philox keyed by (seed, update counter); without repetition up to 256 rows,
             # random.sample's law): the whole update is one launch, and the host only passes the ring's fill count
-            s, a, r, t, s2, n = buf.s, buf.a, buf.r, buf.t, buf.s2, ag.min_batch
+            s, a, r, t, s2, nb = buf.s, buf.a, buf.r, buf.t, buf.s2, ag.min_batch
             idx_p, idx, count = None, None, int(buf.size())
         else:
             s, a, r, t, s2 = (x.contiguous().float() for x in batch)
-            n, idx_p, idx = s.shape[0], None, None
-        if n % 64 != 0 or n > _lib.DDPG_MAX_BATCH:
+            nb, idx_p, idx = s.shape[0], None, None
+        if nb % 64 != 0 or nb > _lib.DDPG_MAX_BATCH:
             raise ValueError("the fused learner takes batches that are multiples of 64 (<= %d)" % _lib.DDPG_MAX_BATCH)
         strm = C.c_void_p(torch.cuda.current_stream(buf.s.device).cuda_stream)
         p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
         io = None if self.idx_out is None else p(self.idx_out)
-        _lib.check(self._L.mrsim_ddpg_update(C.byref(self.struct), int(n), p(s), p(a), p(r), p(t), p(s2), idx_p, count, self.seed,
-                                             self.draws, io, p(self.losses), strm), "mrsim_ddpg_update")
-        self.draws += 1
+        _lib.check(self._L.mrsim_ddpg_update(C.byref(self.struct), int(nb), int(n), p(s), p(a), p(r), p(t), p(s2), idx_p, count,
+                                             self.seed, self.draws, io, p(self.losses), strm), "mrsim_ddpg_update")
+        self.draws += int(n)
         self._keep = (idx, s, a, r, t, s2)      # alive until the next call (the launch is asynchronous)
         return self.losses[0], self.losses[1]

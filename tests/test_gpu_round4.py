@@ -335,3 +335,71 @@ def test_fused_learner_draws_its_batch_in_the_kernel():
     expect = 400 * 64 / 300.0
     assert float(seen.min()) > 0.6 * expect and float(seen.max()) < 1.4 * expect       # +- 4 sigma of a binomial
     assert np.isfinite([float(x) for x in ag.last_losses]).all()
+
+
+def test_device_side_policy_upload_and_replay_push_match_the_host_paths():
+    """mrsim_actor_pack_device (fold + pack of the learner's actor in one launch) writes the block mrsim_actor_fold_bn_host +
+    mrsim_actor_pack_host make of the same network, bit for bit; mrsim_replay_push writes the transitions a torch gather of the
+    same (t, env) pairs gives."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.actor import DeviceActor
+    from mr_rl_amd.collector import RolloutCollector
+    from mr_rl_amd.ddpg import DDPG
+    env = MRVecEnv(4096, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=0)
+    ag = DDPG(env, seed=2, obs_scale=[0.01, 0.02, 0.03, 0.04, 0.05], fused=True)
+    _randomise(ag, 9)
+    for _ in range(2):
+        ag.update(_batch(64, 3))
+    host = DeviceActor.from_module(ag.actor, obs_scale=[0.01, 0.02, 0.03, 0.04, 0.05], device="cuda", slots=2)
+    dev = DeviceActor.from_module(ag.actor, obs_scale=[0.01, 0.02, 0.03, 0.04, 0.05], device="cuda", slots=2)
+    for b in dev.blobs:
+        b.fill_(7.0)
+    dev.load_from_learner(ag.fused, slot=1)
+    assert torch.equal(dev.blobs[1], host.blob) and float(dev.blobs[0].min()) == 7.0
+    dev.load_from_learner(ag.fused)
+    assert torch.equal(dev.blobs[0], host.blob)
+    # replay push
+    col = RolloutCollector(4096, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=1, streams=1)
+    prev = col.reset().clone()
+    col.collect()
+    b = col.ready(0)
+    ag.buffer.clear()
+    ag.buffer.push_from_rollout(b, prev, 3000, [0.01, 0.02, 0.03, 0.04, 0.05], 99, 5)
+    ag.buffer.push_from_rollout(b, prev, 9000, [0.01, 0.02, 0.03, 0.04, 0.05], 99, 6)      # wraps around the 10 000-slot ring
+    assert ag.buffer.size() == 10000 and ag.buffer.head == 2000
+    sc = torch.tensor([0.01, 0.02, 0.03, 0.04, 0.05], device="cuda")
+    obs_T, T, N = b["obs"], col.T, 4096
+    s, s2, a = ag.buffer.s, ag.buffer.s2, ag.buffer.a
+    # every stored row is a real transition of the launch group: find its (t, env) through the (unique) next observation
+    flat = (obs_T * sc).reshape(T * N, 5)
+    for row in (0, 1999, 2000, 2500, 9999):
+        hit = (flat == s2[row]).all(dim=1).nonzero()
+        assert hit.numel() >= 1
+        t, e = divmod(int(hit[0]), N)
+        want_s = (prev[e] if t == 0 else obs_T[t - 1, e]) * sc
+        assert torch.equal(s[row], want_s) and torch.equal(a[row], b["actions"][t, e])
+        assert float(ag.buffer.r[row]) == float(b["rew"][t, e]) and float(ag.buffer.t[row]) == float(b["done"][t, e])
+    ts = (flat[:, 0:1] * 0).squeeze()   # noqa: F841  (shape check only)
+    assert len({tuple(x.tolist()) for x in s2[:64]}) > 60            # different transitions, not one repeated
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_ddpg_loop_learns_a_one_step_goal_task(fused):
+    """Smoke-level learning check of the whole loop on the device env, goal reward, fixed seed (tools/learning_check.py): envs start
+    10 .. 14 units beside a goal of radius 10 and every episode is one step; the untrained actor does not move (return -100),
+    a constant action "f ~ -7, cos(alpha) ~ 1" reaches the goal.  Collection with the actor in the kernel, replay push, fused /
+    graph-replayed learner, device-side policy upload: the mean return must rise from below -60 to above 0 (the plateau, ~ +25,
+    is set by the exploration noise that stays on)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("learning_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                "tools", "learning_check.py"))
+    lc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lc)
+    import torch
+    agent, rets = lc.run(fused, 300, 16)
+    assert len(rets) == 300 and np.isfinite(rets).all()
+    assert np.mean(rets[:3]) < -60.0 and np.mean(rets[-30:]) > 0.0, (rets[:5], rets[-5:])
+    with torch.no_grad():
+        a = agent.actor(torch.tensor([[12.0, 0.0, 0.0, 0.0, 12.0]], device="cuda") * 0.1)[0]
+    assert 1.5 * float(a[0]) * float(torch.cos(a[1])) < -2.0          # the learnt action moves the robot into the goal's radius

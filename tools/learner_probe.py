@@ -57,7 +57,7 @@ if a.fused:
 
     def raw(n):
         for _ in range(n):
-            _lib.check(F._L.mrsim_ddpg_update(C.byref(F.struct), a.batch, p(b.s), p(b.a), p(b.r), p(b.t), p(b.s2), p(idx), 0, 0, 0, None, p(F.losses), strm), "upd")
+            _lib.check(F._L.mrsim_ddpg_update(C.byref(F.struct), a.batch, 1, p(b.s), p(b.a), p(b.r), p(b.t), p(b.s2), p(idx), 0, 0, 0, None, p(F.losses), strm), "upd")
     r_raw = rate(raw, a.updates)
     print(f"fused kernel alone (fixed indices)       : {r_raw:10.1f} updates/s  ({1e6 / r_raw:8.1f} us per update)", flush=True)
     r_f = rate(lambda n: [ag3.update() for _ in range(n)], a.updates)

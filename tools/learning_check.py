@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Smoke-level learning check of the DDPG loop on the device env (goal reward, fixed seed): a one-step task a constant action
+solves -- start 10..14 units to the +x side of the goal, radius 10, a0 = 50 (a step moves 1.5 f), every episode is one step
+(max_timesteps = 0): the return is +100 if the step lands inside the radius, -100 otherwise; the untrained actor (output ~ 0)
+does not move.  python tools/learning_check.py [--fused 0|1] [--episodes 300] [--updates 16]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from mr_rl_amd import MRConfig, MRVecEnv
+from mr_rl_amd.ddpg import DDPG
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--fused", type=int, default=1)
+ap.add_argument("--episodes", type=int, default=300)
+ap.add_argument("--updates", type=int, default=16)
+ap.add_argument("--envs", type=int, default=4096)
+ap.add_argument("--ou-sigma", type=float, default=10.0)
+a = ap.parse_args()
+
+
+def task_cfg():
+    return MRConfig(noise_var=0.1, a0=50.0, reward_mode="goal", auto_reset=True, max_timesteps=0, min_dist2goal=10.0,
+                    init_low=(10.0, -1.0), init_high=(14.0, 1.0))
+
+
+def run(fused, episodes, updates, envs=4096, ou_sigma=10.0, seed=0):
+    env = MRVecEnv(envs, cfg=task_cfg(), seed=seed)
+    agent = DDPG(env, seed=seed, obs_scale=[0.1] * 5, fused=bool(fused))
+    agent.noise.sigma = ou_sigma
+    return agent, agent.train_collected(episodes, updates_per_episode=updates, sample=4096)
+
+
+if __name__ == "__main__":
+    agent, rets = run(a.fused, a.episodes, a.updates, a.envs, a.ou_sigma)
+    k = max(1, len(rets) // 10)
+    print("mean return per tenth of the run:", [round(sum(rets[i:i + k]) / k, 1) for i in range(0, len(rets), k)])
+    with torch.no_grad():
+        s = torch.tensor([[12.0, 0.0, 0.0, 0.0, 12.0]], device="cuda") * 0.1
+        print("actor(12, 0) =", agent.actor(s).tolist(), " updates:", agent._updates)
