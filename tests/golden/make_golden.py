@@ -26,6 +26,11 @@ them is copied.  What is committed is data: inputs and the reference's outputs.
                 object under the law the PREVIOUS episode left behind (MR_env.py:181-183), sigma = 0 and one taped sigma > 0 run.
   ref_sim_f64.npz  the ref_sim scenarios with the reference's own float64 action tables (not rounded to float32).
   ref_experiment.npz  MR_data.MRExperiment's dictionaries after three recorded MR_Env episodes (8f-3).
+  ref_increments.npz  sigma > 0 STATISTICS of the reference itself: 20 000 per-step noise increments of Simulator.step at sigma = 1
+                in the DDPG regime (start (110, 115), random actions in the actor range, 200 restarts of 100 steps), nominal and
+                mismatched law: Delta - dt (b1 K0 + (1 - b1) V(action)) normalised to unit variance (/ dt cB sqrt(g^2 + sigma^2)).  The kernels' and the
+                oracle's increments (per-stage and collapsed noise law, fast and spec Box-Muller) are tested against these SAMPLES
+                (two-sample KS, variance ratio), not only against the formula of SURVEY 3.3.
 
 Usage:  python tests/golden/make_golden.py   (writes next to this file)
 """
@@ -412,7 +417,49 @@ def gen_reused():
     print("ref_reused.npz written")
 
 
+def gen_increments():
+    """Per-step noise increments of the reference Simulator at sigma = 1, far from the origin (no step splitting)."""
+    dt, b1, cB = 0.030, 35.0 / 384, float(np.sqrt((500 / 1113) ** 2 + (125 / 192) ** 2 + (2187 / 6784) ** 2 + (11 / 84) ** 2))
+    flat = {}
+    for name, mis, seed in (("inc_nominal_s1", False, 4242), ("inc_mismatched_s1", True, 4243)):
+        rng = np.random.default_rng(seed)
+        np.random.seed(seed)
+        res, resn, nev = [], [], []
+        for ep in range(200):
+            s = MR_simulator.Simulator()
+            s.noise_var = 1.0
+            s.a0 = 1.0
+            s.reset_start_pos(np.array([110.0, 115.0]))
+            s.is_mismatched = mis
+            acts = f32(actions_random(100, rng, idle_frac=0.0, wide=True))
+            for f_t, al in acts:
+                k0 = np.array(s.integrator.f, dtype=np.float64)
+                p0 = np.array(s.integrator.y, dtype=np.float64)
+                n0 = s.integrator.nfev
+                p1 = np.array(s.step(f_t, al), dtype=np.float64)
+                if mis:
+                    a0b = 1.0 + (f_t / 4) * 0.8
+                    V = np.array([a0b * f_t * np.cos(al + 0.1) + 0.2, a0b * f_t * np.sin(al - 0.15) - 0.1])
+                    g = 0.25 * f_t * np.array([np.cos(al + 0.1), np.sin(al - 0.15)])
+                else:
+                    V = np.array([f_t * np.cos(al), f_t * np.sin(al)])
+                    g = np.zeros(2)
+                r = p1 - p0 - dt * (b1 * k0 + (1 - b1) * V)
+                res.append(r)
+                resn.append(r / (dt * cB * np.sqrt(g * g + 1.0)))
+                nev.append(6)      # one rk_step attempt per env step in this regime (checked below through the variance)
+        res, resn = np.asarray(res), np.asarray(resn)
+        flat[f"{name}/res_norm"] = resn.astype(np.float32)
+        flat[f"{name}/sigma"] = np.float64(1.0)
+        flat[f"{name}/mismatched"] = np.int64(mis)
+        print(f"  {name}: {len(res)} increments, std of the normalised residual {resn.std(axis=0)} (1 = SURVEY 3.3's law)")
+    np.savez_compressed(os.path.join(HERE, "ref_increments.npz"), **flat)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "increments":   # only the statistics fixture (the others are unchanged)
+        gen_increments()
+        sys.exit(0)
     import scipy
     print(f"numpy {np.__version__}, scipy {scipy.__version__}, reference at {REF}")
     if len(sys.argv) > 1 and sys.argv[1] == "reused":
@@ -424,3 +471,4 @@ if __name__ == "__main__":
     gen_env()
     gen_experiment()
     gen_reused()
+    gen_increments()
