@@ -157,6 +157,115 @@ def record_rollout(env, T, env_index=0, actions=None, shared_actions=False):
                                  auto_reset=bool(env.cfg.auto_reset))
 
 
+class BatchedEpisodes:
+    """The episodes of ALL N envs of one resident [T, N, .] rollout, cut on the device with tensor operations (no Python loop
+    over envs): episode index of every transition = exclusive cumulative sum of `done` along T; terminal observations of
+    auto-reset steps rebuilt from the recorded fp64 position; reset rows = the observation the previous episode's last step
+    returned.  `dict_of(i)` / `dicts(envs)` give MRExperiment-layout dictionaries (MR_data.py:27-57) identical to
+    record_rollout(env_index=i); the requested envs' columns travel to the host in ONE transfer.
+
+    Tensors (device): ep_index [T, N] int64, ep_count [N] (episodes, the unfinished tail included), ep_len [N, E] transitions
+    per episode (E = max ep_count), ep_return [N, E] float64, step_obs [T, N, 5] float64 (terminal rows rebuilt), obs0 [N, 5]."""
+
+    def __init__(self, obs0, pos0, traj, obs, actions, rew, done, auto_reset, goals=None):
+        import torch
+        T, N = rew.shape
+        self.T, self.N, self.auto_reset = T, N, bool(auto_reset)
+        f64 = torch.float64
+        done = done.bool()
+        o0 = obs0.to(f64).clone()
+        # the reset state in fp64 where the float32 observation is the rounded position (record_rollout does the same per env)
+        same = (o0[:, 0] == pos0[:, 0].float().to(f64)) & (o0[:, 1] == pos0[:, 1].float().to(f64))
+        o0[:, 0] = torch.where(same, pos0[:, 0], o0[:, 0]); o0[:, 1] = torch.where(same, pos0[:, 1], o0[:, 1])
+        o0[:, 4] = torch.where(same, torch.hypot(o0[:, 2] - pos0[:, 0], o0[:, 3] - pos0[:, 1]), o0[:, 4])
+        self.obs0, self._same0 = o0, same
+        d_i = done.long()
+        self.ep_index = torch.cumsum(d_i, 0) - d_i                                  # episodes finished BEFORE step t
+        tail = ~done[T - 1]
+        self.ep_count = d_i.sum(0) + tail.long()
+        E = int(self.ep_count.max().item()) if N else 0
+        self.ep_len = torch.zeros((N, max(E, 1)), dtype=torch.int64, device=rew.device)
+        self.ep_len.scatter_add_(1, self.ep_index.t().contiguous(), torch.ones((N, T), dtype=torch.int64, device=rew.device))
+        self.ep_return = torch.zeros((N, max(E, 1)), dtype=f64, device=rew.device)
+        self.ep_return.scatter_add_(1, self.ep_index.t().contiguous(), rew.to(f64).t().contiguous())
+        so = obs.to(f64).clone()
+        if self.auto_reset:
+            # the returned observation of a done step is the NEXT episode's reset observation: rebuild the terminal one from the
+            # recorded position and the goal (of that step when `goals` [T, N, 2] is given, else the episode's reset observation's)
+            if goals is None:
+                # goal shown by the reset observation of the episode each step belongs to: obs0 for episode 0, else the observation
+                # returned by the previous done step -- carried forward along T
+                g_reset = torch.where(done[:, :, None], obs[:, :, 2:4].to(f64), torch.full_like(obs[:, :, 2:4].to(f64), float("nan")))
+                shifted = torch.cat([o0[None, :, 2:4], g_reset[:-1]], 0)            # value that applies FROM step t on
+                idx = torch.where(torch.isnan(shifted[:, :, 0]), torch.zeros_like(d_i), torch.arange(T, device=rew.device)[:, None].expand(T, N))
+                last = torch.cummax(idx, 0).values                                   # most recent step that set a goal
+                goal = torch.gather(shifted, 0, last[:, :, None].expand(T, N, 2))
+            else:
+                goal = goals.to(f64)
+            term = torch.stack([traj[:, :, 0], traj[:, :, 1], goal[:, :, 0], goal[:, :, 1],
+                                torch.hypot(goal[:, :, 0] - traj[:, :, 0], goal[:, :, 1] - traj[:, :, 1])], 2)
+            so = torch.where(done[:, :, None], term, so)
+        self.step_obs = so
+        self._traj, self._obs, self._act, self._rew, self._done = traj, obs, actions, rew, done
+
+    def dicts(self, envs):
+        """[MRExperiment-layout dict for env i for i in envs]; one device-to-host transfer for all of them"""
+        import torch
+        idx = torch.as_tensor(list(envs), dtype=torch.long, device=self._rew.device)
+        sel = lambda t: t.index_select(1, idx).cpu().numpy()  # noqa: E731
+        traj, so, ob, act, rew, done = (sel(t) for t in (self._traj, self.step_obs, self._obs.double(), self._act.double(),
+                                                          self._rew.double(), self._done))
+        o0 = self.obs0.index_select(0, idx).cpu().numpy()
+        same0 = self._same0.index_select(0, idx).cpu().numpy()
+        out = []
+        for c in range(len(idx)):
+            # distances recomputed with numpy's hypot (the device's may differ in the last place): bit-equal to record_rollout
+            if same0[c]:
+                o0[c, 4] = np.hypot(o0[c, 2] - o0[c, 0], o0[c, 3] - o0[c, 1])
+            if self.auto_reset:
+                m = done[:, c]
+                so[m, c, 4] = np.hypot(so[m, c, 2] - so[m, c, 0], so[m, c, 3] - so[m, c, 1])
+            r = rew[:, c]
+            integer = bool(np.all(r == np.round(r)))
+            d = _empty()
+            bounds = np.flatnonzero(done[:, c]) + 1
+            starts = np.concatenate([[0], bounds])
+            ends = np.concatenate([bounds, [self.T]])
+            reset_obs = o0[c]
+            for a, b in zip(starts, ends):
+                if b == a:
+                    break
+                it = d["iterations"] = d["iterations"] + 1
+                d["states"][it] = np.vstack([reset_obs[:2], traj[a:b, c]])
+                d["observations"][it] = np.vstack([reset_obs, so[a:b, c]])
+                d["actions"][it] = np.vstack([np.zeros(2), act[a:b, c]])
+                d["rewards"][it] = _rewards_column(r[a:b], integer)
+                d["steps"][it] = int(b - a)
+                if b < self.T or done[b - 1, c]:
+                    reset_obs = ob[b - 1, c]
+            out.append(d)
+        return out
+
+    def dict_of(self, env_index):
+        return self.dicts([env_index])[0]
+
+
+def export_all(env, T, actions=None, shared_actions=False):
+    """Run a fused T-step rollout on `env` and cut the episodes of ALL its envs on the device (BatchedEpisodes): the batched form
+    of record_rollout -- MRExperiment's per-step np.vstack bookkeeping (MR_data.py:44-57) for N envs at once."""
+    obs0, pos0 = env.obs.clone(), env.pos.clone()
+    counter0 = env.counter.clone()
+    out = env.rollout(T, actions=actions, shared_actions=shared_actions, want=("traj", "obs", "rew", "done", "actions"))
+    goals = None
+    if env.goal_table is not None and not env.cfg.auto_reset:       # one episode per env, the goal follows the table
+        import torch
+        K, Tg = env.goal_table.shape[0], env.goal_table.shape[1]
+        k = (env.env_id0 + torch.arange(env.num_envs, device=env.device)) % K
+        rows = (counter0.long()[None, :] + 1 + torch.arange(T, device=env.device)[:, None]).clamp(0, Tg - 1)
+        goals = env.goal_table[k[None, :].expand(T, -1), rows]
+    return BatchedEpisodes(obs0, pos0, out["traj"], out["obs"], out["actions"], out["rew"], out["done"], env.cfg.auto_reset, goals=goals)
+
+
 def record_episodes(env, inits, action_tables, env_index=0, **reset_kwargs):
     """The reference's recorded loop (`env.set_save_experice(name)`; per episode `env.reset(init)` then `env.step(a)`
     until done -- MR_env.py:94-95,190-198) for explicit start positions: episode k resets every env of `env` to

@@ -35,6 +35,20 @@ def actions_circle(time_steps=1800, cycles=3, freq=4.0, dt=DT):
     return a
 
 
+def actions_circle_fm(time_steps=300, cycles=3, f_lo=0.1, f_hi=5.0, dt=DT):
+    """main_2d.py:137-160: the 2-D learning set -- `cycles` circles (alpha = linspace(-pi, pi) per circle) whose frequency is
+    modulated along the run, f = (cos(t / 5) + 1) / 2 * (f_hi - f_lo) + f_lo with t = linspace(0, time_steps, time_steps)
+    (the script's 4.9 and 0.1)."""
+    steps = int(time_steps / cycles)
+    one = np.zeros((steps, 3))
+    one[:, 1] = np.linspace(-np.pi, np.pi, steps)
+    a = np.vstack([one] * cycles)
+    t = np.linspace(0, len(a), len(a))
+    a[:, 0] = (np.cos(t / 5) + 1) / 2 * (f_hi - f_lo) + f_lo
+    a[:, 2] = np.arange(len(a)) * dt
+    return a
+
+
 def actions_ramp(freq=4.0, dt=DT):
     """main.py:39-50: the 1000-step alpha-ramp test profile."""
     T = 1000

@@ -26,6 +26,7 @@ them is copied.  What is committed is data: inputs and the reference's outputs.
                 object under the law the PREVIOUS episode left behind (MR_env.py:181-183), sigma = 0 and one taped sigma > 0 run.
   ref_sim_f64.npz  the ref_sim scenarios with the reference's own float64 action tables (not rounded to float32).
   ref_experiment.npz  MR_data.MRExperiment's dictionaries after three recorded MR_Env episodes (8f-3).
+  ref_circle_fm.npz  utils.run_sim on main_2d.py:137-160's frequency-modulated circle learning set (nominal and mismatched).
   ref_increments.npz  sigma > 0 STATISTICS of the reference itself: 20 000 per-step noise increments of Simulator.step at sigma = 1
                 in the DDPG regime (start (110, 115), random actions in the actor range, 200 restarts of 100 steps), nominal and
                 mismatched law: Delta - dt (b1 K0 + (1 - b1) V(action)) normalised to unit variance (/ dt cB sqrt(g^2 + sigma^2)).  The kernels' and the
@@ -417,6 +418,32 @@ def gen_reused():
     print("ref_reused.npz written")
 
 
+def gen_circle_fm():
+    """ref_circle_fm.npz: utils.run_sim on the frequency-modulated circle learning set of main_2d.py:137-160 (three circles of
+    100 steps, alpha = linspace(-pi, pi), f = (cos(t / 5) + 1) / 2 * 4.9 + 0.1 with t = linspace(0, 300, 300)), a0 = 1.5."""
+    _install_standins()
+    import contextlib
+    import io
+    import utils   # noqa: E402 (reference, unmodified)
+    time_steps, cycles = 300, 3
+    steps = int(time_steps / cycles)
+    circle = np.zeros((steps, 2))
+    circle[:, 1] = np.linspace(-np.pi, np.pi, steps)
+    learn = np.vstack([circle] * cycles)
+    t = np.linspace(0, time_steps, time_steps)
+    learn[:, 0] = (np.cos(t / 5) + 1) / 2 * 4.9 + 0.1
+    a3 = np.zeros((time_steps, 3)); a3[:, :2] = f32(learn); a3[:, 2] = np.arange(time_steps) * 0.030
+    flat = {}
+    for name, mis in (("g7_circle_fm", False), ("g7_circle_fm_mis", True)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            X, Y, alpha, time, freq = utils.run_sim(a3, init_pos=np.array([0.0, 0.0]), noise_var=0.0, a0=1.5, is_mismatched=mis)
+        for key, v in dict(actions=a3, actions_f64=learn, init=np.zeros(2), a0=1.5, mismatched=int(mis), X=X, Y=Y, alpha=alpha, time=time,
+                           freq=freq).items():
+            flat[f"{name}/{key}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, "ref_circle_fm.npz"), **flat)
+    print("ref_circle_fm.npz written")
+
+
 def gen_increments():
     """Per-step noise increments of the reference Simulator at sigma = 1, far from the origin (no step splitting)."""
     dt, b1, cB = 0.030, 35.0 / 384, float(np.sqrt((500 / 1113) ** 2 + (125 / 192) ** 2 + (2187 / 6784) ** 2 + (11 / 84) ** 2))
@@ -460,6 +487,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "increments":   # only the statistics fixture (the others are unchanged)
         gen_increments()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "circle_fm":
+        gen_circle_fm()
+        sys.exit(0)
     import scipy
     print(f"numpy {np.__version__}, scipy {scipy.__version__}, reference at {REF}")
     if len(sys.argv) > 1 and sys.argv[1] == "reused":
@@ -472,3 +502,4 @@ if __name__ == "__main__":
     gen_experiment()
     gen_reused()
     gen_increments()
+    gen_circle_fm()

@@ -433,3 +433,65 @@ def test_kernel_increments_match_the_reference_sample(law, math, mis):
     from tests.test_noise_law_cpu import check_against_reference_increments, normalised_increments
     r = normalised_increments(_KernelSteps(8192, law, mis, math, seed=33), 8192, 8, mis)
     check_against_reference_increments(r, mis)
+
+
+# ---------------------------------------------------------------------------
+# batched MRExperiment export (MR_data.py:27-57 for N envs at once)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["auto_reset_goal", "reference_constant", "goal_table"])
+def test_batched_export_equals_record_rollout(mode):
+    """recorder.export_all cuts the episodes of all 4096 envs of one resident rollout with tensor operations; for sampled envs the
+    MRExperiment-layout dictionary equals recorder.record_rollout(env_index=i) key by key, shape by shape, value by value"""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd import recorder
+    n, T = 4096, 120
+    tab = None
+    if mode == "auto_reset_goal":     # episodes of different lengths: goal reached / timeout, same-step auto-reset
+        kw = dict(noise_var=0.5, auto_reset=True, reward_mode="goal", min_dist2goal=100.0, init_low=(60.0, 60.0), init_high=(80.0, 80.0))
+    elif mode == "reference_constant":  # the reference's behaviour: constant reward 10 (integer column), no auto-reset: one episode + tail
+        kw = dict(noise_var=0.5)
+    else:
+        kw = dict(noise_var=0.2, reward_mode="goal", min_dist2goal=1.0)
+        k = np.arange(130)
+        tab = np.stack([np.stack([110 + 0.2 * k, 110 - 0.1 * k], 1), np.stack([105 + 0.0 * k, 112 + 0.3 * k], 1)]).astype(np.float32)
+    mk = lambda: MRVecEnv(n, cfg=MRConfig(**kw), seed=4, goal_table=tab)  # noqa: E731
+    env = mk()
+    env.reset()
+    be = recorder.export_all(env, T)
+    assert be.ep_index.shape == (T, n) and int(be.ep_len.sum()) == T * n
+    if mode == "auto_reset_goal":
+        assert int(be.ep_count.max()) >= 3 and int(be.ep_count.min()) >= 2
+    picks = [0, 1, 777, 2048, 4095]
+    got = be.dicts(picks)
+    for i, d in zip(picks, got):
+        ref_env = mk()
+        ref_env.reset()
+        want = recorder.record_rollout(ref_env, T, env_index=i)
+        assert d["iterations"] == want["iterations"] and set(d) == set(want)
+        for key in ("states", "observations", "actions", "rewards", "steps"):
+            assert set(d[key]) == set(want[key])
+            for it in want[key]:
+                a, b = np.asarray(d[key][it]), np.asarray(want[key][it])
+                assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b), (mode, i, key, it)
+        # the device-side episode table agrees with the dictionaries
+        for it in d["steps"]:
+            assert int(be.ep_len[i, it]) == d["steps"][it]
+            assert abs(float(be.ep_return[i, it]) - float(np.sum(d["rewards"][it]))) < 1e-9
+
+
+def test_run_sim_on_the_frequency_modulated_circle_set():
+    """mr_rl_amd.rollout.run_sim(actions_circle_fm()) == utils.run_sim on main_2d.py:137-160's learning set (golden ref_circle_fm.npz)"""
+    from mr_rl_amd.rollout import actions_circle_fm, run_sim
+    from tests.util import load_cases
+    for name, G in load_cases("ref_circle_fm.npz").items():
+        X, Y, alpha, time, freq = run_sim(G["actions"], init_pos=G["init"], noise_var=0.0, a0=float(G["a0"]), is_mismatched=bool(G["mismatched"]))
+        np.testing.assert_allclose(X, G["X"], rtol=0, atol=POS_TOL)
+        np.testing.assert_allclose(Y, G["Y"], rtol=0, atol=POS_TOL)
+        np.testing.assert_array_equal(time, G["time"])
+        np.testing.assert_array_equal(freq, G["freq"])
+    # the float64 table through the rollout's fp64 action input: the reference driven with its own unrounded table would differ from
+    # the float32-rounded golden by < 1e-5 (test_gpu_parity.py pins that for the main.py tables); here: it runs and stays close
+    X64, Y64, *_ = run_sim(actions_circle_fm(), init_pos=[0.0, 0.0], noise_var=0.0, a0=1.5)
+    G = load_cases("ref_circle_fm.npz")["g7_circle_fm"]
+    assert np.abs(X64 - G["X"]).max() < 1e-4 and np.abs(Y64 - G["Y"]).max() < 1e-4

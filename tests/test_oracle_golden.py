@@ -124,6 +124,27 @@ def test_run_sim_tuple(name):
     np.testing.assert_array_equal(G["freq"], G["actions"][:, 0])
 
 
+CIRCLE_FM = load_cases("ref_circle_fm.npz")
+
+
+@pytest.mark.parametrize("name", sorted(CIRCLE_FM))
+def test_run_sim_on_the_frequency_modulated_circles(name):
+    """main_2d.py:137-160's learning set (three circles, f = (cos(t / 5) + 1) / 2 * 4.9 + 0.1) through utils.run_sim: the oracle
+    reproduces the reference's tuple, and mr_rl_amd.rollout.actions_circle_fm() is the table the reference was driven with"""
+    from mr_rl_amd.rollout import actions_circle_fm
+    G = CIRCLE_FM[name]
+    tab = actions_circle_fm()
+    np.testing.assert_array_equal(tab[:, :2], G["actions_f64"])
+    np.testing.assert_array_equal(tab[:, :2].astype(np.float32), G["actions"][:, :2].astype(np.float32))
+    np.testing.assert_allclose(tab[:, 2], G["actions"][:, 2], rtol=0, atol=1e-15)
+    p = O.default_params(a0=float(G["a0"]), sigma=0.0, mismatched=int(G["mismatched"]))
+    s = O.Sim(p); s.reset(*G["init"])
+    T = len(G["X"])
+    xy = np.array([s.step(G["actions"][k, 0], G["actions"][k, 1]) for k in range(T)])
+    np.testing.assert_allclose(xy[:, 0], G["X"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(xy[:, 1], G["Y"], rtol=0, atol=TOL)
+
+
 REUSED = load_cases("ref_reused.npz")
 
 
