@@ -389,7 +389,7 @@ def test_ddpg_loop_learns_a_one_step_goal_task(fused):
     """Smoke-level learning check of the whole loop on the device env, goal reward, fixed seed (tools/learning_check.py): envs start
     10 .. 14 units beside a goal of radius 10 and every episode is one step; the untrained actor does not move (return -100),
     a constant action "f ~ -7, cos(alpha) ~ 1" reaches the goal.  Collection with the actor in the kernel, replay push, fused /
-    graph-replayed learner, device-side policy upload: the mean return must rise from below -60 to above 0 (the plateau, ~ +25,
+    graph-replayed learner, device-side policy upload: the mean return must rise from below -60 (first episode) to above 0 (the plateau, ~ +25,
     is set by the exploration noise that stays on)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("learning_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
@@ -399,7 +399,8 @@ def test_ddpg_loop_learns_a_one_step_goal_task(fused):
     import torch
     agent, rets = lc.run(fused, 300, 16)
     assert len(rets) == 300 and np.isfinite(rets).all()
-    assert np.mean(rets[:3]) < -60.0 and np.mean(rets[-30:]) > 0.0, (rets[:5], rets[-5:])
+    # episode 0 is collected before any update; the learner moves fast from there (16 updates per one-step episode)
+    assert rets[0] < -60.0 and np.mean(rets[-30:]) > 0.0 and np.mean(rets[-30:]) - rets[0] > 60.0, (rets[:5], rets[-5:])
     with torch.no_grad():
         a = agent.actor(torch.tensor([[12.0, 0.0, 0.0, 0.0, 12.0]], device="cuda") * 0.1)[0]
     assert 1.5 * float(a[0]) * float(torch.cos(a[1])) < -2.0          # the learnt action moves the robot into the goal's radius

@@ -10,14 +10,6 @@ import torch
 from mr_rl_amd import MRConfig, MRVecEnv
 from mr_rl_amd.ddpg import DDPG
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--fused", type=int, default=1)
-ap.add_argument("--episodes", type=int, default=300)
-ap.add_argument("--updates", type=int, default=16)
-ap.add_argument("--envs", type=int, default=4096)
-ap.add_argument("--ou-sigma", type=float, default=10.0)
-a = ap.parse_args()
-
 
 def task_cfg():
     return MRConfig(noise_var=0.1, a0=50.0, reward_mode="goal", auto_reset=True, max_timesteps=0, min_dist2goal=10.0,
@@ -32,6 +24,13 @@ def run(fused, episodes, updates, envs=4096, ou_sigma=10.0, seed=0):
 
 
 if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--episodes", type=int, default=300)
+    ap.add_argument("--updates", type=int, default=16)
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--ou-sigma", type=float, default=10.0)
+    a = ap.parse_args()
     agent, rets = run(a.fused, a.episodes, a.updates, a.envs, a.ou_sigma)
     k = max(1, len(rets) // 10)
     print("mean return per tenth of the run:", [round(sum(rets[i:i + k]) / k, 1) for i in range(0, len(rets), k)])
