@@ -25,6 +25,13 @@
  * counter: pass a fresh step_idx to every mrsim_reset / mrsim_step call (mrsim_rollout consumes
  * step_idx0 .. step_idx0 + T - 1); passing the same (seed, step_idx) again reproduces the same draws.
  * MrsimParams.step_base lets that counter live in device memory for hipGraph replay.
+ *
+ * A reset CONSUMES a step index: the first mrsim_step / mrsim_rollout after mrsim_reset(step_idx = s) must use s + 1 or later.
+ * The draws of an auto-reset (start position, constructor noise) sit at the step index at which the episode that ENDS took its
+ * first step -- a block of its own per episode, known from the episode's start.  An explicit reset at s followed by a step at the
+ * same s would make that step the first of an episode whose auto-reset block is (env, s) again: the same start position and
+ * constructor noise twice in a row.  mr_rl_amd.MRVecEnv advances its counter in reset(); a C caller must do the same
+ * (tests/test_rng.py pins that the blocks of an explicit reset and of the following episodes' auto-resets are distinct).
  */
 #ifndef MRSIM_H
 #define MRSIM_H
@@ -146,6 +153,8 @@ typedef struct MrsimState {
  * within 4e-5 of its bound of the F32 result with the reference's output-layer init, 3e-2 at output gains of 20-40 x. */
 enum { MRSIM_ACTOR_F32 = 0, MRSIM_ACTOR_BF16X3 = 1, MRSIM_ACTOR_BF16 = 2 };
 
+/* Weights and observations must be finite.  (The kernels' ReLU is an integer maximum on the float's bits: for a NaN it returns 0
+ * when the sign bit is set and the NaN otherwise, unlike fmaxf.) */
 typedef struct MrsimActorWeights {   /* HOST pointers, row-major float32: the network in inference form */
     const float* w1;        /* [64][5]   first fully_connected (+ folded batch norm)   RL/MR_ddpg.py:122-123 */
     const float* b1;        /* [64]                                                                          */

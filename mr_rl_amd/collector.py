@@ -47,7 +47,10 @@ class RolloutCollector:
     WANT = ("obs", "rew", "done", "actions")
 
     def __init__(self, num_envs, cfg=None, device="cuda", seed=None, env_id0=0, goal_table=None, streams=2, T=None,
-                 want=WANT, carry="f64", depth=2, returns_interval=1, policy=None):
+                 want=WANT, carry="f64", depth=2, returns_interval=1, policy=None, stream_list=None):
+        """stream_list: caller-owned torch streams for the sub-shards (len = number of sub-shards) instead of the process-wide
+        shared set -- for two collectors that must run side by side (an evaluation collector beside a training one); the default
+        shared set orders every collector of a device on the same streams (collectors are then used one at a time)."""
         import torch
         self.env = MRVecEnv(num_envs, cfg=cfg if cfg is not None else MRConfig(auto_reset=True), device=device, seed=seed,
                             env_id0=env_id0, goal_table=goal_table)
@@ -61,7 +64,12 @@ class RolloutCollector:
         if policy is not None:
             policy.ou_tensor(env.num_envs)   # created (and its zero fill awaited) HERE, before any sub-shard stream can read it
         self.shards = [(a, n) for a, n in all_shards(self.N, self.S) if n > 0]
-        self.streams = _sub_shard_streams(dev, len(self.shards))
+        if stream_list is not None:
+            if len(stream_list) != len(self.shards):
+                raise ValueError("stream_list must hold one stream per sub-shard (%d)" % len(self.shards))
+            self.streams = list(stream_list)
+        else:
+            self.streams = _sub_shard_streams(dev, len(self.shards))
         T_, N = self.T, self.N
         soa = env._soa
         shapes = {"traj": ((T_, N, 2), torch.float64), "state_prime": ((T_, N, 2), torch.float32),

@@ -219,6 +219,8 @@ __device__ __forceinline__ void lds_load16(const float* __restrict__ p, act_f32x
 // max -- 256 of the kernel's 745 vector instructions per wave and step.  An inline-asm v_max_f32 is NOT an option: the hazard
 // recogniser cannot see into asm, does not pad the MFMA-result -> VALU-read wait states, and the read returns the
 // accumulator's old value -- measured: actions off by 5e-4 in one kernel instantiation and right in another.)
+// NaN handling differs from fmaxf(x, 0): a NaN with the sign bit set becomes 0, one without stays NaN (its bits compare above
+// zero).  Finite weights and observations never produce one; include/mrsim.h says so at MrsimActorWeights.
 __device__ __forceinline__ float act_relu(float x) {
     const int b = __float_as_int(x);
     return __int_as_float(b > 0 ? b : 0);

@@ -886,12 +886,15 @@ static int launch_step(const LaunchCfg& lc, const MrsimParams* p, const KParams&
 }
 
 // MrsimActor -> kernel arguments + flag bits.  Returns MRSIM_OK with `on` = false when there is no actor.
-static int actor_args(const MrsimParams* p, const MrsimActor* a, bool have_actions, ActorArgs& AC, uint32_t& bits, bool& on) {
+static int actor_args(const MrsimParams* p, const MrsimActor* a, bool have_actions, ActorArgs& AC, uint32_t& bits, bool& on,
+                      bool drives_integrator = true) {
     AC = ActorArgs{nullptr, nullptr, {0.f, 0.f}};
     bits = 0u; on = false;
     if (a == nullptr || a->blob == nullptr) return MRSIM_OK;
     if (have_actions) return MRSIM_EINVAL;                      // one policy source per launch
-    if (p->integrator != MRSIM_INT_RK45) return MRSIM_EINVAL;   // the actor drives the reference integrator only
+    // inside the step / rollout kernels the actor drives the reference integrator only; as a kernel of its own
+    // (mrsim_actor_forward) it integrates nothing and takes any integrator (its OU words then come from the POLICY stream)
+    if (drives_integrator && p->integrator != MRSIM_INT_RK45) return MRSIM_EINVAL;
     if (!aligned16(a->blob) || (a->ou_state && !aligned8(a->ou_state))) return MRSIM_EALIGN;
     if (!(a->ou_dt >= 0.0f) || std::isnan(a->ou_theta) || std::isnan(a->ou_sigma)) return MRSIM_EINVAL;
     AC.blob = a->blob;
@@ -1316,7 +1319,7 @@ int mrsim_actor_forward(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     ActorArgs AC;
     uint32_t abits = 0u;
     bool on = false;
-    if ((rc = actor_args(p, actor, false, AC, abits, on))) return rc;
+    if ((rc = actor_args(p, actor, false, AC, abits, on, /*drives_integrator=*/false))) return rc;
     const float* aux = nullptr;
     if (abits & kFOUReset) {
         if (st == nullptr || st->aux == nullptr) return MRSIM_EINVAL;

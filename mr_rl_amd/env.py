@@ -15,9 +15,20 @@ class _Sim:
     def __init__(self, env):
         self._e = env
 
-    noise_var = property(lambda s: s._e._v.cfg.noise_var)
-    a0 = property(lambda s: s._e._v.cfg.a0)
-    is_mismatched = property(lambda s: s._e._v.cfg.is_mismatched)
+    # readable AND writable, as the reference's plain attributes are (MR_env.py:179-183 assigns them; callers may too)
+    def _cfg_attr(name, refresh):  # noqa: N805
+        def get(s):
+            return getattr(s._e._v.cfg, name)
+
+        def put(s, value):
+            setattr(s._e._v.cfg, name, type(getattr(s._e._v.cfg, name))(value))
+            if refresh:
+                s._e._v._refresh_params()
+        return property(get, put)
+
+    noise_var = _cfg_attr("noise_var", True)
+    a0 = _cfg_attr("a0", True)
+    is_mismatched = _cfg_attr("is_mismatched", True)
     state_prime = property(lambda s: s._e.state_prime)
 
     def get_state(self):

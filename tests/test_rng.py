@@ -141,3 +141,33 @@ def test_auto_reset_positions_are_uniform_and_uncorrelated():
     assert abs(np.corrcoef(pos[:, 0], pos[:, 1])[0, 1]) < lim(len(pos))            # x and y of one reset
     assert abs(np.corrcoef(neigh[:, 0], neigh[:, 1])[0, 1]) < lim(len(neigh))      # neighbouring envs, same step
     assert abs(np.corrcoef(pos[:, 0], lens)[0, 1]) < lim(len(pos))                 # position vs length of the ended episode
+
+
+def test_reset_blocks_of_consecutive_episodes_are_distinct():
+    """include/mrsim.h: a reset consumes a step index.  An explicit reset at step s draws its start position from block
+    (env, s); the auto-reset that ends an episode draws from the block of the step at which that episode took its FIRST step.  With
+    the rule (first step after a reset at s uses s + 1) every episode has a block of its own; breaking it (reset and first step
+    both at s) makes the auto-reset reuse the explicit reset's block: the same start position twice in a row."""
+    n = 64
+    p = O.default_params(sigma=0.5, auto_reset=1)
+    lo, hi = (-20.0, -2 * np.pi), (20.0, 2 * np.pi)
+
+    def starts(first_step):
+        orc = O.VecOracle(n, p, seed=5)
+        orc.reset(1)                                  # explicit reset at step index 1
+        out = [orc.envs["y"].copy()]
+        k = first_step
+        for ep in range(2):
+            for _ in range(51):
+                orc.step(orc.random_policy(k, lo, hi), step_idx=k)
+                k += 1
+            assert orc.done.all() and (orc.envs["counter"] == 0).all()
+            out.append(orc.envs["y"].copy())          # the auto-reset's start position
+        return out
+    a = starts(first_step=2)                          # the rule
+    for i in range(3):
+        for j in range(i + 1, 3):
+            assert (np.abs(a[i] - a[j]).max(axis=1) > 0).all()
+    b = starts(first_step=1)                          # reset and first step share index 1
+    assert np.array_equal(b[0], b[1])                 # ... and the first auto-reset repeats the explicit reset's draw
+    assert (np.abs(b[1] - b[2]).max(axis=1) > 0).all()
