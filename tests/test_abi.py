@@ -133,3 +133,46 @@ def test_rollout_and_velocity_argument_validation():
     assert L.mrsim_velocity(4, 8, 14, None, d, d, d, None, None) == _lib.EINVAL
     assert L.mrsim_velocity(4, 8, 14, d + 8, d, d, d, None, None) == _lib.EALIGN
     assert L.mrsim_advance_step_base(None, 1, None) == _lib.EINVAL
+
+
+def test_abi4_entry_points_validate_their_arguments_and_have_no_cpu_path():
+    """noise_law, mrsim_ddpg_update, mrsim_replay_push, mrsim_actor_pack_device: bad arguments -> MRSIM_EINVAL / MRSIM_EALIGN,
+    good arguments without a GPU -> MRSIM_ENODEVICE (no CPU fallback anywhere)"""
+    from mr_rl_amd import _lib
+    L = _lib.lib()
+    p = _lib.default_params()
+    assert p.noise_law == _lib.LAW_PER_STAGE           # the library's default is the reference's per-evaluation noise
+    buf = np.zeros(4096, dtype=np.float64)
+    st = _lib.MrsimState(buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)
+    io = _lib.MrsimStepIO(None, None, None, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)
+    p.noise_law = 7
+    assert L.mrsim_step(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.EINVAL
+    p.noise_law = _lib.LAW_COLLAPSED
+    assert L.mrsim_step(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) in (_lib.ENODEVICE, _lib.OK)
+    # learner
+    big = np.zeros(_lib.DDPG_PARAMS + 16, dtype=np.float32)
+    base = big.ctypes.data + (-big.ctypes.data) % 16
+    lr = _lib.MrsimDdpgLearner(base, base, base, base, base, base, base, 1e-5, 0.99, 0.001, 1e-3, 1e-2, 0.9, 0.999, 1e-8,
+                               (C.c_float * 2)(20.0, 6.28))
+    d = buf.ctypes.data
+    call = lambda batch, n_upd=1, learner=lr, s=d: L.mrsim_ddpg_update(C.byref(learner) if learner else None, batch, n_upd, s, d, d, d,  # noqa: E731
+                                                                      d, None, 0, 0, 0, None, None, None)
+    assert call(64, learner=None) == _lib.EINVAL
+    assert call(63) == _lib.EINVAL and call(32) == _lib.EINVAL and call(_lib.DDPG_MAX_BATCH + 64) == _lib.EINVAL
+    assert call(64, n_upd=0) == _lib.EINVAL and call(64, s=None) == _lib.EINVAL
+    lr2 = _lib.MrsimDdpgLearner(base + 4, base, base, base, base, base, base, 1e-5, 0.99, 0.001, 1e-3, 1e-2, 0.9, 0.999, 1e-8,
+                                (C.c_float * 2)(20.0, 6.28))
+    assert call(64, learner=lr2) == _lib.EALIGN
+    assert call(64) in (_lib.ENODEVICE, _lib.OK)
+    # replay push
+    sc = (C.c_float * 5)(1, 1, 1, 1, 1)
+    push = lambda n, cap, head: L.mrsim_replay_push(16, 4, d, d, d, d, d, sc, n, d, d, d, d, d, cap, head, 0, 0, None)  # noqa: E731
+    assert push(8, 0, 0) == _lib.EINVAL and push(8, 4, 0) == _lib.EINVAL and push(2, 4, 4) == _lib.EINVAL and push(-1, 4, 0) == _lib.EINVAL
+    assert push(0, 4, 0) == _lib.OK                     # nothing to do: no device needed
+    assert push(2, 4, 0) in (_lib.ENODEVICE, _lib.OK)
+    # device-side pack
+    bd = (C.c_float * 2)(20.0, 6.28)
+    assert L.mrsim_actor_pack_device(None, d, 1e-5, sc, bd, base, None) == _lib.EINVAL
+    assert L.mrsim_actor_pack_device(d, d, 0.0, sc, bd, base, None) == _lib.EINVAL
+    assert L.mrsim_actor_pack_device(d, d, 1e-5, sc, bd, base + 4, None) == _lib.EALIGN
+    assert L.mrsim_actor_pack_device(d, d, 1e-5, sc, bd, base, None) in (_lib.ENODEVICE, _lib.OK)
