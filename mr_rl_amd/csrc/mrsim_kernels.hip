@@ -1351,6 +1351,7 @@ int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, int32_t n_updat
         r == nullptr || done == nullptr || s2 == nullptr)
         return MRSIM_EINVAL;
     if (batch < learner::kTile || batch > learner::kMaxBatch || batch % learner::kTile != 0) return MRSIM_EINVAL;
+    if (ring_count < 0 || n_updates < 1 || n_updates > 65536) return MRSIM_EINVAL;
     if (!aligned16(Lr->online) || !aligned16(Lr->target)) return MRSIM_EALIGN;
     if (!(Lr->bn_eps > 0.0f) || !(Lr->beta1 >= 0.0f && Lr->beta1 < 1.0f) || !(Lr->beta2 >= 0.0f && Lr->beta2 < 1.0f)) return MRSIM_EINVAL;
     int rc = check_device();
@@ -1362,7 +1363,6 @@ int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, int32_t n_updat
             return MRSIM_ELAUNCH;
         attr_set = true;
     }
-    if (ring_count < 0 || n_updates < 1 || n_updates > 65536) return MRSIM_EINVAL;
     learner::Args A{Lr->online, Lr->target, Lr->adam_m, Lr->adam_v, Lr->grad_scratch, Lr->steps, Lr->bn_stats, s, a, r, done, s2, idx,
                     idx_out, ring_count, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)draw_counter, (uint32_t)(draw_counter >> 32),
                     losses_out, batch, n_updates, Lr->bn_eps, Lr->gamma, Lr->tau, Lr->actor_lr, Lr->critic_lr, Lr->beta1, Lr->beta2, Lr->adam_eps,
