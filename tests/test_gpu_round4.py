@@ -496,3 +496,79 @@ def test_run_sim_on_the_frequency_modulated_circle_set():
     X64, Y64, *_ = run_sim(actions_circle_fm(), init_pos=[0.0, 0.0], noise_var=0.0, a0=1.5)
     G = load_cases("ref_circle_fm.npz")["g7_circle_fm"]
     assert np.abs(X64 - G["X"]).max() < 1e-4 and np.abs(Y64 - G["Y"]).max() < 1e-4
+
+
+# ---------------------------------------------------------------------------
+# collapsed law: every flag-specialised instantiation gives the generic kernels' bits
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mis", [False, True])
+@pytest.mark.parametrize("mixed", [False, True, "soa"])
+def test_collapsed_flag_specialised_rollout_kernels_equal_the_step_path(mixed, mis):
+    """mr_rollout_kernel<RK45, fast + collapsed, ., FL> (DDPG pattern, goal-table pattern with the reset cache, [5][N] rows) against
+    the generic step kernel, bitwise: observations (through the LDS row strip for [N][5], ragged last wave included), rewards,
+    done flags, actions, final state"""
+    n, T = 2500, 60
+    kw = dict(seed=21, noise_var=1.0, auto_reset=True, is_mismatched=mis, noise_law="collapsed")
+    tab = None
+    if mixed == "soa":
+        kw.update(obs_layout="soa")
+    elif mixed:
+        tab = np.random.default_rng(4).uniform(100, 120, (3, 52, 2)).astype(np.float32)
+        kw.update(reward_mode="goal", min_dist2goal=1.0)
+    torch, e1, _ = _mk(n, goal_table=tab, **kw)
+    torch, e2, _ = _mk(n, goal_table=tab, **kw)
+    e1.reset(); e2.reset()
+    out = e1.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
+    for t in range(T):
+        obs, rew, done, info = e2.step(None)
+        np.testing.assert_array_equal(out["obs"][t].cpu().numpy().view(np.uint32), obs.cpu().numpy().view(np.uint32))
+        np.testing.assert_array_equal(out["rew"][t].cpu().numpy(), rew.cpu().numpy())
+        np.testing.assert_array_equal(out["done"][t].cpu().numpy(), done.cpu().numpy())
+        np.testing.assert_array_equal(out["actions"][t].cpu().numpy(), e2.last_action.cpu().numpy())
+    np.testing.assert_array_equal(e1.pos.cpu().numpy().view(np.uint64), e2.pos.cpu().numpy().view(np.uint64))
+    np.testing.assert_array_equal(e1.aux.cpu().numpy().view(np.uint32), e2.aux.cpu().numpy().view(np.uint32))
+    np.testing.assert_array_equal(e1.final_len.cpu().numpy(), e2.final_len.cpu().numpy())
+    e1.check_status()
+
+
+@pytest.mark.parametrize("mis", [False, True])
+def test_collapsed_flag_specialised_step_kernel_equals_the_generic_one(mis):
+    """the gym loop's launch pattern selects mr_step_kernel<RK45, fast + collapsed, ., FL>; a tracking env takes the generic one"""
+    from mr_rl_amd import MRConfig, MRVecEnv
+    n, T = 3000, 60
+    mk = lambda **kw: MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True, is_mismatched=mis, noise_law="collapsed"), seed=33, **kw)  # noqa: E731
+    e1, e2 = mk(), mk(track_state_prime=True, track_actions=True)
+    e1.reset(); e2.reset()
+    for t in range(T):
+        a = e1.random_policy()
+        o1, r1, d1, i1 = e1.step(a)
+        o2, r2, d2, i2 = e2.step(a.clone())
+        np.testing.assert_array_equal(o1.cpu().numpy().view(np.uint32), o2.cpu().numpy().view(np.uint32))
+        np.testing.assert_array_equal(d1.cpu().numpy(), d2.cpu().numpy())
+    np.testing.assert_array_equal(e1.pos.cpu().numpy().view(np.uint64), e2.pos.cpu().numpy().view(np.uint64))
+    np.testing.assert_array_equal(e1.aux.cpu().numpy().view(np.uint32), e2.aux.cpu().numpy().view(np.uint32))
+    assert (e1.final_len == 51).all()
+    e1.check_status()
+
+
+def test_rollout_obs_rows_through_the_lds_strip_for_ragged_and_misaligned_launches():
+    """[N][5] observation rows of the fused rollout: full waves take the LDS strip (whole-line stores), the ragged last wave and
+    sub-shards whose first row is not 16-byte aligned take per-lane stores -- same values either way, nothing outside the rows"""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    for law in ("per_stage", "collapsed"):
+        cfg = MRConfig(noise_var=1.0, auto_reset=True, noise_law=law)
+        n, T = 1000, 7
+        ref = MRVecEnv(n, cfg=cfg, seed=9); ref.reset()
+        want = ref.rollout(T, want=("obs",))["obs"].clone()
+        # the same envs as three sub-shard launches into one canary-filled buffer: [0, 257) (ragged), [257, 258) (one env, row
+        # not 16-byte aligned), [258, 1000) (starts misaligned)
+        env = MRVecEnv(n, cfg=cfg, seed=9); env.reset()
+        buf = torch.full((T + 2, n, 5), -777.0, device="cuda")
+        obs_T = buf[1:T + 1]
+        for first, cnt in ((0, 257), (257, 1), (258, 742)):
+            env.launch_rollout(T, first, cnt, obs_T=obs_T)
+        env.step_idx += T
+        torch.cuda.synchronize()
+        assert torch.equal(obs_T, want), law
+        assert float(buf[0].max()) == -777.0 and float(buf[T + 1].max()) == -777.0
