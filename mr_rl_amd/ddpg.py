@@ -200,6 +200,12 @@ def soft_update(target, online, tau, copy_buffers=True):
             bt.copy_(bo)
 
 
+def _mean_returns(ret_rows, len_rows):
+    """[E] mean return of the episodes that ended in each launch group, from the [E, N] final_ret / final_len rows"""
+    ended = (len_rows > 0).float()
+    return (ret_rows * ended).sum(1) / ended.sum(1).clamp(min=1.0)
+
+
 class DDPG:
     """The training loop of RL/MR_ddpg.py:251-323 for N envs in lockstep."""
 
@@ -414,7 +420,10 @@ class DDPG:
         T, N = col.T, col.N
         gen = torch.Generator(device=env.device)
         gen.manual_seed(12345)
-        returns = []
+        RB = 32                                   # episodes per block of stashed returns (reduced block by block: bounded memory)
+        ret_rows = torch.zeros((RB, N), dtype=torch.float32, device=env.device)
+        len_rows = torch.zeros((RB, N), dtype=torch.int32, device=env.device)
+        means = []
         cur = torch.cuda.current_stream(env.device)
         native_push = env.device.type == "cuda" and not col.env._soa      # mrsim_replay_push reads [N][5] observation rows
         # Two episodes in flight, two parameter blocks: episode k reads block k % 2.  When episode k is ready its block is free:
@@ -449,8 +458,10 @@ class DDPG:
                 # s2 of a terminal transition is the next episode's reset observation here; its target is r alone (1 - done = 0)
                 self.buffer.add(self._prep(s), b["actions"][ti, ei], b["rew"][ti, ei], b["done"][ti, ei].float(),
                                 self._prep(obs_T[ti, ei]))
-            ended = (b["final_len"] > 0).float()
-            returns.append((b["final_ret"] * ended).sum() / ended.sum().clamp(min=1.0))
+            ret_rows[k % RB].copy_(b["final_ret"], non_blocking=True)   # reduced to mean returns once per RB episodes (two copies per
+            len_rows[k % RB].copy_(b["final_len"], non_blocking=True)   # episode instead of six small kernels)
+            if k % RB == RB - 1 or k == episodes - 1:
+                means.append(_mean_returns(ret_rows[:k % RB + 1], len_rows[:k % RB + 1]))
             prev_obs = obs_T[T - 1].clone()
             col.release(k)
             if updates_per_episode > 0:
@@ -460,7 +471,7 @@ class DDPG:
                     for _ in range(updates_per_episode):
                         self.update()
             if on_episode is not None:
-                on_episode(k, returns[-1])
+                on_episode(k, _mean_returns(ret_rows[k % RB:k % RB + 1], len_rows[k % RB:k % RB + 1])[0])
         col.join()
         if stats is not None and t_start is not None:
             torch.cuda.synchronize(env.device)
@@ -469,7 +480,7 @@ class DDPG:
         col.check_status()
         self.sync_policy(pol)
         self.collector, self.device_actor = col, pol
-        return [float(x) for x in torch.stack(returns).cpu()] if returns else []
+        return [float(x) for x in torch.cat(means).cpu()] if means else []
 
     def train(self, total_steps, updates_per_step=1, log_every=0, warmup_quirk=False, observe=None):
         """Runs `total_steps` lockstep env steps (N transitions each); returns per-episode returns seen.
