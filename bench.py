@@ -21,13 +21,22 @@ a contiguous shard of N x 262144 envs (weak scaling), there is no data-path coll
 episode are all-gathered over RCCL inside the timed region, --gather-interval (8) episodes per collective.
 
 Prints ONE JSON line on rank 0.  Besides the contract's fields:
-  roofline      the dominant kernel against the resource that binds it.  Rollout mode: bound = "valu" (vector-issue
-                floor of the kernel's measured instruction mix, profiles/rNN/pmc_valu.json) with the HBM fraction of
-                the bytes it really moves (`hbm_frac`, traffic from profiles/rNN/pmc_traffic.json) beside it; SURVEY
-                8(d)'s algorithmic 97 B/env-step figure is kept as the labelled `algorithmic_equiv`, never as `frac`.
+  roofline      the dominant kernel (the fused rollout) against HBM: `achieved` = the bytes one launch really moves (`traffic`: the
+                committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS build of libmrsim.so -- refused when the library
+                hash differs -- else the minimal-traffic model, labelled) / the kernel's average launch duration, from HIP events
+                attached to the dispatches of a one-stream region of this very run; `peak` 8000 GB/s.  SURVEY 8(d)'s algorithmic
+                97 B/env-step (state round-trips HBM every step) is what the one-launch-per-step form moves, not the fused
+                kernel: kept as the labelled `algorithmic_equiv`, never as `frac`.  `valu`: the kernel's vector-issue floor from
+                the committed SQ counters.
+  config.noise_law / other_noise_law   the headline runs --noise-law collapsed (same distribution as the reference's per-evaluation
+                noise, element-wise parity against the oracle's restatement of the same law); the per-stage law
+                (the library's default) is measured beside it in the same run, with its own roofline object.
   sustained     the same workload over its own >= 10 200-step region, whatever --steps was (a 20-step timed region is
                 ONE launch and is launch-latency-bound); kernel durations come from HIP events attached to that
                 region's dispatches.
+  actor_in_loop the collection loop with the reference's DDPG actor + OU noise evaluated inside the rollout kernel (MFMA roofline).
+  learner       the DDPG update: updates/s eager / one hipGraph / libmrsim's fused kernel, and env-steps/s of the whole
+                collect-and-learn loop at a stated update : transition ratio.
   cpu_baseline  the oracle (C restatement) on this box's host cores.
 """
 import argparse
