@@ -69,6 +69,9 @@ struct KParams {
     double zmax2_dt;       // 2 * Zmax / dt
     double zmax_e6_sigma;  // Zmax * E6 * sigma: worst-case contribution of K6 to the error estimate
     float h1_thresh2_f, dt2_f;
+    // level -1 test of the fused rollout's fast step (rk45_fast_step, Lm1): fp32 copies with their safety margins folded in
+    float lm_a0, lm_sigma, lm_da, lm_dk, lm_dc, lm_es, lm_ed, lm_rt, lm_at, lm_kh, lm_mg;
+    double lm_ccap;
     int32_t substeps, reward_mode, max_timesteps, auto_reset, goal_K, goal_T;
     int32_t integrator;
     uint32_t flags;  // kF* bits: every wave-uniform yes/no of the launch in ONE scalar register
@@ -529,9 +532,10 @@ __device__ __forceinline__ bool construct_level0(const KParams& P, double x, dou
 // (f0a, f0b) and, under the mismatched law, a third normal f0k already evaluated with its pair partner
 //   per-stage law: pair = (F0a, F0x), f0k = F0y        collapsed law: pair = (F0x, F0y), f0k = F0a
 template <int NZ, bool MIS>
-__device__ __forceinline__ void f0_normals(uint32_t f0a, uint32_t f0b, float f0k, float& za, float& zx, float& zy) {
+__device__ __forceinline__ void f0_normals(uint32_t f0a, uint32_t f0b, float f0k, float& za, float& zx, float& zy,
+                                           float* radius = nullptr) {
     float p, q;
-    box_muller<NZ>(f0a, f0b, p, q);
+    box_muller<NZ>(f0a, f0b, p, q, radius);
     if constexpr (!MIS) { za = 0.f; zx = p; zy = q; }
     else if constexpr (nz_coll(NZ)) { za = f0k; zx = p; zy = q; }
     else { za = p; zx = q; zy = f0k; }
@@ -1105,9 +1109,22 @@ struct EnvRegs {
 // whenever the fast step would have (tested: MRSIM_FAST_STEP = 0 builds, tools/ab_rollout.py reports max |pos| difference 0).
 // Needs nothing of F1 (Simulator.state_prime): callers that want it use the general path.
 // ---------------------------------------------------------------------------
+#ifndef MRSIM_LM1   // A/B switch: 0 = no level -1 test, the fast step always evaluates the fp64 first-level tests
+#define MRSIM_LM1 1
+#endif
+// What a fused rollout carries in fp32 beside the env state so that the fast step can certify its two first-level tests
+// (accept_level0, construct_level0: ~25 fp64-rate instructions) from BOUNDS instead: |x|, |y| as the last observation holds them,
+// an upper bound kb of max|K0|, and |f| of this step's action.
+struct Lm1 {
+    float m, M, kb, fa;   // min / max of (|x|, |y|), the bound of max|K0|, |f|
+};
+__device__ __forceinline__ float lm1_bound(double f0x, double f0y) {
+    return fmaxf(__builtin_fabsf((float)f0x), __builtin_fabsf((float)f0y)) * 1.000001f;
+}
+
 template <int NZ, bool MIS>
 __device__ __forceinline__ bool rk45_fast_step(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, const uint32_t* d0,
-                                               EnvRegs& e) {
+                                               EnvRegs& e, Lm1* lm, int& fail) {
     static_assert(NZ != kNoNoise, "the sigma = 0 kernels have nothing to hide: general path");
     AttemptNoise A = attempt_noise<NZ, MIS, true>(P, C, R, 0u, d0);
     const double h = P.dt;
@@ -1118,6 +1135,48 @@ __device__ __forceinline__ bool rk45_fast_step(const KParams& P, const RhsCtx<MI
     if constexpr (MIS) { sx = __builtin_fma(C.gx, (double)A.ba32, sx); sy = __builtin_fma(C.gy, (double)A.ba32, sy); }
     const double xn = __builtin_fma(h, sx, e.x);
     const double yn = __builtin_fma(h, sy, e.y);
+    // RungeKutta.__init__ of the next step: f0 = simulate() with the F0 draws of this attempt's block
+    float za, zx, zy, rF0 = 0.f;
+    f0_normals<NZ, MIS>(A.f0a, A.f0b, A.f0y, za, zx, zy, &rF0);
+    double f0x, f0y;
+    rhs_value<MIS>(P, C, za, zx, zy, f0x, f0y);
+    // ---- level -1 (nominal law, fused rollout): the first-level tests below hold for EVERY admissible value of the quantities
+    // they read when these fp32 inequalities hold (each bound errs to the safe side; margins 1e-5 .. 1e-3 against fp32 rounding):
+    //   dmax = max|K0 - V| <= Dhi = kb + |a0 f|;   F = max|f0| <= Fhi = |a0 f| + sigma r_F0;   |step| <= dlt = dt (|V| + B0 Dhi + 10.6 sigma)
+    //   (sum |B_i| r_i <= 1.5536 Zmax and cB r_1 <= 0.8642 Zmax are both below 10.6);  m = min(|x|, |y|) -> mn = m - dlt after the step
+    //   accept_level0:     dt (sigma R32 + |E0| Dhi) <= 0.99 (atol + rtol m)
+    //   construct_level0:  mn >= k_h0 Fhi;  h1_thresh_m (atol + rtol mn) >= max(Fhi, Gd);  max|f0| >= 2e-5 (atol + rtol 16385) with max(|x|, |y|) + dlt <= 16384
+    // The host folds the constants and their margins (make_kparams: lm_*): dlt = lm_da |f| + lm_dk kb + lm_dc; the two construct
+    // conditions on mn become mn >= max(lm_kh Fhi, lm_mg) with lm_kh = max(k_h0, 1 / (h1_thresh_m rtol)), lm_mg = (Gd / h1_thresh_m - atol) / rtol.
+    // When every lane of the wave passes, the wave skips the fp64 tests (same outcome: commit); otherwise all lanes evaluate them.
+    float Fhi = 0.f;
+    if constexpr (!MIS && MRSIM_LM1 != 0) {
+        if (lm != nullptr) {
+            const float Vhi = P.lm_a0 * lm->fa;
+            const float Dhi = lm->kb + Vhi;
+            Fhi = __builtin_fmaf(P.lm_sigma, rF0, Vhi);
+            const float dlt = __builtin_fmaf(P.lm_da, lm->fa, __builtin_fmaf(P.lm_dk, lm->kb, P.lm_dc));
+            const float mn = __builtin_fmaf(lm->m, 0.99999f, -dlt);
+            const bool cb = __builtin_fmaf(P.lm_es, A.R32, P.lm_ed * Dhi) <= __builtin_fmaf(P.lm_rt, lm->m, P.lm_at);
+            const bool c12 = mn >= fmaxf(P.lm_kh * Fhi, P.lm_mg);
+            const bool c3 = (__builtin_fmaf(lm->M, 1.00001f, dlt) <= 16384.0f) & ((__builtin_fabs(f0x) >= P.lm_ccap) | (__builtin_fabs(f0y) >= P.lm_ccap));
+            const bool lm1 = cb & c12 & c3 & (e.h_abs >= P.dt);
+#ifdef MRSIM_VERIFY_LM1   // verification build (tests): the bounds must never certify a step the fp64 tests would refuse
+            {
+                const double l0v = __builtin_fma(__builtin_fabs(e.x), P.rtol, P.atol), l1v = __builtin_fma(__builtin_fabs(e.y), P.rtol, P.atol);
+                const double s0v = __builtin_fma(__builtin_fabs(xn), P.rtol, P.atol), s1v = __builtin_fma(__builtin_fabs(yn), P.rtol, P.atol);
+                const bool full = (e.h_abs >= P.dt) && accept_level0(P, A, dfx, dfy, h, l0v, l1v) &&
+                                  construct_level0<MIS>(P, xn, yn, s0v, s1v, f0x, f0y, construct_gd_bound<MIS>(P, C));
+                if (lm1 && !full) fail |= 2;
+            }
+#endif
+            if (__all(lm1)) {
+                e.x = xn; e.y = yn; e.f0x = f0x; e.f0y = f0y; e.h_abs = P.dt;
+                lm->kb = Fhi;
+                return true;
+            }
+        }
+    }
     const double l0 = __builtin_fma(__builtin_fabs(e.x), P.rtol, P.atol);
     const double l1 = __builtin_fma(__builtin_fabs(e.y), P.rtol, P.atol);
     bool acc;
@@ -1126,17 +1185,13 @@ __device__ __forceinline__ bool rk45_fast_step(const KParams& P, const RhsCtx<MI
     } else {
         acc = accept_level1<MIS>(P, C, A, dfx, dfy, h, l0, l1);  // the mismatched attempt forms its E sums eagerly
     }
-    // RungeKutta.__init__ of the next step: f0 = simulate() with the F0 draws of this attempt's block
-    float za, zx, zy;
-    f0_normals<NZ, MIS>(A.f0a, A.f0b, A.f0y, za, zx, zy);
-    double f0x, f0y;
-    rhs_value<MIS>(P, C, za, zx, zy, f0x, f0y);
     const double sc0 = __builtin_fma(__builtin_fabs(xn), P.rtol, P.atol);
     const double sc1 = __builtin_fma(__builtin_fabs(yn), P.rtol, P.atol);
     const bool pass = construct_level0<MIS>(P, xn, yn, sc0, sc1, f0x, f0y, construct_gd_bound<MIS>(P, C));
     const bool ok = (e.h_abs >= P.dt) && acc && pass;
     if (ok) {
         e.x = xn; e.y = yn; e.f0x = f0x; e.f0y = f0y; e.h_abs = P.dt;
+        if constexpr (!MIS && MRSIM_LM1 != 0) { if (lm != nullptr) lm->kb = Fhi; }
     }
     return ok;
 }
@@ -1378,7 +1433,7 @@ template <bool RK45, int NZ, bool MIS, bool DEFER = false>
 __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const float* __restrict__ goal_table,
                                          EnvRegs& e, double act_f, double act_a, const StepWords<RK45, NZ, MIS>& W,
                                          uint32_t fl, StepOut& o, int& fail, const double2* __restrict__ sincos_lds = nullptr,
-                                         const float2* goal_pre = nullptr, const float2* goal0_pre = nullptr) {
+                                         const float2* goal_pre = nullptr, const float2* goal0_pre = nullptr, Lm1* lm = nullptr) {
     e.counter += 1;  // :80
     // the goal of this step only depends on the counter: the one-launch-per-step kernel fetches it now, so that the table
     // read (an L1/L2 hit, but hundreds of cycles) completes behind the integrator instead of stalling the termination
@@ -1390,7 +1445,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         bool fast = false;
         // (noise_math = spec is the test-oriented bit-exact mode: its long Box-Muller would only be duplicated)
         if constexpr (nz_fast(NZ) && MRSIM_FAST_STEP != 0) {
-            if (!(fl & kFOutStatePrime)) fast = rk45_fast_step<NZ, MIS>(P, C, R, &W.w[0][0], e);
+            if (!(fl & kFOutStatePrime)) fast = rk45_fast_step<NZ, MIS>(P, C, R, &W.w[0][0], e, lm, fail);
         }
 #ifdef MRSIM_BUDGET_BUILD  // tools/isa_budget.py only: drop the general path so that the time loop is the common path alone
         if (!fast) __builtin_trap();
@@ -1399,6 +1454,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
             SubStep LS = rk45_integrate<NZ, MIS>(P, C, R, e.x, e.y, e.f0x, e.f0y, e.h_abs, fail, &W.w[0][0]);  // MR_simulator.py:42-45
             rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy,           // :46-50
                                     (fl & kFOutStatePrime) != 0, NZ != kNoNoise ? &LS : nullptr);
+            if (lm != nullptr) lm->kb = lm1_bound(e.f0x, e.f0y);
         }
     } else {
         fixed_integrate<NZ, MIS>(P, C, R, e.x, e.y, spx, spy);
@@ -1445,6 +1501,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
         if constexpr (DEFER) return;
         double rx, ry;
         auto_reset_env<RK45, NZ, MIS>(P, R, fl, e.counter, e, rx, ry);
+        if (lm != nullptr) lm->kb = lm1_bound(e.f0x, e.f0y);
         if constexpr (RK45) { o.spx = (float)rx; o.spy = (float)ry; }  // state_prime = last RHS value
         if (goal0_pre != nullptr) { gx = (double)goal0_pre->x; gy = (double)goal0_pre->y; }  // row 0: loaded once per launch
         else goal_at(P, fl, goal_table, R.env, 0, gx, gy);

@@ -342,6 +342,10 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     // stores count in vmcnt): each wave stalled for a store round trip per step (SQ_WAIT_ANY 16 % of wave time).
     asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.f0x), "+v"(e.f0y), "+v"(e.h_abs), "+v"(e.counter), "+v"(e.ep_ret));
     int fail = 0;
+    // fp32 side data of the fast step's level -1 test (mrsim_device.h: Lm1)
+    Lm1 lm;
+    lm.m = fminf(__builtin_fabsf((float)e.x), __builtin_fabsf((float)e.y)); lm.M = fmaxf(__builtin_fabsf((float)e.x), __builtin_fabsf((float)e.y));
+    lm.kb = lm1_bound(e.f0x, e.f0y); lm.fa = 0.f;
     const unsigned slot = hw_wave_slot();
     float* obs_lane = ra.obs_T != nullptr ? ra.obs_T + (blk0 + tid) * 5 : nullptr;  // row t = 0 of this lane's [N][5] record
     // [N][5] observation rows leave a FULL wave as 16-byte stores of whole 128-byte lines: the wave's 64 rows (1280 contiguous
@@ -441,7 +445,8 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         }
         if (!(fl & kFActions64)) { adf = (double)af; ada = (double)aa; }
         StepOut o;
-        env_step<RK45, NZ, MIS, CACHE>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr);
+        lm.fa = __builtin_fabsf(af);
+        env_step<RK45, NZ, MIS, CACHE>(P, R, ra.goal_table, e, adf, ada, W, fl, o, fail, sincos_lds, &goal_next, kGoal0 ? &goal0 : nullptr, HAS_ACT ? nullptr : &lm);   // (the actor kernels have no registers to spare for it)
         if constexpr (CACHE) {
             const unsigned long long ended = __ballot(o.has_final);
             if (ended != 0ull) {                                   // wave-uniform
@@ -463,10 +468,13 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
                     e.x = r.x; e.y = r.y; e.f0x = r.f0x; e.f0y = r.f0y; e.h_abs = r.h_abs;
                     e.counter = 0; e.ep_ret = 0.f;
                     o.obs[0] = (float)r.x; o.obs[1] = (float)r.y; o.obs[2] = goal0.x; o.obs[3] = goal0.y; o.obs[4] = r.d;
+                    lm.kb = lm1_bound(r.f0x, r.f0y);
                 }
                 have_slot &= ~ended;                               // their next episode starts now: no slot for it yet
             }
         }
+        lm.m = fminf(__builtin_fabsf(o.obs[0]), __builtin_fabsf(o.obs[1]));      // the position the next step starts from, as float32
+        lm.M = fmaxf(__builtin_fabsf(o.obs[0]), __builtin_fabsf(o.obs[1]));
         if constexpr (HAS_ACT) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) obs_cur[j] = o.obs[j];  // what the policy sees next (the reset row after an auto-reset)
@@ -771,6 +779,22 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
     }
     K.zmax_e6_sigma = kZmaxE6 * p->sigma;
     K.h1_thresh2_f = (float)(K.h1_thresh * K.h1_thresh);
+    // level -1 test of the fused rollout's fast step (mrsim_device.h: rk45_fast_step), constants folded with their margins:
+    // upper bounds inflated, lower bounds deflated, far above fp32 rounding of the few operations that use them
+    {
+        const double dtu = p->time_span * 1.0001, sgu = p->sigma * 1.00002, a0u = std::fabs(p->a0) * 1.00002;
+        K.lm_a0 = (float)a0u; K.lm_sigma = (float)sgu;
+        // dlt = dt (|V| + B0 (kb + |V|) + 10.6 sigma),  |V| <= a0u |f|
+        K.lm_da = (float)(dtu * a0u * (1.0 + 0.0912) * 1.00001); K.lm_dk = (float)(dtu * 0.0912); K.lm_dc = (float)(dtu * 10.6 * sgu);
+        // accept: dt sigma R32 + dt |E0| Dhi <= 0.99 (atol + rtol m),  m >= 0.9999 (float)m
+        K.lm_es = (float)(dtu * sgu); K.lm_ed = (float)(dtu * 1.2340e-3);
+        K.lm_rt = (float)(0.9895 * 0.9999 * p->rtol); K.lm_at = (float)(0.9895 * 0.9999 * p->atol);
+        // construct: mn >= k_h0 Fhi and h1_thresh_m (atol + rtol mn) >= max(Fhi, Gd)
+        const double q = 1.0 / (K.h1_thresh_m * 0.998 * p->rtol * 0.9999);
+        K.lm_kh = (float)(std::fmax(K.k_h0, q) * 1.001);
+        K.lm_mg = (float)(K.gmax_dt * 1.001 * q * 1.001);    // dropping - atol / rtol only raises the demand on mn
+    }
+    K.lm_ccap = 2e-5 * (p->atol + p->rtol * 16385.0) * 1.001;
     K.dt2_f = (float)(p->time_span * p->time_span);
     K.substeps = p->substeps; K.reward_mode = p->reward_mode; K.max_timesteps = p->max_timesteps;
     K.auto_reset = p->auto_reset; K.goal_K = p->goal_K; K.goal_T = p->goal_T; K.integrator = p->integrator;

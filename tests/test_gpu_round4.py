@@ -6,6 +6,7 @@ Tolerances as in test_gpu_parity.py: positions 1e-6 (noise_math="spec": normals 
 ("fast"); observations within 2 ulp_f32; reward / done / counter exact.
 """
 import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import numpy as np
 import pytest
@@ -572,3 +573,52 @@ def test_rollout_obs_rows_through_the_lds_strip_for_ragged_and_misaligned_launch
         torch.cuda.synchronize()
         assert torch.equal(obs_T, want), law
         assert float(buf[0].max()) == -777.0 and float(buf[T + 1].max()) == -777.0
+
+
+# ---------------------------------------------------------------------------
+# the fast step's level -1 test (rk45_fast_step: fp32 bounds that certify the two fp64 first-level tests)
+# ---------------------------------------------------------------------------
+_LM_CASES = {
+    "ddpg":        dict(),
+    "sigma3":      dict(noise_var=3.0),
+    "small_noise": dict(noise_var=0.05, a0=3.0),
+    "near_origin": dict(init_low=(-2.0, -2.0), init_high=(2.0, 2.0)),          # |x| ~ the tolerance scale: level 0 / the general path
+    "one_axis":    dict(init_low=(-0.05, 100.0), init_high=(0.05, 120.0)),     # min(|x|, |y|) tiny, max large
+    "far":         dict(init_low=(4000.0, -4900.0), init_high=(4900.0, -4000.0), obs_high=(20000.0,) * 4 + (80000.0,),
+                        obs_low=(-20000.0,) * 4 + (0.0,)),
+    "tight_tol":   dict(number_iterations=3000, atol=1e-6),
+    "slow":        dict(a0=0.01, noise_var=0.2),
+}
+
+
+@pytest.mark.parametrize("law", ["per_stage", "collapsed"])
+@pytest.mark.parametrize("case", sorted(_LM_CASES))
+def test_fast_step_bounds_never_certify_a_step_the_fp64_tests_refuse(case, law):
+    """libmrsim_lmverify.so (-DMRSIM_VERIFY_LM1: evaluates the fp64 first-level tests beside the fp32 bounds and raises status bit 1
+    when the bounds pass and they do not) over start regions and parameters chosen to sit on both sides of every bound; the
+    rollout (which uses the bounds) must also give the bits of the step kernel (which has no level -1 test)"""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv, _lib
+    path = os.path.join(ROOT, "mr_rl_amd", "variants", "libmrsim_lmverify.so")
+    assert os.path.exists(path), "make -C mr_rl_amd/csrc lmverify (or __graft_entry__.build())"
+    n, T = 16384, 51
+    cfg = MRConfig(auto_reset=True, noise_law=law, **{"noise_var": 1.0, **_LM_CASES[case]})
+    for carry in ("f32", "f64"):
+        ev = MRVecEnv(n, cfg=cfg, seed=77); ev._L = _lib.load(path); ev.reset()
+        e1 = MRVecEnv(n, cfg=cfg, seed=77); e1.reset()
+        for rep in range(3):
+            ov = ev.rollout(T, want=("obs", "done"), carry=carry)
+            o1 = e1.rollout(T, want=("obs", "done"), carry=carry)
+            assert torch.equal(ov["obs"].view(torch.int32), o1["obs"].view(torch.int32))
+            assert torch.equal(ov["done"], o1["done"])
+        assert int(ev.status.item()) == 0, f"status 0x{int(ev.status.item()):x}"
+        assert torch.equal(ev.pos.view(torch.int64), e1.pos.view(torch.int64))
+    # against the step kernel (general + fast step without the bounds): f32 carry is bit-identical to stepping
+    e2 = MRVecEnv(n, cfg=cfg, seed=77); e2.reset()
+    e3 = MRVecEnv(n, cfg=cfg, seed=77); e3.reset()
+    out = e3.rollout(T, want=("obs", "rew", "done"))
+    for t in range(T):
+        obs, rew, done, info = e2.step(None)
+        assert torch.equal(out["obs"][t].view(torch.int32), obs.view(torch.int32)), t
+        assert torch.equal(out["done"][t], done)
+    e3.check_status()
