@@ -725,12 +725,19 @@ def measure_learner(args, n_local, dev, seed, streams):
            "batch": 64, "updates_per_s": {k: round(v, 1) for k, v in ups.items()},
            "us_per_update": {k: round(1e6 / v, 1) for k, v in ups.items()}, "end_to_end": []}
     ep = cfg.max_timesteps + 1
-    for math, U, episodes in (("f32", 8, 60), ("bf16", 4, 150), ("bf16", 0, 150)):
+    # learner_cus = 1: the learner's launches on 8 compute units of their own (one per XCC), the collection on the other 248
+    # (mr_rl_amd.partition) -- reported beside the shared-device rows
+    for math, U, episodes, cus in (("f32", 8, 60, 0), ("bf16", 4, 150, 0), ("bf16", 4, 150, 1), ("bf16", 0, 150, 0)):
         agent = DDPG(env, seed=seed, obs_scale=scale, fused=True)
         st = {}
-        rets = agent.train_collected(episodes, updates_per_episode=U, sample=4096, streams=streams, math=math, stats=st, warm_episodes=10)
+        rets = agent.train_collected(episodes, updates_per_episode=U, sample=4096, streams=streams, math=math, stats=st, warm_episodes=10,
+                                     learner_cus=cus)
+        if getattr(agent, "partition", None) is not None:
+            torch.cuda.synchronize(dev)
+            agent.partition.close()
         out["end_to_end"].append({
-            "actor_math": math, "updates_per_episode": U, "transitions_per_episode": n_local * ep,
+            "actor_math": math, "updates_per_episode": U, "learner_compute_units": 8 * cus if cus else "shared",
+            "transitions_per_episode": n_local * ep,
             "update_to_transition_ratio": U / float(n_local * ep), "value": st["env_steps_timed"] / st["seconds"], "unit": "env-steps/s",
             "updates_per_s": st["updates_timed"] / st["seconds"], "episodes_timed": st["episodes_timed"],
             "mean_return_last_episode": rets[-1] if rets else None})

@@ -393,6 +393,22 @@ int mrsim_velocity(int64_t n, int32_t T, int32_t n_filter, const double* traj_xy
 /* *step_base += delta on `stream` (a one-lane kernel; graph-capturable). */
 int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream);
 
+/* Streams confined to a subset of the device's compute units (hipExtStreamCreateWithCUMask), for running the learner beside
+ * the collection launches: one fused-rollout launch group of 262 144 envs is exactly one resident round of workgroups, so a kernel
+ * enqueued on any ordinary stream meanwhile (the learner's one-workgroup update, the replay push, the parameter upload) only finds a
+ * unit at a launch boundary and then displaces collection blocks for its whole duration.  With the collection streams masked off
+ * a few units and the learner's stream confined to those, neither waits for the other (mr_rl_amd/partition.py; RL/MR_ddpg.py:270-311
+ * is one loop -- this is what lets its two halves overlap on one GPU).
+ * mrsim_device_cu_layout: compute units of `device` and the number of XCCs mask bits are dealt over -- bit i of the mask is a
+ *   unit of XCC i % xccs (measured on MI355X: tools/cumask_probe.hip; workgroups are dealt round robin over the XCCs, so a mask must
+ *   keep at least one unit in EVERY XCC or a workgroup can be dealt where the queue has none -- mrsim_stream_create_cu_mask refuses
+ *   such masks with MRSIM_EINVAL).
+ * mrsim_stream_create_cu_mask: mask = n_words 32-bit words, bit set = unit usable; *stream_out receives a hipStream_t.
+ * mrsim_stream_destroy: synchronises and destroys such a stream. */
+int mrsim_device_cu_layout(int32_t device, int32_t* compute_units, int32_t* xccs);
+int mrsim_stream_create_cu_mask(int32_t device, const uint32_t* mask, int32_t n_words, void** stream_out);
+int mrsim_stream_destroy(void* stream);
+
 /* Test aid: out[n][4] = the 4 standard normals of RNG call `c0` for envs env_id0..env_id0+n-1
  * (bit-compared with the oracle's definition in tests/). */
 int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, uint32_t c0,

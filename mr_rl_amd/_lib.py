@@ -20,7 +20,7 @@ DDPG_PARAMS, DDPG_MAX_BATCH = 7680, 4096
 # every symbol include/mrsim.h declares (tests check the .so exports exactly these)
 SYMBOLS = (
     "mrsim_abi_version", "mrsim_strerror", "mrsim_default_params", "mrsim_reset", "mrsim_step",
-    "mrsim_step_timed", "mrsim_random_policy", "mrsim_random_policy_steps", "mrsim_rollout", "mrsim_rollout_timed", "mrsim_advance_step_base", "mrsim_velocity", "mrsim_debug_normals",
+    "mrsim_step_timed", "mrsim_random_policy", "mrsim_random_policy_steps", "mrsim_rollout", "mrsim_rollout_timed", "mrsim_advance_step_base", "mrsim_device_cu_layout", "mrsim_stream_create_cu_mask", "mrsim_stream_destroy", "mrsim_velocity", "mrsim_debug_normals",
     "mrsim_device_count", "mrsim_device_name",
     "mrsim_event_create", "mrsim_event_destroy", "mrsim_event_elapsed_ms", "mrsim_rollout_events", "mrsim_step_events",
     "mrsim_actor_fold_bn_host", "mrsim_actor_pack_host", "mrsim_actor_forward", "mrsim_ddpg_update",
@@ -120,6 +120,9 @@ def load(path):
     L.mrsim_rollout_timed.argtypes = L.mrsim_rollout.argtypes + [C.POINTER(C.c_float)]
     L.mrsim_velocity.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp]
     L.mrsim_advance_step_base.argtypes = [vp, u64, vp]
+    L.mrsim_device_cu_layout.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.mrsim_stream_create_cu_mask.argtypes = [C.c_int32, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]
+    L.mrsim_stream_destroy.argtypes = [vp]
     L.mrsim_event_create.argtypes = [C.POINTER(vp)]
     L.mrsim_event_destroy.argtypes = [vp]
     L.mrsim_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]

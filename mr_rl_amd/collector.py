@@ -83,7 +83,7 @@ class RolloutCollector:
         self._free_ev = [None] * self.depth     # recorded by release(): set b may be overwritten after it
         self._ret_free_ev = [None, None]        # recorded by free_returns_block(): block b may be overwritten after it
         self._start_ev = torch.cuda.Event()
-        self._prepared = {}                     # (shard, set, block, row, steps) -> prepared launch
+        self._prepared = {}                     # (shard, set, steps, parameter block) -> prepared launch
         self._prepared_version = env._params_version
         self.episodes = 0
         self._synced_streams = False
@@ -145,8 +145,9 @@ class RolloutCollector:
         """The prepared launch (argument block built once, vec_env.launch_rollout(prepare_only=True)) of sub-shard s into
         buffer set b / returns row (blk, row) for T steps (launch group k: which parameter block an in-kernel policy reads)."""
         slot = 0 if self.policy is None else k % len(self.policy.blobs)
-        key = (s, b, blk, row, T, slot)
+        key = (s, b, T, slot)
         launch = self._prepared.get(key)
+        first = self.shards[s][0]
         if launch is None:
             bufs, (first, n) = self.sets[b], self.shards[s]
             launch = self._prepared[key] = self.env.launch_rollout(
@@ -154,6 +155,9 @@ class RolloutCollector:
                 rew_T=bufs.get("rew"), done_T=bufs.get("done"), acts_T=bufs.get("actions"),
                 final_ret=self.ret_blocks[blk][row], final_len=self.len_blocks[blk][row], carry=self.carry,
                 stream=self.streams[s], prepare_only=True, actor=self.policy, actor_slot=slot)
+        # the returns row rotates every launch group: re-pointed in the prepared argument block (one block per buffer set, not per row)
+        launch.io.final_ret = self.ret_blocks[blk][row].data_ptr() + 4 * first
+        launch.io.final_len = self.len_blocks[blk][row].data_ptr() + 4 * first
         return launch
 
     def prime(self, schedule):

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
                 const float2 u = reinterpret_cast<const float2*>(ac.ou_state)[il];
                 ou0 = u.x; ou1 = u.y;
             }
-            actor_policy<ou_nz<NZ>(), ACT>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
+            // (the OU reset-on-done switch stays a run-time bit in the flag-specialised kernels too: one scalar test per step)
+            actor_policy<ou_nz<NZ>(), ACT>(P, FL != 0 ? (fl | (P.flags & kFOUReset)) : fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
         }
         int fail = 0;
         env_step<RK45, NZ, MIS>(P, R, io.goal_table, e, (double)af, (double)aa, W, fl, o, fail,
@@ -439,7 +440,8 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
         }
         step_prologue<RK45, NZ, MIS>(P, R, !HAS_ACT && !(fl & kFActions), W, af, aa, HAS_ACT && (fl & kFActorOU));
         if constexpr (HAS_ACT) {
-            actor_policy<ou_nz<NZ>(), ACT>(P, fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
+            // (the OU reset-on-done switch stays a run-time bit in the flag-specialised kernels too: one scalar test per step)
+            actor_policy<ou_nz<NZ>(), ACT>(P, FL != 0 ? (fl | (P.flags & kFOUReset)) : fl, ac, s_actor, obs_cur, e.counter, W.w[0], ou0, ou1, af, aa);
             if constexpr (MRSIM_ACTOR_PRIO == 3) __builtin_amdgcn_s_setprio(0);
             if constexpr (MRSIM_ACTOR_PRIO == 4) __builtin_amdgcn_s_setprio(3);
         }
@@ -1165,16 +1167,17 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
         const int nz = noise_variant(p);
         const bool mis = p->mismatched != 0;
         const bool bf = (K.flags & kFActorBf16) != 0, bfs = (K.flags & kFActorBf16s) != 0;
-        if (K.flags == kFlDdpgActor) rc = launch_rollout_actor_fl<kFlDdpgActor, kActF32>(lc, nz, mis, K, S, ra, AC, handled);
-        else if (K.flags == (kFlDdpgActor | kFActorBf16))
+        const uint32_t kf = K.flags & ~kFOUReset;   // (read at run time by the specialised kernels)
+        if (kf == kFlDdpgActor) rc = launch_rollout_actor_fl<kFlDdpgActor, kActF32>(lc, nz, mis, K, S, ra, AC, handled);
+        else if (kf == (kFlDdpgActor | kFActorBf16))
             rc = launch_rollout_actor_fl<kFlDdpgActor | kFActorBf16, kActBf16x3>(lc, nz, mis, K, S, ra, AC, handled);
-        else if (K.flags == (kFlDdpgActor | kFActorBf16s))
+        else if (kf == (kFlDdpgActor | kFActorBf16s))
             rc = launch_rollout_actor_fl<kFlDdpgActor | kFActorBf16s, kActBf16>(lc, nz, mis, K, S, ra, AC, handled);
 #ifndef MRSIM_NO_MIXED_ACTOR_FL   // (measurement builds: the generic actor rollout kernel on goal tables, tools/actor_mixed_probe.py)
-        else if (K.flags == kFlMixedActor) rc = launch_rollout_actor_fl<kFlMixedActor, kActF32>(lc, nz, mis, K, S, ra, AC, handled);
-        else if (K.flags == (kFlMixedActor | kFActorBf16))
+        else if (kf == kFlMixedActor) rc = launch_rollout_actor_fl<kFlMixedActor, kActF32>(lc, nz, mis, K, S, ra, AC, handled);
+        else if (kf == (kFlMixedActor | kFActorBf16))
             rc = launch_rollout_actor_fl<kFlMixedActor | kFActorBf16, kActBf16x3>(lc, nz, mis, K, S, ra, AC, handled);
-        else if (K.flags == (kFlMixedActor | kFActorBf16s))
+        else if (kf == (kFlMixedActor | kFActorBf16s))
             rc = launch_rollout_actor_fl<kFlMixedActor | kFActorBf16s, kActBf16>(lc, nz, mis, K, S, ra, AC, handled);
 #endif
         if (!handled)
@@ -1460,6 +1463,59 @@ int mrsim_advance_step_base(uint64_t* step_base, uint64_t delta, void* stream) {
     hipLaunchKernelGGL(mr_advance_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<unsigned long long*>(step_base), (unsigned long long)delta);
     return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+}
+
+// gfx950 (MI355X) in SPX mode: 8 XCCs; the driver deals the bits of a queue's CU mask over them round robin (bit i -> XCC i % 8,
+// tools/cumask_probe.hip).  A device whose unit count is not a multiple of 8 is reported as one XCC (no assumption made).
+static int xcc_count(int cus) { return (cus > 0 && cus % 8 == 0) ? 8 : 1; }
+
+int mrsim_device_cu_layout(int32_t device, int32_t* compute_units, int32_t* xccs) {
+    if (compute_units == nullptr || xccs == nullptr || device < 0) return MRSIM_EINVAL;
+    int rc = check_device();
+    if (rc) return rc;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return MRSIM_EINVAL;
+    }
+    *compute_units = cus;
+    *xccs = xcc_count(cus);
+    return MRSIM_OK;
+}
+
+int mrsim_stream_create_cu_mask(int32_t device, const uint32_t* mask, int32_t n_words, void** stream_out) {
+    if (mask == nullptr || stream_out == nullptr || n_words <= 0 || device < 0) return MRSIM_EINVAL;
+    int rc = check_device();
+    if (rc) return rc;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return MRSIM_EINVAL;
+    }
+    if ((long long)n_words * 32 < cus) return MRSIM_EINVAL;
+    // every XCC must keep a unit: workgroups are dealt over the XCCs whatever the mask says
+    const int xccs = xcc_count(cus);
+    for (int x = 0; x < xccs; ++x) {
+        bool any = false;
+        for (int b = x; b < cus && !any; b += xccs) any = (mask[b / 32] >> (b % 32)) & 1u;
+        if (!any) return MRSIM_EINVAL;
+    }
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return MRSIM_EINVAL; }
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) { (void)hipGetLastError(); return MRSIM_ELAUNCH; }
+    *stream_out = s;
+    return MRSIM_OK;
+}
+
+int mrsim_stream_destroy(void* stream) {
+    if (stream == nullptr) return MRSIM_EINVAL;
+    int rc = check_device();
+    if (rc) return rc;
+    (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    return hipStreamDestroy(static_cast<hipStream_t>(stream)) == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 
 int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, uint32_t c0, int32_t noise_math,

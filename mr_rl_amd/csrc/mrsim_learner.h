@@ -210,6 +210,14 @@ __device__ __forceinline__ void adam_soft(const Args& A, int p0, int p1, float l
     }
 }
 
+// Measurement build (tools/learner_phase_probe.py): thread 0 leaves the s_memtime reading (100 MHz) at the end of every phase of
+// the launch's LAST update in losses[2 + i], relative to that update's start; losses must then hold 16 floats.
+#ifdef MRSIM_LEARNER_PROBE
+#define LPROBE(i) do { if (tid == 0 && upd == A.n_updates - 1) A.losses[2 + (i)] = (float)(long long)(__builtin_readcyclecounter() - lprobe_t0); } while (0)
+#else
+#define LPROBE(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Lds& L = *reinterpret_cast<Lds*>(lds_raw);
@@ -228,6 +236,9 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
     const bool sampled = A.idx == nullptr && A.ring_count > 0;
     const bool one_tile = ntiles == 1;
   for (int upd = 0; upd < A.n_updates; ++upd) {   // (body not re-indented: one update = everything down to the closing brace)
+#ifdef MRSIM_LEARNER_PROBE
+    const unsigned long long lprobe_t0 = __builtin_readcyclecounter();
+#endif
     {
         const unsigned long long c = (((unsigned long long)A.ctr_hi << 32) | A.ctr_lo) + (unsigned long long)upd;
         c_lo = (uint32_t)c; c_hi = (uint32_t)(c >> 32);
@@ -251,6 +262,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             }
         }
     }
+    LPROBE(0);   // rows drawn
     auto load_tile = [&](int tile, bool force) {   // gather the tile's transitions
         if (one_tile && !force) return;            // a single tile stays in LDS for all three phases
         if (tid < kTile) {
@@ -292,6 +304,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
     // ------------------------------------------------------------------------------------------------ targets y
     stage_params(L, A.target, A.bn + 3 * 2 * 64, A.bn_eps, tid);
     __syncthreads();
+    LPROBE(1);   // target networks staged
     for (int tile = 0; tile < ntiles; ++tile) {
         load_tile(tile, true);
         layer1(L, L.s2, A_W1, A_B1, A_G1, A_BE1, 0, X0, nullptr, tid);                      // mu'(s2): layer 1
@@ -341,9 +354,11 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
         }
         __syncthreads();
     }
+    LPROBE(2);   // targets y
     // ------------------------------------------------------------------------------------------------ critic step
     stage_params(L, A.online, A.bn, A.bn_eps, tid);
     __syncthreads();
+    LPROBE(3);   // online networks staged
     for (int tile = 0; tile < ntiles; ++tile) {
         const bool first = tile == 0;
         load_tile(tile, false);
@@ -429,13 +444,16 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
     }
     __threadfence_block();
     __syncthreads();
+    LPROBE(4);   // critic forward + backward
     adam_soft(A, C_W1, kParams, A.critic_lr, L.bc[0], L.bc[1], tid);
     __threadfence_block();
     __syncthreads();
+    LPROBE(5);   // critic Adam + soft update
     // ------------------------------------------------------------------------------------------------ actor step (against the UPDATED critic)
     for (int p = C_W1 + tid * 4; p < kParams; p += kThreads * 4)
         *reinterpret_cast<float4*>(&L.P[p]) = *reinterpret_cast<const float4*>(A.online + p);
     __syncthreads();
+    LPROBE(6);   // updated critic re-staged
     for (int tile = 0; tile < ntiles; ++tile) {
         const bool first = tile == 0;
         load_tile(tile, false);
@@ -566,11 +584,13 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
     }
     __threadfence_block();
     __syncthreads();
+    LPROBE(7);   // actor forward, critic forward, backward through both
     adam_soft(A, A_W1, C_W1, A.actor_lr, L.bc[2], L.bc[3], tid);
     if (tid < 2) A.steps[tid] += 1;
     if (A.losses != nullptr && tid < 2) A.losses[tid] = L.loss[tid];
     __threadfence_block();
     __syncthreads();    // the next update of this launch stages the parameters this one wrote
+    LPROBE(8);   // actor Adam + soft update
   }
 }
 

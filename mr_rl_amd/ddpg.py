@@ -392,7 +392,7 @@ class DDPG:
         return self.last_losses
 
     def train_collected(self, episodes, updates_per_episode=4, sample=4096, streams=2, math="f32", graphed=True,
-                        on_episode=None, stats=None, warm_episodes=0):
+                        on_episode=None, stats=None, warm_episodes=0, learner_cus=0):
         """The loop of RL/MR_ddpg.py:251-323 at collection speed: every episode of all N envs is ONE fused launch group of
         the rollout kernel with this agent's actor (+ OU noise) as its in-kernel policy (RolloutCollector(policy=DeviceActor)),
         `sample` of its N x 51 transitions go into the replay ring, `updates_per_episode` learner updates follow (graph
@@ -404,7 +404,35 @@ class DDPG:
         updates_per_episode / (N x 51) -- say which one you ran.  Needs an env config with auto_reset=True.
         Returns the mean return of every episode (device tensors gathered once at the end: one host sync).
         stats: optional dict that receives the wall-clock seconds of episodes [warm_episodes, episodes) (the device is
-        synchronised at both ends of that span -- a measurement aid, two host syncs)."""
+        synchronised at both ends of that span -- a measurement aid, two host syncs).
+        learner_cus: 0 = everything shares the device (the learner's launches find a compute unit only at a launch boundary and
+        displace collection blocks: they do NOT hide behind the collection); k >= 1 = the device is partitioned
+        (mr_rl_amd.partition.CuPartition): k compute units of every XCC belong to the learner's stream (updates, replay push,
+        parameter upload, the bookkeeping copies), all others to `streams` collection streams (8 or 16 sub-shards then: the
+        collection no longer fits one resident round and the blocks that do not fit must be able to run beside the other
+        sub-shards' next launch group).  The learner then costs the collection its units (3 % for k = 1), not its time."""
+        env = self.env
+        if not learner_cus:
+            return self._train_collected(episodes, updates_per_episode, sample, streams, math, graphed, on_episode, stats,
+                                         warm_episodes, None)
+        from .partition import CuPartition
+        key = (int(learner_cus), int(streams))
+        if getattr(self, "_partition_key", None) != key:
+            if getattr(self, "partition", None) is not None:
+                torch.cuda.synchronize(env.device)
+                self.partition.close()
+            self.partition, self._partition_key = CuPartition(env.device, per_xcc=int(learner_cus), collection_streams=int(streams)), key
+        part = self.partition
+        outer = torch.cuda.current_stream(env.device)
+        part.learner_stream.wait_stream(outer)
+        with torch.cuda.stream(part.learner_stream):
+            out = self._train_collected(episodes, updates_per_episode, sample, streams, math, graphed, on_episode, stats,
+                                        warm_episodes, part.collection_streams)
+        outer.wait_stream(part.learner_stream)
+        return out
+
+    def _train_collected(self, episodes, updates_per_episode, sample, streams, math, graphed, on_episode, stats, warm_episodes,
+                         stream_list):
         from .actor import DeviceActor
         from .collector import RolloutCollector
         env = self.env
@@ -414,15 +442,17 @@ class DDPG:
         self._set_mode(training=False)
         pol = DeviceActor.from_module(self.actor, obs_scale=scale, device=env.device, ou=True, theta=self.noise.theta,
                                       sigma=self.noise.sigma, dt=self.noise.dt, reset_on_done=True, math=math, slots=2)
+        RB = 32                                   # episodes per block of returns (reduced block by block: bounded memory)
+        # Three rotating transition sets: the set of episode k - 1 stays untouched until episode k's replay push has read the
+        # observations its first actions were computed from (the last row of episode k - 1) -- no copy of that row.  Episode
+        # returns / lengths land in [RB, N] blocks written by the launches themselves (returns_interval).
         col = RolloutCollector(env.num_envs, cfg=env.cfg, device=env.device, seed=env.seed_value, env_id0=env.env_id0,
-                               goal_table=env.goal_table, streams=streams, policy=pol)
+                               goal_table=env.goal_table, streams=streams, policy=pol, stream_list=stream_list, depth=3,
+                               returns_interval=RB)
         prev_obs = col.reset().clone()                      # the observation the first action of the episode is computed from
         T, N = col.T, col.N
         gen = torch.Generator(device=env.device)
         gen.manual_seed(12345)
-        RB = 32                                   # episodes per block of stashed returns (reduced block by block: bounded memory)
-        ret_rows = torch.zeros((RB, N), dtype=torch.float32, device=env.device)
-        len_rows = torch.zeros((RB, N), dtype=torch.int32, device=env.device)
         means = []
         cur = torch.cuda.current_stream(env.device)
         native_push = env.device.type == "cuda" and not col.env._soa      # mrsim_replay_push reads [N][5] observation rows
@@ -440,13 +470,10 @@ class DDPG:
                 torch.cuda.synchronize(env.device)
                 t_start = time.perf_counter()
             b = col.ready(k)                                 # the current stream waits for episode k
-            if k + 2 < episodes:
+            if k > 0 and k + 2 < episodes:
                 # Block k % 2 was last read by episode k, which has finished: upload the parameters the learner has produced so far
-                # (its launches of the previous iterations precede this one on the current stream) and start episode k + 2 behind
-                # the upload alone.  The learner burst of THIS iteration is enqueued after it and runs beside the collection.
-                if k > 0:
-                    self.sync_policy(pol, slot=k % 2)
-                col.collect(after=cur)
+                # (its launches of the previous iterations precede this one on the current stream)
+                self.sync_policy(pol, slot=k % 2)
             obs_T = b["obs"]
             n_s = min(int(sample), T * N)
             if native_push:
@@ -458,12 +485,15 @@ class DDPG:
                 # s2 of a terminal transition is the next episode's reset observation here; its target is r alone (1 - done = 0)
                 self.buffer.add(self._prep(s), b["actions"][ti, ei], b["rew"][ti, ei], b["done"][ti, ei].float(),
                                 self._prep(obs_T[ti, ei]))
-            ret_rows[k % RB].copy_(b["final_ret"], non_blocking=True)   # reduced to mean returns once per RB episodes (two copies per
-            len_rows[k % RB].copy_(b["final_len"], non_blocking=True)   # episode instead of six small kernels)
-            if k % RB == RB - 1 or k == episodes - 1:
-                means.append(_mean_returns(ret_rows[:k % RB + 1], len_rows[:k % RB + 1]))
-            prev_obs = obs_T[T - 1].clone()
-            col.release(k)
+            prev_obs = obs_T[T - 1]                          # a view: its set is released one episode late (below)
+            if k > 0:
+                col.release(k - 1)
+            if k + 2 < episodes:
+                col.collect(after=cur)                       # episode k + 2 starts behind the upload and the release alone;
+            blk, row = (k // RB) % 2, k % RB                 # the learner burst below runs beside the collection
+            if row == RB - 1 or k == episodes - 1:
+                means.append(_mean_returns(col.ret_blocks[blk][:row + 1], col.len_blocks[blk][:row + 1]))
+                col.free_returns_block(blk)
             if updates_per_episode > 0:
                 if graphed and env.device.type == "cuda":
                     self.update_graphed(updates_per_episode)
@@ -471,7 +501,7 @@ class DDPG:
                     for _ in range(updates_per_episode):
                         self.update()
             if on_episode is not None:
-                on_episode(k, _mean_returns(ret_rows[k % RB:k % RB + 1], len_rows[k % RB:k % RB + 1])[0])
+                on_episode(k, _mean_returns(b["final_ret"][None], b["final_len"][None])[0])
         col.join()
         if stats is not None and t_start is not None:
             torch.cuda.synchronize(env.device)

@@ -1,0 +1,67 @@
+"""CuPartition: the GPU's compute units split between the collection launches and the learner, so that the two halves of the
+DDPG loop (RL/MR_ddpg.py:270-311: act / step / store, then the update) overlap on ONE device.
+
+Why a partition.  A fused-rollout launch group of 262 144 envs is exactly one resident round of workgroups on 256 units.  Work
+enqueued meanwhile on an ordinary stream -- the learner's one-workgroup update burst (152 KB of LDS: a whole unit), the replay
+push, the parameter upload the next-but-one episode waits for -- finds a unit only at a launch boundary, where it races the next
+launch group for it, and then holds up the collection blocks it displaced for its own duration.  Measured without a partition:
+the loop runs at 406 us per episode against 272 us of collection kernel with NO updates at all, and every update adds its full
+49 us (profiles/r04/NOTES.md).
+
+The partition: hipExtStreamCreateWithCUMask (through libmrsim: mrsim_stream_create_cu_mask).  Mask bit i is a unit of XCC i % 8
+(tools/cumask_probe.hip); workgroups are dealt round robin over the XCCs whatever the mask says, so both sides keep units in
+every XCC: the learner gets `per_xcc` units of each XCC (8 units for per_xcc = 1: 3 % of the device), the collection streams all
+the others.  The collection launches no longer fit one round; with the env set cut into 8 or 16 sub-shards on as many streams the
+blocks that do not fit run beside the next launch group of the other sub-shards (no env waits for an env of another sub-shard).
+"""
+import ctypes as C
+
+from . import _lib
+
+
+class CuPartition:
+    def __init__(self, device="cuda", per_xcc=1, collection_streams=8):
+        import torch
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("CuPartition needs a HIP device (libmrsim has no CPU fallback)")
+        self._L = _lib.lib()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.index = int(idx)
+        cus, xccs = C.c_int32(0), C.c_int32(0)
+        _lib.check(self._L.mrsim_device_cu_layout(self.index, C.byref(cus), C.byref(xccs)), "mrsim_device_cu_layout")
+        self.compute_units, self.xccs = int(cus.value), int(xccs.value)
+        per_xcc = int(per_xcc)
+        if per_xcc < 1 or per_xcc * self.xccs * 2 > self.compute_units:
+            raise ValueError("per_xcc must leave the collection at least half of the device")
+        self.learner_units = per_xcc * self.xccs
+        words = (self.compute_units + 31) // 32
+        learner, collect = [0] * words, [0] * words
+        for b in range(self.compute_units):
+            (learner if b < self.learner_units else collect)[b // 32] |= 1 << (b % 32)    # bits 0 .. per_xcc * xccs - 1: per_xcc units per XCC
+        self.learner_mask, self.collection_mask = learner, collect
+        self._handles = []
+        self.learner_stream = self._stream(learner)
+        self.collection_streams = [self._stream(collect) for _ in range(int(collection_streams))]
+
+    def _stream(self, mask):
+        import torch
+        arr = (C.c_uint32 * len(mask))(*mask)
+        h = C.c_void_p()
+        _lib.check(self._L.mrsim_stream_create_cu_mask(self.index, arr, len(mask), C.byref(h)), "mrsim_stream_create_cu_mask")
+        self._handles.append(h)
+        return torch.cuda.ExternalStream(h.value, device=self.device)
+
+    def close(self):
+        """synchronise and destroy the streams (the torch wrappers must not be used afterwards)"""
+        for h in self._handles:
+            self._L.mrsim_stream_destroy(h)
+        self._handles = []
+        self.learner_stream, self.collection_streams = None, []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

@@ -414,6 +414,7 @@ class MRVecEnv:
             else:
                 _lib.check(L.mrsim_rollout(*head, int(step_idx), strm), "mrsim_rollout")
 
+        launch.io = io    # (a caller that rotates final_ret / final_len rows re-points them here instead of preparing a launch per row)
         if prepare_only:
             return launch
         launch(self.step_idx if step_idx is None else int(step_idx), events=events, timed_into=timed_into)

@@ -176,3 +176,21 @@ def test_abi4_entry_points_validate_their_arguments_and_have_no_cpu_path():
     assert L.mrsim_actor_pack_device(d, d, 0.0, sc, bd, base, None) == _lib.EINVAL
     assert L.mrsim_actor_pack_device(d, d, 1e-5, sc, bd, base + 4, None) == _lib.EALIGN
     assert L.mrsim_actor_pack_device(d, d, 1e-5, sc, bd, base, None) in (_lib.ENODEVICE, _lib.OK)
+
+
+def test_cu_mask_stream_entry_points_validate_their_arguments():
+    from mr_rl_amd import _lib
+    L = _lib.lib()
+    cus, xccs, h = C.c_int32(0), C.c_int32(0), C.c_void_p()
+    m = (C.c_uint32 * 8)(*([0xffffffff] * 8))
+    assert L.mrsim_device_cu_layout(0, None, C.byref(xccs)) == _lib.EINVAL
+    assert L.mrsim_device_cu_layout(-1, C.byref(cus), C.byref(xccs)) == _lib.EINVAL
+    assert L.mrsim_stream_create_cu_mask(0, None, 8, C.byref(h)) == _lib.EINVAL
+    assert L.mrsim_stream_create_cu_mask(0, m, 0, C.byref(h)) == _lib.EINVAL
+    assert L.mrsim_stream_create_cu_mask(0, m, 8, None) == _lib.EINVAL
+    assert L.mrsim_stream_destroy(None) == _lib.EINVAL
+    assert L.mrsim_device_cu_layout(0, C.byref(cus), C.byref(xccs)) in (_lib.ENODEVICE, _lib.OK)
+    rc = L.mrsim_stream_create_cu_mask(0, m, 8, C.byref(h))
+    assert rc in (_lib.ENODEVICE, _lib.OK)
+    if rc == _lib.OK:
+        assert L.mrsim_stream_destroy(h) == _lib.OK

@@ -622,3 +622,67 @@ def test_fast_step_bounds_never_certify_a_step_the_fp64_tests_refuse(case, law):
         assert torch.equal(out["obs"][t].view(torch.int32), obs.view(torch.int32)), t
         assert torch.equal(out["done"][t], done)
     e3.check_status()
+
+
+# ---------------------------------------------------------------------------
+# compute-unit partition (mrsim_stream_create_cu_mask, mr_rl_amd.partition): scheduling only -- same numbers
+# ---------------------------------------------------------------------------
+def test_cu_mask_streams_refuse_masks_that_leave_an_xcc_without_a_unit():
+    import ctypes as C
+    from mr_rl_amd import _lib
+    L = _lib.lib()
+    cus, xccs = C.c_int32(0), C.c_int32(0)
+    assert L.mrsim_device_cu_layout(0, C.byref(cus), C.byref(xccs)) == _lib.OK
+    assert cus.value == 256 and xccs.value == 8          # MI355X, SPX
+    h = C.c_void_p()
+    words = (cus.value + 31) // 32
+    one_xcc = (C.c_uint32 * words)(*([0x01010101] * words))      # bits 0, 8, 16, ...: units of XCC 0 only
+    assert L.mrsim_stream_create_cu_mask(0, one_xcc, words, C.byref(h)) == _lib.EINVAL
+    assert L.mrsim_stream_create_cu_mask(0, one_xcc, words - 1, C.byref(h)) == _lib.EINVAL
+    per_xcc = (C.c_uint32 * words)(*([0xff] + [0] * (words - 1)))  # one unit in each XCC
+    assert L.mrsim_stream_create_cu_mask(0, per_xcc, words, C.byref(h)) == _lib.OK and h.value
+    assert L.mrsim_stream_destroy(h) == _lib.OK
+    assert L.mrsim_stream_destroy(None) == _lib.EINVAL
+
+
+def test_rollout_on_cu_masked_streams_gives_the_same_bits():
+    """a collector whose sub-shards run on streams confined to 248 of the 256 units, driven from the learner's 8-unit stream"""
+    import torch
+    from mr_rl_amd import MRConfig
+    from mr_rl_amd.collector import RolloutCollector
+    from mr_rl_amd.partition import CuPartition
+    cfg = MRConfig(noise_var=1.0, auto_reset=True, noise_law="collapsed")
+    n = 40000
+    ref = RolloutCollector(n, cfg=cfg, seed=3, streams=2)
+    ref.reset(); ref.collect(); ref.collect()
+    want = {k: v.clone() for k, v in ref.ready(1).items()}
+    ref.check_status()
+    with CuPartition("cuda", per_xcc=1, collection_streams=4) as part:
+        assert part.learner_units == 8 and part.compute_units == 256
+        with torch.cuda.stream(part.learner_stream):
+            col = RolloutCollector(n, cfg=cfg, seed=3, streams=4, stream_list=part.collection_streams)
+            col.reset(); col.collect(); col.collect()
+            got = col.ready(1)
+            for k in want:
+                assert torch.equal(got[k], want[k]), k
+            col.check_status()
+        torch.cuda.synchronize()
+
+
+def test_partitioned_training_equals_shared_training():
+    """DDPG.train_collected(learner_cus=1): the learner's launches on their own compute units -- every update, push and upload is
+    ordered against the collection by the same events, so returns and parameters come out bit-identical"""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.ddpg import DDPG
+    cfg = MRConfig(noise_var=1.0, auto_reset=True, noise_law="collapsed", reward_mode="goal", min_dist2goal=8.0)
+    out = []
+    for cus in (0, 1):
+        env = MRVecEnv(8192, cfg=cfg, seed=5)
+        ag = DDPG(env, seed=5, obs_scale=[0.01] * 5, fused=True)
+        rets = ag.train_collected(12, updates_per_episode=3, sample=1024, streams=2, math="bf16", learner_cus=cus)
+        torch.cuda.synchronize()
+        out.append((rets, ag.fused.online.clone(), ag.fused.target.clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    assert len(out[0][0]) == 12
