@@ -66,13 +66,21 @@ __device__ __forceinline__ void ldvec(const float* __restrict__ p, float (&v)[N]
     }
 }
 
+// The products run on packed fp32 FMAs (v_pk_fma_f32: two IEEE fmas per lane and instruction, twice v_fma_f32's rate -- the rate
+// the 157 TFLOP/s fp32 vector peak is quoted on): the accumulator tile is held as pairs along its TN direction, the A element is
+// splat into both halves.  Same roundings as the scalar form.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int TM, int TN, int K, bool AT>
 __device__ __forceinline__ void lgemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int m0, int n0,
                                       float (&acc)[TM][TN]) {
+    static_assert(TN == 2 || TN == 4, "tile widths are 2 or 4");
+    constexpr int H = TN / 2;
+    f32x2 c[TM][H];
 #pragma unroll
     for (int x = 0; x < TM; ++x)
 #pragma unroll
-        for (int y = 0; y < TN; ++y) acc[x][y] = 0.f;
+        for (int y = 0; y < H; ++y) c[x][y] = (f32x2){0.f, 0.f};
     if constexpr (AT) {
         for (int k = 0; k < K; k += 4) {
             float av[TM][4];
@@ -83,9 +91,11 @@ __device__ __forceinline__ void lgemm(const float* __restrict__ A, int lda, cons
                 float bv[TN];
                 ldvec<TN>(B + (k + kk) * ldb + n0, bv);
 #pragma unroll
-                for (int x = 0; x < TM; ++x)
+                for (int x = 0; x < TM; ++x) {
+                    const f32x2 a2 = {av[x][kk], av[x][kk]};
 #pragma unroll
-                    for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_fmaf(av[x][kk], bv[y], acc[x][y]);
+                    for (int y = 0; y < H; ++y) c[x][y] = __builtin_elementwise_fma(a2, (f32x2){bv[2 * y], bv[2 * y + 1]}, c[x][y]);
+                }
             }
         }
     } else {
@@ -95,11 +105,17 @@ __device__ __forceinline__ void lgemm(const float* __restrict__ A, int lda, cons
             ldvec<TM>(A + k * lda + m0, av);
             ldvec<TN>(B + k * ldb + n0, bv);
 #pragma unroll
-            for (int x = 0; x < TM; ++x)
+            for (int x = 0; x < TM; ++x) {
+                const f32x2 a2 = {av[x], av[x]};
 #pragma unroll
-                for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_fmaf(av[x], bv[y], acc[x][y]);
+                for (int y = 0; y < H; ++y) c[x][y] = __builtin_elementwise_fma(a2, (f32x2){bv[2 * y], bv[2 * y + 1]}, c[x][y]);
+            }
         }
     }
+#pragma unroll
+    for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < H; ++y) { acc[x][2 * y] = c[x][y].x; acc[x][2 * y + 1] = c[x][y].y; }
 }
 
 struct Lds {
@@ -111,7 +127,7 @@ struct Lds {
     float loss[2];
     float bc[4];               // Adam bias corrections: critic (1 - b1^t, sqrt(1 - b2^t)), actor
     int rows[kTile];
-    int sel[kMaxBatch];        // rows drawn in-kernel
+    alignas(16) int sel[kMaxBatch];   // rows drawn in-kernel (read 16 bytes at a time by the duplicate check)
 };
 
 __device__ __forceinline__ void stage_params(Lds& L, const float* __restrict__ src, const float* __restrict__ bn, float eps, int tid) {
@@ -187,14 +203,29 @@ __device__ __forceinline__ void layer1_backward(Lds& L, const float* __restrict_
 
 // Adam (torch.optim.Adam's formula: theta -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)) + soft update of the target,
 // four parameters per thread and pass (16-byte accesses; [p0, p1) is 16-byte aligned -- the padding floats carry zero gradients)
-__device__ __forceinline__ void adam_soft(const Args& A, int p0, int p1, float lr, float bc1, float bc2s, int tid) {
+template <int P0, int P1>
+__device__ __forceinline__ void adam_soft(const Args& A, float lr, float bc1, float bc2s, int tid) {
     const float c1 = 1.0f - A.beta1, c2 = 1.0f - A.beta2, step = lr / bc1, omt = 1.0f - A.tau;
-    for (int p = p0 + tid * 4; p < p1; p += kThreads * 4) {
-        const float4 g4 = *reinterpret_cast<const float4*>(A.grad + p), m4 = *reinterpret_cast<const float4*>(A.adam_m + p),
-                     v4 = *reinterpret_cast<const float4*>(A.adam_v + p), o4 = *reinterpret_cast<const float4*>(A.online + p),
-                     t4 = *reinterpret_cast<const float4*>(A.target + p);
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w},
-                    oo[4] = {o4.x, o4.y, o4.z, o4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+    // every load of the thread's parameters in flight before the first store (the pointers may alias as far as the compiler knows:
+    // written as one loop it waits for a round trip to L2 per pass)
+    constexpr int NIT = (P1 - P0 + kThreads * 4 - 1) / (kThreads * 4);
+    float4 g4[NIT], m4[NIT], v4[NIT], o4[NIT], t4[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = P0 + (it * kThreads + tid) * 4;
+        if (p < P1) {
+            g4[it] = *reinterpret_cast<const float4*>(A.grad + p); m4[it] = *reinterpret_cast<const float4*>(A.adam_m + p);
+            v4[it] = *reinterpret_cast<const float4*>(A.adam_v + p); o4[it] = *reinterpret_cast<const float4*>(A.online + p);
+            t4[it] = *reinterpret_cast<const float4*>(A.target + p);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = P0 + (it * kThreads + tid) * 4;
+        if (p >= P1) continue;
+        const float g[4] = {g4[it].x, g4[it].y, g4[it].z, g4[it].w}, mm[4] = {m4[it].x, m4[it].y, m4[it].z, m4[it].w},
+                    vv[4] = {v4[it].x, v4[it].y, v4[it].z, v4[it].w}, oo[4] = {o4[it].x, o4[it].y, o4[it].z, o4[it].w},
+                    tt[4] = {t4[it].x, t4[it].y, t4[it].z, t4[it].w};
         float mo[4], vo[4], th[4], tg[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -211,7 +242,7 @@ __device__ __forceinline__ void adam_soft(const Args& A, int p0, int p1, float l
 }
 
 // Measurement build (tools/learner_phase_probe.py): thread 0 leaves the s_memtime reading (100 MHz) at the end of every phase of
-// the launch's LAST update in losses[2 + i], relative to that update's start; losses must then hold 16 floats.
+// the launch's LAST update in losses[2 + i], relative to that update's start; losses must then hold 32 floats.
 #ifdef MRSIM_LEARNER_PROBE
 #define LPROBE(i) do { if (tid == 0 && upd == A.n_updates - 1) A.losses[2 + (i)] = (float)(long long)(__builtin_readcyclecounter() - lprobe_t0); } while (0)
 #else
@@ -253,7 +284,10 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
                 int dup = 0;
                 if (tid < A.batch) {
                     const int mine = L.sel[tid];
-                    for (int j = 0; j < tid; ++j) dup |= (L.sel[j] == mine);
+                    for (int j = 0; j < tid; j += 4) {     // (sel is 16-byte aligned; entries at or past tid are masked)
+                        const int4 e = *reinterpret_cast<const int4*>(&L.sel[j]);
+                        dup |= (e.x == mine) | ((j + 1 < tid) & (e.y == mine)) | ((j + 2 < tid) & (e.z == mine)) | ((j + 3 < tid) & (e.w == mine));
+                    }
                 }
                 const int any = __syncthreads_or(dup);
                 if (!any) break;
@@ -445,7 +479,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
     __threadfence_block();
     __syncthreads();
     LPROBE(4);   // critic forward + backward
-    adam_soft(A, C_W1, kParams, A.critic_lr, L.bc[0], L.bc[1], tid);
+    adam_soft<C_W1, kParams>(A, A.critic_lr, L.bc[0], L.bc[1], tid);
     __threadfence_block();
     __syncthreads();
     LPROBE(5);   // critic Adam + soft update
@@ -459,6 +493,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
         load_tile(tile, false);
         layer1(L, L.s, A_W1, A_B1, A_G1, A_BE1, 0, X0, X1, tid);                            // h1: X0 feature-major, X1 sample-major
         __syncthreads();
+        LPROBE(9);
         {
             float z[4][4];
             lgemm<4, 4, 64, true>(&L.P[A_W2], 64, X0, 64, ty * 4, tx * 4, z);
@@ -485,6 +520,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             }
         }
         __syncthreads();
+        LPROBE(10);
         if (tid < kTile * 2) {
             float z3 = L.P[A_B3 + (tid & 1)];
             for (int q = 0; q < 16; ++q) z3 += X4[q * 128 + tid];
@@ -493,8 +529,10 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             L.ap[tid] = t * ((tid & 1) ? A.bound1 : A.bound0);                               // a' = mu(s)
         }
         __syncthreads();
+        LPROBE(11);
         layer1(L, L.s, C_W1, C_B1, C_G1, C_BE1, 2, X4, nullptr, tid);                       // Q(s, a') with the new critic: layer 1 -> X4
         __syncthreads();
+        LPROBE(12);
         {
             float z[2][4];
             critic_l2(X4, L.ap, z);
@@ -517,6 +555,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
                 for (int c = 0; c < 3; ++c) X0[(ty * 64 + tx * 4 + v) * 3 + c] = pq[v][c];   // X0 (h1 feature-major) is free
         }
         __syncthreads();
+        LPROBE(13);
         if (tid < kTile) {
             float q = L.P[C_BO], d0 = 0.f, d1 = 0.f;
             for (int w = 0; w < 16; ++w) { q += X0[(w * 64 + tid) * 3]; d0 += X0[(w * 64 + tid) * 3 + 1]; d1 += X0[(w * 64 + tid) * 3 + 2]; }
@@ -526,6 +565,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             L.dz3[tid * 2 + 1] = -d1 * invB * A.bound1 * (1.0f - t1 * t1);
         }
         __syncthreads();
+        LPROBE(14);
         {   // output layer gradients, delta of hidden layer 2 (in place of z-hat 2, X3), gamma / beta / bias 2 gradients
             const int k = tid & 63, part = tid >> 6;
             float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // dg2, dbe2, db2, dW3[0][k], dW3[1][k]
@@ -545,6 +585,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             for (int q = 0; q < 5; ++q) X4[(part * 64 + k) * 5 + q] = acc[q];               // X4: its reader (critic_l2) passed two barriers
         }
         __syncthreads();
+        LPROBE(15);
         for (int o = tid; o < 64 * 5; o += kThreads) {
             const int k = o / 5, q = o - 5 * k;
             const float v = X4[(0 * 64 + k) * 5 + q] + X4[(1 * 64 + k) * 5 + q] + X4[(2 * 64 + k) * 5 + q] + X4[(3 * 64 + k) * 5 + q];
@@ -567,7 +608,8 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
                     A.grad[p] = first ? g[u][v] : A.grad[p] + g[u][v];
                 }
         }
-        __syncthreads();                                                                    // X2 (h2) was read above by other threads
+        __syncthreads();
+        LPROBE(16);                                                                    // X2 (h2) was read above by other threads
         {   // d h1[i][k] = sum_f dz2[i][f] W2[f][k]  ->  dL/dn of layer 1 (sample-major, X2)
             float e[4][4];
             lgemm<4, 4, 64, true>(X3, 64, &L.P[A_W2], 64, ty * 4, tx * 4, e);
@@ -580,12 +622,13 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
                 }
         }
         __syncthreads();
+        LPROBE(17);
         layer1_backward(L, X2, L.s, A_W1, A_B1, A_G1, A_BE1, 0, X4, A.grad, first, tid);
     }
     __threadfence_block();
     __syncthreads();
     LPROBE(7);   // actor forward, critic forward, backward through both
-    adam_soft(A, A_W1, C_W1, A.actor_lr, L.bc[2], L.bc[3], tid);
+    adam_soft<A_W1, C_W1>(A, A.actor_lr, L.bc[2], L.bc[3], tid);
     if (tid < 2) A.steps[tid] += 1;
     if (A.losses != nullptr && tid < 2) A.losses[tid] = L.loss[tid];
     __threadfence_block();
