@@ -132,6 +132,9 @@ def parse(argv=None):
     ap.add_argument("--no-power", action="store_true", help="skip the 1.5 s package-power leg (hwmon sysfs)")
     ap.add_argument("--no-actor-leg", action="store_true", help="skip the actor-in-the-loop collection measurement")
     ap.add_argument("--no-learner-leg", action="store_true", help="skip the DDPG learner measurement (updates/s, end-to-end training rate)")
+    ap.add_argument("--no-partition-row", action="store_true",
+                    help="learner leg without its compute-unit-partition row (rocprofv3's kernel trace of ROCm 7.2 crashes at exit "
+                         "when the process has created CU-masked streams)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--master-port", type=int, default=0, help="--gpus N launcher: rendezvous port (0 = pick a free one)")
@@ -727,7 +730,10 @@ def measure_learner(args, n_local, dev, seed, streams):
     ep = cfg.max_timesteps + 1
     # learner_cus = 1: the learner's launches on 8 compute units of their own (one per XCC), the collection on the other 248
     # (mr_rl_amd.partition) -- reported beside the shared-device rows
-    for math, U, episodes, cus in (("f32", 8, 60, 0), ("bf16", 4, 150, 0), ("bf16", 4, 150, 1), ("bf16", 0, 150, 0)):
+    rows = [("f32", 8, 60, 0), ("bf16", 4, 150, 0), ("bf16", 4, 150, 1), ("bf16", 0, 150, 0)]
+    if getattr(args, "no_partition_row", False):
+        rows = [r for r in rows if r[3] == 0]
+    for math, U, episodes, cus in rows:
         agent = DDPG(env, seed=seed, obs_scale=scale, fused=True)
         st = {}
         rets = agent.train_collected(episodes, updates_per_episode=U, sample=4096, streams=streams, math=math, stats=st, warm_episodes=10,

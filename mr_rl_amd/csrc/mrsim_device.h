@@ -1116,8 +1116,13 @@ struct EnvRegs {
 // (accept_level0, construct_level0: ~25 fp64-rate instructions) from BOUNDS instead: |x|, |y| as the last observation holds them,
 // an upper bound kb of max|K0|, and |f| of this step's action.
 struct Lm1 {
-    float m, M, kb, fa;   // min / max of (|x|, |y|), the bound of max|K0|, |f|
+    float m, kb, fa;   // min(|x|, |y|), the bound of max|K0|, |f|
+    uint32_t xy_or;    // bits(x) | bits(y) of the float32 coordinates: as a float, its magnitude is >= max(|x|, |y|)
 };
+__device__ __forceinline__ void lm1_position(Lm1& lm, float ox, float oy) {
+    lm.m = fminf(__builtin_fabsf(ox), __builtin_fabsf(oy));
+    lm.xy_or = __float_as_uint(ox) | __float_as_uint(oy);
+}
 __device__ __forceinline__ float lm1_bound(double f0x, double f0y) {
     return fmaxf(__builtin_fabsf((float)f0x), __builtin_fabsf((float)f0y)) * 1.000001f;
 }
@@ -1146,6 +1151,7 @@ __device__ __forceinline__ bool rk45_fast_step(const KParams& P, const RhsCtx<MI
     //   (sum |B_i| r_i <= 1.5536 Zmax and cB r_1 <= 0.8642 Zmax are both below 10.6);  m = min(|x|, |y|) -> mn = m - dlt after the step
     //   accept_level0:     dt (sigma R32 + |E0| Dhi) <= 0.99 (atol + rtol m)
     //   construct_level0:  mn >= k_h0 Fhi;  h1_thresh_m (atol + rtol mn) >= max(Fhi, Gd);  max|f0| >= 2e-5 (atol + rtol 16385) with max(|x|, |y|) + dlt <= 16384
+    //                      (max(|x|, |y|) < 8192 and dlt <= m, which mn >= 0 implies)
     // The host folds the constants and their margins (make_kparams: lm_*): dlt = lm_da |f| + lm_dk kb + lm_dc; the two construct
     // conditions on mn become mn >= max(lm_kh Fhi, lm_mg) with lm_kh = max(k_h0, 1 / (h1_thresh_m rtol)), lm_mg = (Gd / h1_thresh_m - atol) / rtol.
     // When every lane of the wave passes, the wave skips the fp64 tests (same outcome: commit); otherwise all lanes evaluate them.
@@ -1159,7 +1165,8 @@ __device__ __forceinline__ bool rk45_fast_step(const KParams& P, const RhsCtx<MI
             const float mn = __builtin_fmaf(lm->m, 0.99999f, -dlt);
             const bool cb = __builtin_fmaf(P.lm_es, A.R32, P.lm_ed * Dhi) <= __builtin_fmaf(P.lm_rt, lm->m, P.lm_at);
             const bool c12 = mn >= fmaxf(P.lm_kh * Fhi, P.lm_mg);
-            const bool c3 = (__builtin_fmaf(lm->M, 1.00001f, dlt) <= 16384.0f) & ((__builtin_fabs(f0x) >= P.lm_ccap) | (__builtin_fabs(f0y) >= P.lm_ccap));
+            // max(|x|, |y|) < 8192 (the OR of the two bit patterns has the larger exponent or more) and, from c12, dlt <= m: |xn|, |yn| < 16384
+            const bool c3 = (__builtin_fabsf(__uint_as_float(lm->xy_or)) < 8192.0f) & ((__builtin_fabs(f0x) >= P.lm_ccap) | (__builtin_fabs(f0y) >= P.lm_ccap));
             const bool lm1 = cb & c12 & c3 & (e.h_abs >= P.dt);
 #ifdef MRSIM_VERIFY_LM1   // verification build (tests): the bounds must never certify a step the fp64 tests would refuse
             {

@@ -345,7 +345,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
     int fail = 0;
     // fp32 side data of the fast step's level -1 test (mrsim_device.h: Lm1)
     Lm1 lm;
-    lm.m = fminf(__builtin_fabsf((float)e.x), __builtin_fabsf((float)e.y)); lm.M = fmaxf(__builtin_fabsf((float)e.x), __builtin_fabsf((float)e.y));
+    lm1_position(lm, (float)e.x, (float)e.y);
     lm.kb = lm1_bound(e.f0x, e.f0y); lm.fa = 0.f;
     const unsigned slot = hw_wave_slot();
     float* obs_lane = ra.obs_T != nullptr ? ra.obs_T + (blk0 + tid) * 5 : nullptr;  // row t = 0 of this lane's [N][5] record
@@ -475,8 +475,7 @@ __device__ __forceinline__ void rollout_body(const KParams& P, const StateArgs& 
                 have_slot &= ~ended;                               // their next episode starts now: no slot for it yet
             }
         }
-        lm.m = fminf(__builtin_fabsf(o.obs[0]), __builtin_fabsf(o.obs[1]));      // the position the next step starts from, as float32
-        lm.M = fmaxf(__builtin_fabsf(o.obs[0]), __builtin_fabsf(o.obs[1]));
+        lm1_position(lm, o.obs[0], o.obs[1]);      // the position the next step starts from, as float32
         if constexpr (HAS_ACT) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) obs_cur[j] = o.obs[j];  // what the policy sees next (the reset row after an auto-reset)
