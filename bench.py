@@ -723,6 +723,8 @@ def measure_learner(args, n_local, dev, seed, streams):
     ups["hipgraph_replay"] = rate(lambda n: ag.update_graphed(n), 1000)
     ag = filled(fused=True)
     ups["fused_kernel"] = rate(lambda n: [ag.update() for _ in range(n)], 3000)
+    # the form train_collected uses: a burst of updates per launch (the kernel loops; one host call per burst)
+    ups["fused_kernel_8_per_launch"] = rate(lambda n: [ag.update_graphed(8) for _ in range(n // 8)], 3200)
     out = {"what": "the DDPG learner: updates/s on a filled ring (batch 64, the reference's) and env-steps/s of the whole loop "
                    "(collection with the actor in the kernel + learner) at a stated update : transition ratio",
            "batch": 64, "updates_per_s": {k: round(v, 1) for k, v in ups.items()},
