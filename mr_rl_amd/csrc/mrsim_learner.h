@@ -66,56 +66,55 @@ __device__ __forceinline__ void ldvec(const float* __restrict__ p, float (&v)[N]
     }
 }
 
-// The products run on packed fp32 FMAs (v_pk_fma_f32: two IEEE fmas per lane and instruction, twice v_fma_f32's rate -- the rate
-// the 157 TFLOP/s fp32 vector peak is quoted on): the accumulator tile is held as pairs along its TN direction, the A element is
-// splat into both halves.  Same roundings as the scalar form.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The 64 x 64 (x 64 / 32) and 32 x 64 products of the update run on the matrix cores: v_mfma_f32_16x16x4_f32, laid out so that every
+// lane ends up with EXACTLY the TM x 4 register tile the surrounding code works on (rows m0 = ty TM .., columns n0 = 4 tx ..;
+// tid = 16 ty + tx, so lane = 16 (ty & 3) + tx):
+//   * a wave owns the 4 TM rows of its four ty values and all 64 columns, as four 16 x 16 MFMA tiles t = 0..3; MFMA tile t's column
+//     j stands for logical column 4 j + t, i.e. the B operand of lane (k-group gk = lane >> 4, j = lane & 15) for the four tiles
+//     is ONE 16-byte LDS read B[k][4 j .. 4 j + 3] -- the read the register-tiled loop did;
+//   * the D operand of lane (g = lane >> 4, j) holds rows 4 g + r of tile t: acc[r][t] = tile t, register r = the thread tile
+//     (TM = 2: only r < 2 carry rows, the A lanes of the other two feed zeros -- half the matrix work is idle there);
+//   * step s of a 16-deep k block contracts k = 16 b + 4 gk + s: a row-major A (AT) is read 16 bytes per lane and block.
+// Per wave and 64 x 64 x 64 product: 64 MFMAs (2 048 cycles) and 20 sixteen-byte LDS reads -- the register-tiled loop issued 128
+// such reads per lane and was bound by the LDS return path (profiles/r04/NOTES.md section 6).  Accumulation order differs from a
+// sequential fma chain (four products per instruction): parity with the PyTorch twin is within the tolerance the test states.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int TM, int TN, int K, bool AT>
 __device__ __forceinline__ void lgemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int m0, int n0,
                                       float (&acc)[TM][TN]) {
-    static_assert(TN == 2 || TN == 4, "tile widths are 2 or 4");
-    constexpr int H = TN / 2;
-    f32x2 c[TM][H];
+    static_assert(TN == 4 && (TM == 4 || TM == 2) && K % 16 == 0, "thread tiles are 4 x 4 or 2 x 4, K a multiple of 16");
+    const int lane = (int)threadIdx.x & 63, gk = lane >> 4, i = lane & 15;
+    const int mw = m0 - gk * TM;                                   // first row of the wave (lane >> 4 == ty & 3)
+    // the logical row this lane feeds as MFMA row i (D row i belongs to lane group i >> 2, register i & 3)
+    const bool a_on = TM == 4 || (i & 3) < 2;
+    const int a_row = TM == 4 ? mw + i : mw + 2 * (i >> 2) + (i & 1);
+    f32x4 c[4];
 #pragma unroll
-    for (int x = 0; x < TM; ++x)
+    for (int t = 0; t < 4; ++t) c[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int y = 0; y < H; ++y) c[x][y] = (f32x2){0.f, 0.f};
-    if constexpr (AT) {
-        for (int k = 0; k < K; k += 4) {
-            float av[TM][4];
+    for (int b = 0; b < K / 16; ++b) {
+        const int k0 = 16 * b + 4 * gk;
+        float av[4];
+        if constexpr (AT) {
+            ldvec<4>(A + a_row * lda + k0, av);
+        } else {
 #pragma unroll
-            for (int x = 0; x < TM; ++x) ldvec<4>(A + (m0 + x) * lda + k, av[x]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float bv[TN];
-                ldvec<TN>(B + (k + kk) * ldb + n0, bv);
-#pragma unroll
-                for (int x = 0; x < TM; ++x) {
-                    const f32x2 a2 = {av[x][kk], av[x][kk]};
-#pragma unroll
-                    for (int y = 0; y < H; ++y) c[x][y] = __builtin_elementwise_fma(a2, (f32x2){bv[2 * y], bv[2 * y + 1]}, c[x][y]);
-                }
-            }
+            for (int st = 0; st < 4; ++st) av[st] = A[(k0 + st) * lda + a_row];
         }
-    } else {
-#pragma unroll 4
-        for (int k = 0; k < K; ++k) {
-            float av[TM], bv[TN];
-            ldvec<TM>(A + k * lda + m0, av);
-            ldvec<TN>(B + k * ldb + n0, bv);
 #pragma unroll
-            for (int x = 0; x < TM; ++x) {
-                const f32x2 a2 = {av[x], av[x]};
+        for (int st = 0; st < 4; ++st) {
+            float bv[4];
+            ldvec<4>(B + (k0 + st) * ldb + n0, bv);
+            const float a = a_on ? av[st] : 0.f;
 #pragma unroll
-                for (int y = 0; y < H; ++y) c[x][y] = __builtin_elementwise_fma(a2, (f32x2){bv[2 * y], bv[2 * y + 1]}, c[x][y]);
-            }
+            for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[t], c[t], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int x = 0; x < TM; ++x)
+    for (int u = 0; u < TM; ++u)
 #pragma unroll
-        for (int y = 0; y < H; ++y) { acc[x][2 * y] = c[x][y].x; acc[x][2 * y + 1] = c[x][y].y; }
+        for (int v = 0; v < 4; ++v) acc[u][v] = c[v][u];
 }
 
 struct Lds {
