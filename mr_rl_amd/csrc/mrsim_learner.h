@@ -117,6 +117,24 @@ __device__ __forceinline__ void lgemm(const float* __restrict__ A, int lda, cons
         for (int v = 0; v < 4; ++v) acc[u][v] = c[v][u];
 }
 
+// sum over the 64 lanes of a wave (every lane active), result in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// b^t in double by repeated squaring (t >= 1): ~2 log2 t multiplications; the library pow() is thousands of cycles on the one
+// lane that needs it while 255 wait
+__device__ __forceinline__ double ipow(double b, int t) {
+    double r = 1.0;
+    for (unsigned e = (unsigned)t; e != 0u; e >>= 1) {
+        if (e & 1u) r *= b;
+        b *= b;
+    }
+    return r;
+}
+
 struct Lds {
     float P[kParams];          // the staged network pair (target, then online)
     float rstd[3][64], mean[3][64];
@@ -129,9 +147,17 @@ struct Lds {
     alignas(16) int sel[kMaxBatch];   // rows drawn in-kernel (read 16 bytes at a time by the duplicate check)
 };
 
+// parameters [p0, kParams) of `src` into L.P by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no VGPRs; the
+// image is lane-linear -- a wave-instruction fills 1 KiB at its first lane's address -- and every instruction of the copy is in
+// flight before the wait the next __syncthreads() brings).  As a load + ds_write loop the copy took one L2 round trip per pass.
+__device__ __forceinline__ void stage_range(Lds& L, const float* __restrict__ src, int p0, int tid) {
+    for (int p = p0 + tid * 4; p < kParams; p += kThreads * 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p),
+                                         (__attribute__((address_space(3))) void*)(&L.P[p]), 16, 0, 0);
+}
+
 __device__ __forceinline__ void stage_params(Lds& L, const float* __restrict__ src, const float* __restrict__ bn, float eps, int tid) {
-    for (int p = tid * 4; p < kParams; p += kThreads * 4)
-        *reinterpret_cast<float4*>(&L.P[p]) = *reinterpret_cast<const float4*>(src + p);
+    stage_range(L, src, 0, tid);
     for (int q = tid; q < 3 * 64; q += kThreads) {
         const int l = q >> 6, k = q & 63;
         L.mean[l][k] = bn[(l * 2 + 0) * 64 + k];
@@ -331,8 +357,8 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
     if (tid == 0) { L.loss[0] = 0.f; L.loss[1] = 0.f; }
     if (tid < 2) {      // Adam bias corrections of this update (the step counters live on the device: graph replays advance them)
         const int t = A.steps[tid] + 1;
-        L.bc[tid * 2 + 0] = (float)(1.0 - pow((double)A.beta1, (double)t));
-        L.bc[tid * 2 + 1] = (float)sqrt(1.0 - pow((double)A.beta2, (double)t));
+        L.bc[tid * 2 + 0] = (float)(1.0 - ipow((double)A.beta1, t));
+        L.bc[tid * 2 + 1] = (float)sqrt(1.0 - ipow((double)A.beta2, t));
     }
     // ------------------------------------------------------------------------------------------------ targets y
     stage_params(L, A.target, A.bn + 3 * 2 * 64, A.bn_eps, tid);
@@ -418,7 +444,9 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             for (int w = 0; w < 16; ++w) q += X3[w * 64 + tid];
             const float e = q - L.y[tile * kTile + tid];
             L.dq[tid] = 2.0f * e * invB;                                                    // d mean (y - q)^2 / dq
-            atomicAdd(&L.loss[0], e * e * invB);
+            const float le = wave_sum(e * e * invB);        // (tid < kTile is exactly wave 0: one writer instead of 64 LDS atomics)
+            const float sdq = wave_sum(2.0f * e * invB);    // output bias gradient
+            if (tid == 0) { L.loss[0] += le; A.grad[C_BO] = first ? sdq : A.grad[C_BO] + sdq; }
         }
         __syncthreads();
         {   // output layer and T2 / bt2 gradients; delta of hidden layer 2 in place of hc2
@@ -444,11 +472,6 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             for (int part = 0; part < 8; ++part) v += X3[2048 + (part * 32 + f) * 4 + q];
             const int p = q == 0 ? C_WO + f : q == 1 ? C_BT2 + f : C_T2 + f * 2 + (q - 2);
             A.grad[p] = first ? v : A.grad[p] + v;
-        }
-        if (tid == 128) {
-            float v = 0.f;
-            for (int i = 0; i < kTile; ++i) v += L.dq[i];
-            A.grad[C_BO] = first ? v : A.grad[C_BO] + v;
         }
         {   // dT1[f][k] = sum_i delta2[i][f] hc1[i][k]
             float g[2][4];
@@ -483,8 +506,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
     __syncthreads();
     LPROBE(5);   // critic Adam + soft update
     // ------------------------------------------------------------------------------------------------ actor step (against the UPDATED critic)
-    for (int p = C_W1 + tid * 4; p < kParams; p += kThreads * 4)
-        *reinterpret_cast<float4*>(&L.P[p]) = *reinterpret_cast<const float4*>(A.online + p);
+    stage_range(L, A.online, C_W1, tid);
     __syncthreads();
     LPROBE(6);   // updated critic re-staged
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -558,10 +580,14 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
         if (tid < kTile) {
             float q = L.P[C_BO], d0 = 0.f, d1 = 0.f;
             for (int w = 0; w < 16; ++w) { q += X0[(w * 64 + tid) * 3]; d0 += X0[(w * 64 + tid) * 3 + 1]; d1 += X0[(w * 64 + tid) * 3 + 2]; }
-            atomicAdd(&L.loss[1], -q * invB);
+            const float lq = wave_sum(-q * invB);
+            if (tid == 0) L.loss[1] += lq;
             const float t0 = L.th[tid * 2], t1 = L.th[tid * 2 + 1];                          // loss = -mean Q: dL/dz3 = -dQ/da' bound (1 - tanh^2) / B
-            L.dz3[tid * 2] = -d0 * invB * A.bound0 * (1.0f - t0 * t0);
-            L.dz3[tid * 2 + 1] = -d1 * invB * A.bound1 * (1.0f - t1 * t1);
+            const float g0 = -d0 * invB * A.bound0 * (1.0f - t0 * t0), g1 = -d1 * invB * A.bound1 * (1.0f - t1 * t1);
+            L.dz3[tid * 2] = g0;
+            L.dz3[tid * 2 + 1] = g1;
+            const float s0 = wave_sum(g0), s1 = wave_sum(g1);                               // output bias gradients
+            if (tid < 2) { const float v = tid ? s1 : s0; A.grad[A_B3 + tid] = first ? v : A.grad[A_B3 + tid] + v; }
         }
         __syncthreads();
         LPROBE(14);
@@ -590,11 +616,6 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             const float v = X4[(0 * 64 + k) * 5 + q] + X4[(1 * 64 + k) * 5 + q] + X4[(2 * 64 + k) * 5 + q] + X4[(3 * 64 + k) * 5 + q];
             const int p = q == 0 ? A_G2 + k : q == 1 ? A_BE2 + k : q == 2 ? A_B2 + k : A_W3 + (q - 3) * 64 + k;
             A.grad[p] = first ? v : A.grad[p] + v;
-        }
-        if (tid < 2) {
-            float v = 0.f;
-            for (int i = 0; i < kTile; ++i) v += L.dz3[i * 2 + tid];
-            A.grad[A_B3 + tid] = first ? v : A.grad[A_B3 + tid] + v;
         }
         {   // dW2[f][k] = sum_i dz2[i][f] h1[i][k]
             float g[4][4];

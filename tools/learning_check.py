@@ -16,9 +16,18 @@ def task_cfg():
                     init_low=(10.0, -1.0), init_high=(14.0, 1.0))
 
 
-def run(fused, episodes, updates, envs=4096, ou_sigma=10.0, seed=0):
+def run(fused, episodes, updates, envs=4096, ou_sigma=10.0, seed=0, learner_lib=None, host_sampler=False):
     env = MRVecEnv(envs, cfg=task_cfg(), seed=seed)
     agent = DDPG(env, seed=seed, obs_scale=[0.1] * 5, fused=bool(fused))
+    if learner_lib and fused:        # A/B of learner builds: mr_rl_amd/variants/libmrsim_<tag>.so
+        from mr_rl_amd import _lib
+        agent.fused._L = _lib.load(os.path.join(ROOT, "mr_rl_amd", "variants", f"libmrsim_{learner_lib}.so"))
+    if host_sampler and fused:       # experiment: the fused update on batches drawn by the host-side sampler of the ring
+        def burst(n=1):
+            for _ in range(n):
+                agent.fused.update(agent.buffer.sample_batch(64), n=1)
+            agent._updates += n
+        agent.update_graphed = burst
     agent.noise.sigma = ou_sigma
     return agent, agent.train_collected(episodes, updates_per_episode=updates, sample=4096)
 
@@ -30,8 +39,11 @@ if __name__ == "__main__":
     ap.add_argument("--updates", type=int, default=16)
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--ou-sigma", type=float, default=10.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--learner-lib", default=None)
+    ap.add_argument("--host-sampler", type=int, default=0)
     a = ap.parse_args()
-    agent, rets = run(a.fused, a.episodes, a.updates, a.envs, a.ou_sigma)
+    agent, rets = run(a.fused, a.episodes, a.updates, a.envs, a.ou_sigma, a.seed, a.learner_lib, bool(a.host_sampler))
     k = max(1, len(rets) // 10)
     print("mean return per tenth of the run:", [round(sum(rets[i:i + k]) / k, 1) for i in range(0, len(rets), k)])
     with torch.no_grad():
