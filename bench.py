@@ -732,7 +732,7 @@ def measure_learner(args, n_local, dev, seed, streams):
     ep = cfg.max_timesteps + 1
     # learner_cus = 1: the learner's launches on 8 compute units of their own (one per XCC), the collection on the other 248
     # (mr_rl_amd.partition) -- reported beside the shared-device rows
-    rows = [("f32", 8, 60, 0), ("bf16", 4, 150, 0), ("bf16", 4, 150, 1), ("bf16", 0, 150, 0)]
+    rows = [("f32", 8, 60, 0), ("bf16", 8, 150, 0), ("bf16", 8, 150, 1), ("bf16", 0, 150, 0)]
     if getattr(args, "no_partition_row", False):
         rows = [r for r in rows if r[3] == 0]
     for math, U, episodes, cus in rows:
