@@ -125,6 +125,13 @@ class RolloutCollector:
             self._prepared_version = env._params_version
         b, blk, row = self._where(k)
         free_set, free_blk = self._free_ev[b], (self._ret_free_ev[blk] if row == 0 else None)
+        # An event that has already completed orders nothing: asking (hipEventQuery, ~1 us) is cheaper than making every sub-shard
+        # stream wait for it (hipStreamWaitEvent, ~10 us of host time each -- a consumer that calls ready() / release() per episode
+        # otherwise pays more host time in waits than in launches: 118 instead of 144 G env-steps/s at 90 us per episode)
+        if free_set is not None and free_set.query():
+            free_set = self._free_ev[b] = None
+        if free_blk is not None and free_blk.query():
+            free_blk = None
         for s, ((first, n), st) in enumerate(zip(self.shards, self.streams)):
             if free_set is not None:
                 st.wait_event(free_set)         # the consumer has released this buffer set
@@ -179,7 +186,8 @@ class RolloutCollector:
         assert 0 <= k < self.episodes and k >= self.episodes - self.depth, "that episode's events were reused"
         cur = torch.cuda.current_stream(self.env.device)
         for ev in self._done_ev[k % self.depth]:
-            cur.wait_event(ev)
+            if not ev.query():                    # (a consumer that lags an episode behind has nothing to wait for)
+                cur.wait_event(ev)
         return k
 
     def ready(self, k=None):
