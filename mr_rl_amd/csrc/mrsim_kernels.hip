@@ -1166,7 +1166,7 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
         const int nz = noise_variant(p);
         const bool mis = p->mismatched != 0;
         const bool bf = (K.flags & kFActorBf16) != 0, bfs = (K.flags & kFActorBf16s) != 0;
-        const uint32_t kf = K.flags & ~kFOUReset;   // (read at run time by the specialised kernels)
+        const uint32_t kf = K.flags & ~(kFOUReset | kFStepBase);   // (both read at run time by the specialised kernels)
         if (kf == kFlDdpgActor) rc = launch_rollout_actor_fl<kFlDdpgActor, kActF32>(lc, nz, mis, K, S, ra, AC, handled);
         else if (kf == (kFlDdpgActor | kFActorBf16))
             rc = launch_rollout_actor_fl<kFlDdpgActor | kFActorBf16, kActBf16x3>(lc, nz, mis, K, S, ra, AC, handled);
@@ -1191,7 +1191,7 @@ static int rollout_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const
     } else if (p->integrator == MRSIM_INT_RK45) {
         const int nz = noise_variant(p);
         const bool mis = p->mismatched != 0;
-        switch (K.flags) {
+        switch (K.flags & ~kFStepBase) {   // (the device step base is read at run time by every kernel: step_words)
             case kFlDdpg: rc = launch_rollout_fl<kFlDdpg>(lc, nz, mis, K, S, ra, handled); break;
             case kFlMixed: rc = launch_rollout_fl<kFlMixed>(lc, nz, mis, K, S, ra, handled); break;
             case kFlDdpgSoa: rc = launch_rollout_fl<kFlDdpgSoa>(lc, nz, mis, K, S, ra, handled); break;

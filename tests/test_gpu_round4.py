@@ -721,3 +721,25 @@ def test_fused_learner_burst_equals_single_update_launches():
     assert a.steps.tolist() == b.steps.tolist() == [12, 12]
     for name in ("online", "target", "adam_m", "adam_v"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+@pytest.mark.parametrize("law", ["per_stage", "collapsed"])
+def test_rollout_with_a_device_step_base_takes_the_specialised_kernels_and_gives_the_same_bits(law):
+    """MrsimParams.step_base (the RNG step counter in HBM, what a captured hipGraph of launches needs) is read at run time by every
+    kernel: the flag-specialised rollout kernels serve it too, and the numbers are those of the host-side counter"""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    cfg = MRConfig(noise_var=1.0, auto_reset=True, noise_law=law)
+    n, T = 5000, 51
+    a, b = MRVecEnv(n, cfg=cfg, seed=13), MRVecEnv(n, cfg=cfg, seed=13)
+    a.reset(); b.reset()
+    a.rollout(7, want=("obs",)); b.rollout(7, want=("obs",))      # a non-zero step index to move into the device word
+    b.enable_device_step_base()
+    for rep in range(3):
+        oa = a.rollout(T, want=("obs", "rew", "done", "actions"), carry="f64")
+        ob = b.rollout(T, want=("obs", "rew", "done", "actions"), carry="f64")
+        b.advance_step_base(T); b.step_idx = 0                    # the base moves on the device, the offset stays 0 (as under a graph)
+        for k in ("obs", "rew", "done", "actions"):
+            assert torch.equal(oa[k], ob[k]), (rep, k)
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.aux, b.aux)
+    a.check_status(); b.check_status()
