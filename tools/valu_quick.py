@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Mean SQ_INSTS_VALU (or any one counter) per wave and env step of the fused rollout kernels in rocprofv3 --pmc output directories:
+python tools/valu_quick.py <dir> [<dir> ...]   (later half of the dispatches of every kernel / counter / grid; T = 51)"""
 import csv, glob, sys, collections
 for d in sys.argv[1:]:
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
