@@ -62,8 +62,12 @@ class ReplayBuffer:
         if B >= self.buffer_size:
             s, a, r, t, s2 = (x[-self.buffer_size:] for x in (s, a, r, t, s2))
             B = self.buffer_size
-        idx = (self.head + torch.arange(B, device=self.s.device)) % self.buffer_size
-        self.s[idx], self.a[idx], self.r[idx], self.t[idx], self.s2[idx] = s, a, r.float(), t.float(), s2
+        # contiguous slice copies (two segments when the batch wraps): no index tensors, five / ten copy kernels
+        first = min(B, self.buffer_size - self.head)
+        for dst, src in ((self.s, s), (self.a, a), (self.r, r), (self.t, t), (self.s2, s2)):
+            dst[self.head:self.head + first].copy_(src[:first])
+            if first < B:
+                dst[:B - first].copy_(src[first:])
         self.head = (self.head + B) % self.buffer_size
         self.count = min(self.count + B, self.buffer_size)
 
