@@ -120,7 +120,8 @@ class OUNoise:
         if mask is None:
             self.x_prev.zero_()
         else:
-            self.x_prev[mask] = 0.0
+            self.x_prev = torch.where(mask.reshape(-1, *([1] * (self.x_prev.dim() - 1))), torch.zeros_like(self.x_prev), self.x_prev)
+            # (no boolean-mask assignment: that form reads the mask back to size its index -- a host sync per step)
 
 
 def _uniform_(layer, lim, bias_too=True):
@@ -523,7 +524,9 @@ class DDPG:
         the observation the episode was reset to.  observe: optional callback(step, obs_fed_to_the_policy) (tests)."""
         env = self.env
         obs = env.reset().clone()
-        returns = []
+        # per-step (sum of the returns of the episodes that ended, their number) stay on the device: the loop never waits for the
+        # host (the reference reads every reward on the host, RL/MR_ddpg.py:278-311); read back once per log line and at the end
+        ended = []
         if self.device_actor is not None and env._actions_out is None:
             raise ValueError("DDPG(device_actor=True) needs MRVecEnv(track_actions=True): the replay ring stores the applied actions")
         for k in range(total_steps):
@@ -540,17 +543,23 @@ class DDPG:
             # with auto_reset the returned obs of a done env is the reset obs; the transition's s2 is final_obs
             s2 = torch.where(done[:, None], info["final_obs"], obs2) if env.cfg.auto_reset else obs2
             self.buffer.add(self._prep(obs), a, rew, done.float(), self._prep(s2))
-            if env.cfg.auto_reset and bool(done.any()):
-                returns.append(float(info["final_ret"][done].mean()))   # (one host read per episode end)
+            if env.cfg.auto_reset:
+                df = done.float()
+                ended.append(torch.stack(((info["final_ret"] * df).sum(), df.sum())))
                 if self.device_actor is None:
                     self.noise.reset(done)      # (the device actor zeroes its OU state in-kernel: reset_on_done)
             warming = warmup_quirk and self.buffer.size() < self.min_batch
             if not warming:
                 obs = obs2.clone()                  # :307 (skipped by the `continue` of :283-286 while the ring fills)
-            elif env.cfg.auto_reset and bool(done.any()):
+            elif env.cfg.auto_reset:
                 obs = torch.where(done[:, None], obs2, obs)   # `if done: break` -> the next episode's state = env.reset()
             for _ in range(updates_per_step):
                 self.update()
-            if log_every and (k + 1) % log_every == 0 and returns:
-                print(f"step {k + 1}: mean return of last finished episodes {returns[-1]:.2f}")
-        return returns
+            if log_every and (k + 1) % log_every == 0 and ended:
+                tail = torch.stack(ended[-log_every:]).sum(0).tolist()
+                if tail[1] > 0:
+                    print(f"step {k + 1}: mean return of the episodes finished in the last {log_every} steps {tail[0] / tail[1]:.2f}")
+        if not ended:
+            return []
+        rows = torch.stack(ended).cpu().tolist()
+        return [sm / cnt for sm, cnt in rows if cnt > 0]          # mean return of the episodes that ended at each such step
