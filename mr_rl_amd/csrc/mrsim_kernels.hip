@@ -1413,7 +1413,8 @@ int mrsim_replay_push(int64_t n_envs, int32_t T, const float* obs_T, const float
     learner::PushArgs A{obs_T, actions_T, rew_T, done_T, prev_obs, ring_s, ring_a, ring_r, ring_done, ring_s2, (long long)n_envs, T, n,
                         capacity, head, {obs_scale[0], obs_scale[1], obs_scale[2], obs_scale[3], obs_scale[4]},
                         (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)draw_counter, (uint32_t)(draw_counter >> 32)};
-    hipLaunchKernelGGL(learner::mr_replay_push_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+    hipLaunchKernelGGL(learner::mr_replay_push_kernel, dim3((n + learner::kPushThreads - 1) / learner::kPushThreads), dim3(learner::kPushThreads), 0,
+                       static_cast<hipStream_t>(stream), A);
     return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 

@@ -670,8 +670,11 @@ struct PushArgs {
     float scale[5];
     uint32_t seed_lo, seed_hi, ctr_lo, ctr_hi;
 };
-__global__ __launch_bounds__(256) void mr_replay_push_kernel(const PushArgs A) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
+// One wave per workgroup: every lane gathers from a different page of the [T][N][.] buffers (hundreds of MB), and 64 workgroups
+// spread the address translations over 64 compute units' TLBs instead of 16.
+constexpr int kPushThreads = 64;
+__global__ __launch_bounds__(kPushThreads) void mr_replay_push_kernel(const PushArgs A) {
+    const int q = blockIdx.x * kPushThreads + threadIdx.x;
     if (q >= A.n) return;
     uint32_t o[4];
     philox4x32_10((uint32_t)q, 0x52494E47u /* "RING" */, A.ctr_lo, A.ctr_hi, A.seed_lo, A.seed_hi, o);
@@ -707,21 +710,21 @@ __device__ __forceinline__ uint16_t bf16_rne_bits(float x) {
 }
 __global__ __launch_bounds__(256) void mr_actor_pack_kernel(const PackArgs A) {
     __shared__ float w1f[64 * 5], b1f[64], w2f[64 * 64], b2f[64];
+    __shared__ double g2s[64];
     const int tid = threadIdx.x;
     constexpr int H = 64;
-    // fold: y = gamma (W x + b - mean) / sqrt(var + eps) + beta == W' x + b'   (double, rounded once)
+    // fold: y = gamma (W x + b - mean) / sqrt(var + eps) + beta == W' x + b'   (double, rounded once; the per-feature gains are
+    // formed once -- a double divide and square root per ELEMENT of W2 made this kernel 14 us long)
     for (int f = tid; f < H; f += 256) {
         const double g1 = (double)A.params[A_G1 + f] / sqrt((double)A.bn[(0 * 2 + 1) * 64 + f] + (double)A.eps);
         for (int k = 0; k < 5; ++k) w1f[f * 5 + k] = (float)((double)A.params[A_W1 + f * 5 + k] * g1);
         b1f[f] = (float)(((double)A.params[A_B1 + f] - (double)A.bn[(0 * 2 + 0) * 64 + f]) * g1 + (double)A.params[A_BE1 + f]);
         const double g2 = (double)A.params[A_G2 + f] / sqrt((double)A.bn[(1 * 2 + 1) * 64 + f] + (double)A.eps);
         b2f[f] = (float)(((double)A.params[A_B2 + f] - (double)A.bn[(1 * 2 + 0) * 64 + f]) * g2 + (double)A.params[A_BE2 + f]);
+        g2s[f] = g2;
     }
-    for (int o = tid; o < H * H; o += 256) {
-        const int f = o >> 6;
-        const double g2 = (double)A.params[A_G2 + f] / sqrt((double)A.bn[(1 * 2 + 1) * 64 + f] + (double)A.eps);
-        w2f[o] = (float)((double)A.params[A_W2 + o] * g2);
-    }
+    __syncthreads();
+    for (int o = tid; o < H * H; o += 256) w2f[o] = (float)((double)A.params[A_W2 + o] * g2s[o >> 6]);
     for (int o = tid; o < kActBlobFloats; o += 256) A.blob[o] = 0.0f;
     __syncthreads();
     if (tid < 128) {

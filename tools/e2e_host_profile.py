@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the HOST time of DDPG.train_collected goes (cProfile over the episode loop; the device is idle-waiting whenever the host
-is behind): python tools/e2e_host_profile.py [math] [U] [episodes] [streams]"""
+is behind): python tools/e2e_host_profile.py [math] [U] [episodes] [streams] [learner_cus] [envs]"""
 import cProfile, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,7 +15,8 @@ if len(sys.argv) > 5:
     kw["learner_cus"] = int(sys.argv[5])
 dev = torch.device("cuda", 0)
 cfg = MRConfig(noise_var=1.0, auto_reset=True, seed=7, noise_law="collapsed")
-env = MRVecEnv(262144, cfg=cfg, device=dev, seed=7)
+N = int(sys.argv[6]) if len(sys.argv) > 6 else 262144
+env = MRVecEnv(N, cfg=cfg, device=dev, seed=7)
 agent = DDPG(env, seed=7, obs_scale=[0.01] * 5, fused=True)
 agent.train_collected(30, updates_per_episode=U, sample=4096, streams=streams, math=math, **kw)   # warm
 torch.cuda.synchronize()
