@@ -41,10 +41,15 @@ def owner(ranges, line):
 
 
 def main():
-    # usage: isa_budget.py [per_stage|collapsed] [nominal|mismatched]
+    # usage: isa_budget.py [per_stage|collapsed] [nominal|mismatched] [actor math: f32|bf16x3|bf16 -> the actor-in-the-loop kernel]
     law = sys.argv[1] if len(sys.argv) > 1 else "per_stage"
     mis = (sys.argv[2] if len(sys.argv) > 2 else "nominal") == "mismatched"
     KERNEL = KERNEL_FMT % (4 if law == "collapsed" else 2, 1 if mis else 0)
+    actor = sys.argv[3] if len(sys.argv) > 3 else None
+    if actor is not None:
+        fl, act = {"f32": (7011461, 1), "bf16x3": (40565893, 2), "bf16": (74120325, 3)}[actor]
+        KERNEL = ("_ZN5mrsim26mr_rollout_actor_fl_kernelILb1ELi%dELb%dELj%dELi%dEEEvNS_7KParamsENS_9StateArgsENS_11RolloutArgsENS_9ActorArgsE"
+                  % (4 if law == "collapsed" else 2, 1 if mis else 0, fl, act))
     tmp = tempfile.mkdtemp(prefix="isa_budget_")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
            "-fno-slp-vectorize", "-gline-tables-only", "-DMRSIM_BUDGET_BUILD=1", "-shared", "-I../../include",
@@ -55,6 +60,7 @@ def main():
     body = asm[asm.index(KERNEL + ":"):]
     body = body[:body.index(".Lfunc_end")]
     ranges = {"mrsim_device.h": function_ranges(os.path.join(CSRC, "mrsim_device.h")),
+              "mrsim_actor.h": function_ranges(os.path.join(CSRC, "mrsim_actor.h")),
               "mrsim_kernels.hip": function_ranges(os.path.join(CSRC, "mrsim_kernels.hip"))}
     # the time loop = the blocks the compiler marks "in Loop:"
     cur, in_loop = ("?", 0), False
