@@ -19,6 +19,20 @@ import ctypes as C
 from . import _lib
 
 
+def partition_masks(compute_units, xccs, per_xcc):
+    """(learner mask, collection mask) as lists of 32-bit words: the learner gets bits 0 .. per_xcc * xccs - 1 (mask bit i is a unit
+    of XCC i % xccs, so that is per_xcc units of every XCC), the collection every other unit.  Both sides keep a unit in every XCC."""
+    compute_units, xccs, per_xcc = int(compute_units), int(xccs), int(per_xcc)
+    if per_xcc < 1 or per_xcc * xccs * 2 > compute_units:
+        raise ValueError("per_xcc must leave the collection at least half of the device")
+    n_learner = per_xcc * xccs
+    words = (compute_units + 31) // 32
+    learner, collect = [0] * words, [0] * words
+    for b in range(compute_units):
+        (learner if b < n_learner else collect)[b // 32] |= 1 << (b % 32)
+    return learner, collect
+
+
 class CuPartition:
     def __init__(self, device="cuda", per_xcc=1, collection_streams=8):
         import torch
@@ -31,14 +45,8 @@ class CuPartition:
         cus, xccs = C.c_int32(0), C.c_int32(0)
         _lib.check(self._L.mrsim_device_cu_layout(self.index, C.byref(cus), C.byref(xccs)), "mrsim_device_cu_layout")
         self.compute_units, self.xccs = int(cus.value), int(xccs.value)
-        per_xcc = int(per_xcc)
-        if per_xcc < 1 or per_xcc * self.xccs * 2 > self.compute_units:
-            raise ValueError("per_xcc must leave the collection at least half of the device")
-        self.learner_units = per_xcc * self.xccs
-        words = (self.compute_units + 31) // 32
-        learner, collect = [0] * words, [0] * words
-        for b in range(self.compute_units):
-            (learner if b < self.learner_units else collect)[b // 32] |= 1 << (b % 32)    # bits 0 .. per_xcc * xccs - 1: per_xcc units per XCC
+        learner, collect = partition_masks(self.compute_units, self.xccs, per_xcc)
+        self.learner_units = int(per_xcc) * self.xccs
         self.learner_mask, self.collection_mask = learner, collect
         self._handles = []
         self.learner_stream = self._stream(learner)

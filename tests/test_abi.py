@@ -194,3 +194,20 @@ def test_cu_mask_stream_entry_points_validate_their_arguments():
     assert rc in (_lib.ENODEVICE, _lib.OK)
     if rc == _lib.OK:
         assert L.mrsim_stream_destroy(h) == _lib.OK
+
+
+def test_partition_masks_keep_a_unit_of_every_xcc_on_both_sides():
+    """mr_rl_amd.partition.partition_masks (host logic of CuPartition): complementary masks; mask bit i is a unit of XCC i % xccs"""
+    from mr_rl_amd.partition import partition_masks
+    for per_xcc in (1, 2, 4):
+        learner, collect = partition_masks(256, 8, per_xcc)
+        assert len(learner) == len(collect) == 8
+        bits = lambda m: {32 * w + b for w in range(len(m)) for b in range(32) if (m[w] >> b) & 1}  # noqa: E731
+        L, K = bits(learner), bits(collect)
+        assert L | K == set(range(256)) and not (L & K) and len(L) == 8 * per_xcc
+        for x in range(8):
+            assert sum(1 for b in L if b % 8 == x) == per_xcc and sum(1 for b in K if b % 8 == x) == 32 - per_xcc
+    with pytest.raises(ValueError):
+        partition_masks(256, 8, 0)
+    with pytest.raises(ValueError):
+        partition_masks(256, 8, 17)
