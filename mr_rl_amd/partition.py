@@ -49,8 +49,12 @@ class CuPartition:
         self.learner_units = int(per_xcc) * self.xccs
         self.learner_mask, self.collection_mask = learner, collect
         self._handles = []
-        self.learner_stream = self._stream(learner)
-        self.collection_streams = [self._stream(collect) for _ in range(int(collection_streams))]
+        try:
+            self.learner_stream = self._stream(learner)
+            self.collection_streams = [self._stream(collect) for _ in range(int(collection_streams))]
+        except Exception:
+            self.close()                      # (no half-built partition: the streams created so far are destroyed)
+            raise
 
     def _stream(self, mask):
         import torch
