@@ -109,12 +109,13 @@ def parse(argv=None):
     ap.add_argument("--obs-layout", choices=["aos", "soa"], default="aos")
     ap.add_argument("--noise-math", choices=["fast", "spec"], default="fast")
     ap.add_argument("--sigma", type=float, default=1.0)
-    ap.add_argument("--noise-law", choices=["collapsed", "per_stage"], default="collapsed",
-                    help="where the normals of an RK45 step enter (include/mrsim.h, MRSIM_LAW_*): per_stage = one draw per RHS "
-                         "evaluation as MR_simulator.py:73-83 (the library's default and parity mode); collapsed = the weighted stage "
-                         "sums drawn directly from their joint Gaussian -- the same distribution (tests/test_noise_law_cpu.py), element-"
-                         "wise parity against the oracle's restatement of the same law (tests/test_gpu_round4.py).  The line reports "
-                         "the other law beside the headline (`other_noise_law`)")
+    ap.add_argument("--noise-law", choices=["collapsed", "per_stage"], default=None,
+                    help="where the normals of an RK45 step enter (include/mrsim.h, MRSIM_LAW_*).  Default: the LIBRARY's default "
+                         "(mrsim_default_params / MRConfig: collapsed = the weighted stage sums drawn directly from their joint "
+                         "Gaussian; the law of MR_simulator.py:73-83's per-evaluation noise, pinned against the reference's own "
+                         "samples -- tests/increments.py -- and element-wise against the oracle's restatement).  per_stage = one draw "
+                         "per RHS evaluation in the reference's order.  The line reports the other law beside the headline "
+                         "(`other_noise_law`)")
     ap.add_argument("--no-other-law", action="store_true", help="skip the leg that measures the other noise law")
     ap.add_argument("--mismatched", action="store_true", help="non-default: the reference's is_mismatched=True law")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,6 +133,8 @@ def parse(argv=None):
     ap.add_argument("--no-power", action="store_true", help="skip the 1.5 s package-power leg (hwmon sysfs)")
     ap.add_argument("--no-actor-leg", action="store_true", help="skip the actor-in-the-loop collection measurement")
     ap.add_argument("--no-learner-leg", action="store_true", help="skip the DDPG learner measurement (updates/s, end-to-end training rate)")
+    ap.add_argument("--no-facade-leg", action="store_true", help="skip the single-env MR_Env.step() drop-in measurement")
+    ap.add_argument("--no-streaming-point", action="store_true", help="skip the N = 2 097 152 single-GPU streaming point (SURVEY H4)")
     ap.add_argument("--no-partition-row", action="store_true",
                     help="learner leg without its compute-unit-partition row (rocprofv3's kernel trace of ROCm 7.2 crashes at exit "
                          "when the process has created CU-masked streams)")
@@ -856,6 +859,169 @@ def measure_other_law(args, cfg, n_local, env_id0, world, dev, seed, streams, go
     return out
 
 
+def measure_facade(seed, episodes=40):
+    """The literal drop-in call: mr_rl_amd.MR_Env.step() for ONE env, once per Python loop iteration, as utils.run_sim
+    (utils.py:51-54) and the DDPG loop (RL/MR_ddpg.py:270-278) call the reference's MR_env.MR_Env.step (MR_env.py:70-98).
+    One launch + one stream wait per step on a pinned host record (mr_rl_amd/env.py).  `value` includes the reset of every
+    51-step episode (the DDPG loop's shape); `phases_us` splits a step into the launch call, the wait and the Python around
+    them; the reference's own rate is quoted from the committed measurement (the reference never travels to the GPU box)."""
+    import ctypes as C
+    from mr_rl_amd import MR_Env, _lib
+    env = MR_Env(seed=seed)
+    env.reset()
+    a = [5.0, 1.0]
+    for _ in range(500):
+        env.step(a)
+    n = 0
+    t0 = time.perf_counter()
+    for _ in range(episodes):
+        env.reset()
+        for _ in range(51):
+            env.step(a)
+            n += 1
+    el = time.perf_counter() - t0
+    # run_sim's shape: one reset, then steps whatever `done` says
+    env.reset()
+    t0 = time.perf_counter()
+    for _ in range(1000):
+        env.step(a)
+    el_rs = time.perf_counter() - t0
+    # where a step goes: the same two C calls the facade makes, timed apart
+    L = env._L
+    t_launch = t_wait = 0.0
+    for k in range(500):
+        t1 = time.perf_counter()
+        L.mrsim_step(env._pp, 1, env.env_id, C.byref(env._st), C.byref(env._io), env.seed_value, env.step_idx + k, None)
+        t2 = time.perf_counter()
+        L.mrsim_stream_synchronize(None)
+        t3 = time.perf_counter()
+        t_launch += t2 - t1; t_wait += t3 - t2
+    env.step_idx += 500
+    out = {"what": "mr_rl_amd.MR_Env.step(action) for one env, one call per Python iteration (the drop-in for MR_env.py:70-98): one "
+                   "launch + one wait per step on a pinned host record, no copy calls",
+           "value": n / el, "unit": "MR_Env.step calls/s (one env; the reset of every 51-step episode included)",
+           "us_per_step": round(el / n * 1e6, 2), "steps": n,
+           "run_sim_shape": {"value": 1000 / el_rs, "us_per_step": round(el_rs / 1000 * 1e6, 2),
+                             "what": "1000 consecutive steps without resets (utils.run_sim ignores done)"},
+           "phases_us": {"mrsim_step_call": round(t_launch / 500 * 1e6, 2), "mrsim_stream_synchronize": round(t_wait / 500 * 1e6, 2),
+                         "python_around_them": round(el_rs / 1000 * 1e6 - (t_launch + t_wait) / 500 * 1e6, 2)}}
+    env.close()
+    f = newest_profile("ref_python_baseline.json")
+    if f is not None:
+        try:
+            ref = json.load(open(f))
+            out["reference_python"] = {"quoted_from": os.path.relpath(f, ROOT), "record": ref}
+        except Exception:
+            pass
+    return out
+
+
+def measure_streaming_point(args, cfg, dev, seed, n=2097152, episodes=60):
+    """SURVEY H4's streaming point: N = 2 097 152 envs on ONE GPU (BASELINE config 5's total; 3.7 GB of transitions per 51-step
+    launch, far beyond the 256 MB Infinity Cache): the fused rollout under both noise laws (one launch per episode on one stream,
+    a HIP event pair on every dispatch) and the one-launch-per-step kernel, each against the HBM peak on the bytes it must move."""
+    import copy
+    import torch
+    from mr_rl_amd import MRVecEnv
+    from mr_rl_amd._lib import EventPair
+    ep = cfg.max_timesteps + 1
+    out = {"what": "N = 2 097 152 envs on one GPU (the size at which nothing fits the Infinity Cache): kernel durations from HIP events "
+                   "on the dispatches, bytes = the minimal-traffic model N (33 T + 80) for the fused rollout (the PMC passes at N = 262 144 "
+                   "measured 1.01 x it; profiles/rNN/pmc_traffic_2m.json holds this size's own counters when collected), SURVEY 8(d)'s 97 B "
+                   "per env-step for the step kernel", "envs": n, "rollout": {}}
+    for law in (args.noise_law, "per_stage" if args.noise_law == "collapsed" else "collapsed"):
+        c2 = copy.copy(cfg)
+        c2.noise_law = law
+        reg = make_region(args, c2, n, 0, 1, dev, seed, 1, T=ep)
+        pool, used = [EventPair() for _ in range(episodes)], []
+        reg.run(40 * ep)
+        el, _ = reg.timed(episodes * ep, pool, used)
+        reg.col.check_status()
+        avg_us, med_us = stats_us([e.elapsed_ms() for e in used])
+        for e in pool:
+            e.close()
+        moved = modelled_traffic(n, ep)
+        gbs = moved / (avg_us * 1e-6) / 1e9
+        out["rollout"][law] = {"value": n * episodes * ep / el, "unit": "env-steps/s", "avg_kernel_us": round(avg_us, 2),
+                               "median_kernel_us": round(med_us, 2), "bytes_per_launch": moved,
+                               "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(gbs / HBM_PEAK_GBS, 4)},
+                               "in_kernel_env_steps_per_s": n * ep / (avg_us * 1e-6)}
+        del reg
+        torch.cuda.empty_cache()
+    env = MRVecEnv(n, cfg=cfg, device=dev, seed=seed)
+    env.reset()
+    act = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    for _ in range(30):
+        env.step(env.random_policy(out=act))
+    ms = [env.step_timed(env.random_policy(out=act)) for _ in range(102)]
+    avg_us, med_us = stats_us(ms)
+    env.check_status()
+    gbs = n * ALGO_BYTES_PER_ENV_STEP / (avg_us * 1e-6) / 1e9
+    out["step_kernel"] = {"avg_kernel_us": round(avg_us, 2), "median_kernel_us": round(med_us, 2),
+                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                          "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(gbs / HBM_PEAK_GBS, 4)},
+                          "in_kernel_env_steps_per_s": n / (avg_us * 1e-6)}
+    del env, act
+    torch.cuda.empty_cache()
+    return out
+
+
+def verify_ranks(args, cfg, world, rank, dev, seed, n_local, probe_envs=4096):
+    """Self-verification of an N > 1 run, inside the record: (1) what the process group says its size is, (2) every rank's device
+    identity (PCI address, UUID, name, host) gathered with all_gather_object, (3) a data check through the SAME backend the returns
+    travel on: every rank runs one episode of the first `probe_envs` envs of ITS shard (global env ids env_id0 ..) and contributes
+    {rank, env_id0, sum x, sum y, sum of returns} to an all_gather_into_tensor; rank 0 recomputes every shard's probe itself -- the
+    RNG is keyed by the global env id, so the values must agree bit for bit -- and says whether they did."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from mr_rl_amd import MRVecEnv
+    from mr_rl_amd.dist import shard_of
+
+    def probe(env_id0):
+        env = MRVecEnv(probe_envs, cfg=cfg, device=dev, seed=seed, env_id0=env_id0)
+        env.reset()
+        env.rollout(cfg.max_timesteps + 1, want=())
+        v = torch.stack([env.pos[:, 0].sum(), env.pos[:, 1].sum(), env.final_ret.double().sum()])
+        env.check_status()
+        return v
+
+    env_id0, _ = shard_of(n_local * world, rank, world)
+    mine = torch.cat([torch.tensor([float(rank), float(env_id0)], dtype=torch.float64, device=dev), probe(env_id0)])
+    pr = torch.cuda.get_device_properties(dev)
+    ident = {"rank": rank, "host": socket.gethostname(), "device_index": dev.index, "name": pr.name,
+             "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+             "uuid": str(getattr(pr, "uuid", "")), "pid": os.getpid()}
+    if world > 1:
+        every = torch.zeros((world, 5), dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_gather_into_tensor(every, mine if args.dist_backend == "nccl" else mine.cpu())
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    else:
+        every, idents = mine.unsqueeze(0), [ident]
+    if rank != 0:
+        return None
+    every = every.cpu()
+    ok, rows = True, []
+    for r in range(world):
+        e0, _ = shard_of(n_local * world, r, world)
+        want = probe(e0).cpu() if r != 0 else mine[2:].cpu()
+        same = bool(int(every[r, 0]) == r and int(every[r, 1]) == e0 and torch.equal(every[r, 2:], want))
+        ok = ok and same
+        rows.append({"rank": r, "env_id0": int(every[r, 1]), "probe_sum_x": float(every[r, 2]), "probe_sum_y": float(every[r, 3]),
+                     "probe_sum_returns": float(every[r, 4]), "equals_rank0_recomputation": same})
+    distinct = len({(d["host"], d["pci"], d["uuid"]) for d in idents})
+    return {"world_size_from_process_group": dist.get_world_size() if (world > 1 or dist.is_initialized()) else 1,
+            "backend": (dist.get_backend() if (world > 1 or dist.is_initialized()) else "none"),
+            "devices": idents, "distinct_devices": distinct, "one_device_per_rank": bool(distinct == world or args.share_gpu),
+            "probe": {"what": "%d envs of every rank's shard, one episode, sums of final positions and returns gathered with "
+                              "all_gather_into_tensor over the run's backend and recomputed on rank 0 from the global env ids" % probe_envs,
+                      "per_rank": rows, "all_equal": ok}}
+
+
+
 def stats_us(ms):
     ms = sorted(ms)
     return sum(ms) / len(ms) * 1e3, ms[len(ms) // 2] * 1e3
@@ -866,6 +1032,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))
     ensure_built()
+    if args.noise_law is None:   # the headline runs whatever law a user of the library gets without asking
+        from mr_rl_amd import MRConfig as _C
+        args.noise_law = _C().noise_law
+        args.noise_law_is_library_default = True
+    else:
+        from mr_rl_amd import MRConfig as _C
+        args.noise_law_is_library_default = args.noise_law == _C().noise_law
     # The contract is ONE JSON line on stdout.  Native libraries write to file descriptor 1 as well (RCCL prints a five-line
     # version banner there when its first communicator comes up, gloo announces its connections): from here on fd 1 is
     # stderr, and the JSON line goes to the saved descriptor at the very end.
@@ -992,15 +1165,6 @@ def main():
     # clock settle (tools/clock_ramp_probe.py: ~35 ms of load after idle), independent of the W the caller asks for
     trace("env ready; settle phase: %d episodes" % args.settle_episodes)
     run(args.settle_episodes * ep)
-    short_region = K <= 4 * ep
-    if short_region:
-        # A timed region of a few launch groups (the driver's --steps 20) is mostly host time, and right behind hundreds of
-        # queued launches the HIP runtime is still retiring them: the next launches then cost 25 - 100 us instead of 13 - 22
-        # (tools/enqueue_profile.py).  Drain the settle phase, give the runtime 2 ms, and put the load back on for 60 episodes
-        # (7 ms) so that the region starts behind a SHORT queue with the chip still busy.
-        torch.cuda.synchronize(dev)
-        time.sleep(2e-3)
-        run(60 * ep)
     trace("settle issued; warm-up %d steps" % W)
     run(W)
     barrier()
@@ -1147,6 +1311,21 @@ def main():
         learner_leg = measure_learner(args, n_local, dev, seed, streams)
         trace("learner leg done")
 
+    facade = None
+    if rank == 0 and world == 1 and not args.no_facade_leg and not pmc:
+        facade = measure_facade(seed)
+        trace("facade leg done")
+
+    streaming = None
+    if rank == 0 and world == 1 and args.mode == "rollout" and args.workload == "ddpg" and not args.no_streaming_point and not pmc:
+        streaming = measure_streaming_point(args, cfg, dev, seed)
+        trace("streaming point done")
+
+    rank_check = None
+    if world > 1 or os.environ.get("MRSIM_BENCH_FORCE_DIST"):
+        rank_check = verify_ranks(args, cfg, world, rank, dev, seed, n_local)
+        trace("rank verification done")
+
     power = None
     if rank == 0 and world == 1 and args.mode == "rollout" and not args.no_power and not pmc:
         power = measure_power(reg, dev, total)
@@ -1160,7 +1339,8 @@ def main():
                               "device, sigma=%g, integrator=reference(RK45), reward+done on device, auto-reset, all "
                               "transitions written to HBM" % args.sigma,
                   "trajectory_set": args.workload, "mode": args.mode, "envs_per_gpu": n_local, "total_envs": total, "obs_layout": args.obs_layout,
-                  "noise_math": args.noise_math, "noise_law": args.noise_law, "sigma": args.sigma, "seed": seed,
+                  "noise_math": args.noise_math, "noise_law": args.noise_law,
+                  "noise_law_is_library_default": bool(args.noise_law_is_library_default), "sigma": args.sigma, "seed": seed,
                   "is_mismatched": bool(args.mismatched),
                   "mean_episode_return": mean_ret,
                   "ranks": dist.get_world_size() if world > 1 else 1,
@@ -1182,12 +1362,9 @@ def main():
         out["per_rank_value"] = [n_local * K / max(s_, 1e-12) for s_ in per_rank_s]
         if region_phases is not None:
             out["timed_region_phases_us"] = region_phases  # rank 0's wall time of the K-step region, by phase
-        if short_region:
-            #  said in the record, not only in a comment: a K this short is ONE launch group per stream, so `value` is
-            # a host-enqueue figure; the kernel's rate is `sustained`
-            out["short_region_preconditioning"] = ("K <= 4 episodes: the settle phase was drained, the host slept 2 ms and 60 "
-                                                   "untimed episodes were re-issued before the region; `value` of such a region "
-                                                   "is host-launch-bound -- see `sustained` for the kernel's rate")
+        if K < 4 * ep:
+            out["short_region_note"] = ("K < 4 episodes: the timed region is one or two launch groups per stream and its `value` is "
+                                        "host-launch-bound (nothing is done to precondition it); `sustained` is the kernel's rate")
         if sustained is not None:
             out["sustained"] = sustained
         if rmse is not None:
@@ -1204,6 +1381,12 @@ def main():
             out["learner"] = learner_leg
         if power is not None:
             out["power"] = power
+        if facade is not None:
+            out["facade"] = facade
+        if streaming is not None:
+            out["streaming_point"] = streaming
+        if rank_check is not None:
+            out["rank_verification"] = rank_check
         if pmc:
             out["note"] = "run under rocprofv3 counter collection: kernels are serialised, timings are not representative"
         sys.stdout.flush()

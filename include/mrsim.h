@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MRSIM_ABI_VERSION 4
+#define MRSIM_ABI_VERSION 5
 
 enum {
     MRSIM_OK = 0,
@@ -58,15 +58,21 @@ enum { MRSIM_OBS_AOS = 0 /* [N][5] */, MRSIM_OBS_SOA = 1 /* [5][N] */ };
 /* FAST: hardware v_log/v_sqrt/v_sin/v_cos (normals within ~1e-6 of SPEC).  SPEC: the operation-by-
  * operation fp32 definition shared with the CPU oracle -- normals are bit-identical to the oracle's. */
 enum { MRSIM_NOISE_FAST = 0, MRSIM_NOISE_SPEC = 1 };
-/* Where the normals of an RK45 env step enter (ABI 4).
- * PER_STAGE (default, the parity mode): a fresh N(0, sigma) at every RHS evaluation, in the reference's order
- *   (MR_simulator.py:73-83; 8 evaluations per env step: stages K1..K5, f_new, and the two of the next RK45 constructor).
- * COLLAPSED (opt-in): the stage normals of one rk_step attempt reach a result only through the B-weighted sum (position)
- *   and the E-weighted sum (error estimate); those two are jointly Gaussian with the tableau's fixed covariance and are
- *   drawn directly (2 normals per noise component instead of 4; f_new and the constructor keep their own draws).  Every
- *   quantity a step returns or carries has the same distribution as under PER_STAGE -- tested on the CPU oracle over 1e6
- *   steps per configuration, tests/test_noise_law_cpu.py -- but not the same numbers for a given seed.  RK45 integrator
- *   only (the fixed-step modes ignore it); 2 Philox calls + 2 Box-Muller pairs per env step instead of 3 + 5. */
+/* Where the normals of an RK45 env step enter (ABI 4; the default changed in ABI 5).  The reference draws from NumPy's global
+ * MT19937 stream, which no counter-based generator reproduces: at sigma > 0 either law matches the reference in DISTRIBUTION
+ * (and the CPU oracle element for element on equal seeds), neither number for number.
+ * COLLAPSED (default since ABI 5): the stage normals of one rk_step attempt reach a result only through the B-weighted sum
+ *   (position) and the E-weighted sum (error estimate); those two are jointly Gaussian with the tableau's fixed covariance
+ *   and are drawn directly (2 normals per noise component instead of 4; f_new and the constructor keep their own draws).
+ *   Every quantity a step returns or carries has the law it has under PER_STAGE and in the reference: pinned against
+ *   statistics of the reference's own Simulator.step (tests/golden/ref_increments.npz: 1e6 env steps per model law far from
+ *   the origin, 1e6 where the first attempt's error_norm is about 1, 4e5 per start where every step is split into 20-50
+ *   attempts; increments at |std ratio - 1| < 0.005 + KS, attempts per step by chi-square; CPU oracle and kernels) and
+ *   against the per-stage oracle over 1e6 steps x 8 configurations (tests/test_noise_law_cpu.py).  RK45 integrator only
+ *   (the fixed-step modes ignore it); 2 Philox calls + 2 Box-Muller pairs per env step instead of 3 + 5.
+ * PER_STAGE: a fresh N(0, sigma) at every RHS evaluation, in the reference's order (MR_simulator.py:73-83; 8 evaluations
+ *   per env step: stages K1..K5, f_new, and the two of the next RK45 constructor) -- the layout the oracle's tape replays
+ *   of the reference's own np.random.normal draws use (tests/golden/ref_noise.npz); about 1.25 x the instructions. */
 enum { MRSIM_LAW_PER_STAGE = 0, MRSIM_LAW_COLLAPSED = 1 };
 
 /* Tunables of the reference path, with the place each one lives in the reference. */
@@ -100,7 +106,7 @@ typedef struct MrsimParams {
                            /*   behind = params.mismatched.  1: a fresh MR_Env per episode (utils.run_sim,       */
                            /*   utils.py:46): the constructor runs under the nominal law.  Same thing unless     */
                            /*   mismatched != 0.                                                                 */
-    int32_t noise_law;     /* MRSIM_LAW_* (ABI 4; 0 = PER_STAGE = the reference's per-evaluation noise)          */
+    int32_t noise_law;     /* MRSIM_LAW_* (mrsim_default_params: COLLAPSED; 0 = PER_STAGE)                       */
     const uint64_t* step_base; /* optional DEVICE word added to every step_idx argument.  Kernel      */
                            /*   arguments are frozen inside a captured hipGraph; keeping the base in */
                            /*   HBM (advanced by mrsim_advance_step_base) lets each replay draw new  */
@@ -206,6 +212,10 @@ typedef struct MrsimStepIO {
     const MrsimActor* actor; /* optional (HOST pointer; ABI 3): the policy source is the      */
                              /*   in-kernel actor on the env's current observation; actions   */
                              /*   must then be NULL and the integrator RK45                   */
+    int32_t* attempts;       /* optional [n] (ABI 5): rk_step attempts this env step took =   */
+                             /*   (integrator.nfev after - before) / 6 of the RK45 object     */
+                             /*   that integrates it (MR_simulator.py:42-43); fixed-step      */
+                             /*   modes: substeps                                             */
 } MrsimStepIO;
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -291,12 +301,6 @@ int mrsim_reset(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimSt
 int mrsim_step(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
                const MrsimStepIO* io, uint64_t seed, uint64_t step_idx, void* stream);
 
-/* Same launch bracketed by HIP events on `stream`; *kernel_ms_host = duration of the step
- * kernel alone (synchronises the stream; measurement aid for bench.py, not a product path). */
-int mrsim_step_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
-                     const MrsimStepIO* io, uint64_t seed, uint64_t step_idx, void* stream,
-                     float* kernel_ms_host);
-
 /* Uniform random policy (the DDPG warm-up / exploration workload, RL/MR_ddpg.py:277):
  * actions[n][2] ~ U[act_low, act_high). */
 int mrsim_random_policy(const MrsimParams* p, int64_t n, uint32_t env_id0, float* actions,
@@ -349,27 +353,6 @@ typedef struct MrsimRolloutIO {
 int mrsim_rollout(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
                   const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream);
 
-/* mrsim_rollout with HIP events attached to the dispatch: *kernel_ms_host = kernel duration
- * (synchronises the stream; measurement aid for bench.py). */
-int mrsim_rollout_timed(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
-                        const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream,
-                        float* kernel_ms_host);
-
-/* Non-blocking measurement aids: the same launches with two caller-owned HIP events attached to the dispatch
- * (hipExtLaunchKernelGGL), nothing synchronised.  Lets bench.py read each kernel's duration INSIDE its timed
- * region, on the stream the kernel runs on, without perturbing it.  Events come from mrsim_event_create (thin
- * wrappers over hipEventCreate / hipEventElapsedTime / hipEventDestroy so a ctypes caller needs no second HIP
- * binding); mrsim_event_elapsed_ms synchronises on `stop`. */
-int mrsim_event_create(void** event_out);
-int mrsim_event_destroy(void* event);
-int mrsim_event_elapsed_ms(void* start_event, void* stop_event, float* ms_host);
-int mrsim_rollout_events(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
-                         const MrsimRolloutIO* io, uint64_t seed, uint64_t step_idx0, void* stream,
-                         void* start_event, void* stop_event);
-int mrsim_step_events(const MrsimParams* p, int64_t n, uint32_t env_id0, const MrsimState* st,
-                      const MrsimStepIO* io, uint64_t seed, uint64_t step_idx, void* stream,
-                      void* start_event, void* stop_event);
-
 /* actions[n][2] = actor.predict(obs) + actor_noise() (RL/MR_ddpg.py:277) as a kernel of its own -- the gym-loop form:
  * feed `actions` to mrsim_step with the SAME (seed, step_idx).  obs: [n][5] or [5][n] per p->obs_layout (what
  * mrsim_reset / mrsim_step wrote).  st: the env state, read only when actor->ou_reset_on_done (MR_Env.counter); may be
@@ -409,10 +392,16 @@ int mrsim_device_cu_layout(int32_t device, int32_t* compute_units, int32_t* xccs
 int mrsim_stream_create_cu_mask(int32_t device, const uint32_t* mask, int32_t n_words, void** stream_out);
 int mrsim_stream_destroy(void* stream);
 
-/* Test aid: out[n][4] = the 4 standard normals of RNG call `c0` for envs env_id0..env_id0+n-1
- * (bit-compared with the oracle's definition in tests/). */
-int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, uint32_t c0,
-                        int32_t noise_math, float* out, void* stream);
+/* Pinned, device-mapped host memory (hipHostMalloc, mapped + coherent) for callers that drive FEW envs from the host -- the
+ * single-env MR_Env facade (MR_env.py:70-98 called once per Python loop iteration, utils.py:51-54, RL/MR_ddpg.py:278): the env
+ * state, the action and every output of mrsim_step live in ONE such block, the kernel reads and writes it over the bus, and a step
+ * is one launch + one mrsim_stream_synchronize with no copy call on either side of it.  *dev_ptr_out is the address to hand to the
+ * entry points above (equal to *host_ptr_out under unified addressing; returned separately so that nothing is assumed).
+ * For many envs keep state and outputs in device memory: every access to such a block crosses PCIe. */
+int mrsim_host_alloc(int64_t bytes, void** host_ptr_out, void** dev_ptr_out);
+int mrsim_host_free(void* host_ptr);
+/* hipStreamSynchronize(stream) for callers that bind no HIP runtime of their own (ctypes). */
+int mrsim_stream_synchronize(void* stream);
 
 /* Number of HIP devices visible (0 without a GPU); fills name_host (may be NULL). */
 int mrsim_device_count(void);

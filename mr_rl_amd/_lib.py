@@ -12,20 +12,27 @@ REW_CONSTANT10, REW_GOAL = 0, 1
 OBS_AOS, OBS_SOA = 0, 1
 NOISE_FAST, NOISE_SPEC = 0, 1
 LAW_PER_STAGE, LAW_COLLAPSED = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 ACTOR_HIDDEN, ACTOR_BLOB_FLOATS = 64, 10888
 ACTOR_F32, ACTOR_BF16X3, ACTOR_BF16 = 0, 1, 2
 DDPG_PARAMS, DDPG_MAX_BATCH = 7680, 4096
 
-# every symbol include/mrsim.h declares (tests check the .so exports exactly these)
-SYMBOLS = (
+# every symbol include/mrsim.h declares -- the product ABI (tests check the .so exports exactly these + BENCH_SYMBOLS)
+PRODUCT_SYMBOLS = (
     "mrsim_abi_version", "mrsim_strerror", "mrsim_default_params", "mrsim_reset", "mrsim_step",
-    "mrsim_step_timed", "mrsim_random_policy", "mrsim_random_policy_steps", "mrsim_rollout", "mrsim_rollout_timed", "mrsim_advance_step_base", "mrsim_device_cu_layout", "mrsim_stream_create_cu_mask", "mrsim_stream_destroy", "mrsim_velocity", "mrsim_debug_normals",
+    "mrsim_random_policy", "mrsim_random_policy_steps", "mrsim_rollout", "mrsim_advance_step_base", "mrsim_device_cu_layout",
+    "mrsim_stream_create_cu_mask", "mrsim_stream_destroy", "mrsim_velocity",
     "mrsim_device_count", "mrsim_device_name",
-    "mrsim_event_create", "mrsim_event_destroy", "mrsim_event_elapsed_ms", "mrsim_rollout_events", "mrsim_step_events",
     "mrsim_actor_fold_bn_host", "mrsim_actor_pack_host", "mrsim_actor_forward", "mrsim_ddpg_update",
     "mrsim_replay_push", "mrsim_actor_pack_device",
+    "mrsim_host_alloc", "mrsim_host_free", "mrsim_stream_synchronize",
 )
+# include/mrsim_bench.h: measurement and test aids (bench.py, tools/, tests/); nothing in mr_rl_amd's product path calls them
+BENCH_SYMBOLS = (
+    "mrsim_step_timed", "mrsim_rollout_timed", "mrsim_event_create", "mrsim_event_destroy", "mrsim_event_elapsed_ms",
+    "mrsim_rollout_events", "mrsim_step_events", "mrsim_debug_normals",
+)
+SYMBOLS = PRODUCT_SYMBOLS + BENCH_SYMBOLS
 
 
 class MrsimParams(C.Structure):
@@ -69,7 +76,7 @@ class MrsimStepIO(C.Structure):
         ("actions", C.c_void_p), ("actions_out", C.c_void_p), ("goal_table", C.c_void_p),
         ("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("state_prime", C.c_void_p),
         ("final_obs", C.c_void_p), ("final_ret", C.c_void_p), ("final_len", C.c_void_p),
-        ("status", C.c_void_p), ("actor", C.POINTER(MrsimActor)),
+        ("status", C.c_void_p), ("actor", C.POINTER(MrsimActor)), ("attempts", C.c_void_p),
     ]
 
 
@@ -135,6 +142,9 @@ def load(path):
     L.mrsim_ddpg_update.argtypes = [C.POINTER(MrsimDdpgLearner), i32, i32, vp, vp, vp, vp, vp, vp, i32, u64, u64, vp, vp, vp]
     L.mrsim_replay_push.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, u64, u64, vp]
     L.mrsim_actor_pack_device.argtypes = [vp, vp, C.c_float, vp, vp, vp, vp]
+    L.mrsim_host_alloc.argtypes = [i64, C.POINTER(vp), C.POINTER(vp)]
+    L.mrsim_host_free.argtypes = [vp]
+    L.mrsim_stream_synchronize.argtypes = [vp]
     L.mrsim_device_count.restype = C.c_int
     L.mrsim_device_name.argtypes = [C.c_int, C.c_char_p, i32]
     for name in SYMBOLS:
@@ -144,6 +154,7 @@ def load(path):
         raise ImportError(f"{path}: ABI {L.mrsim_abi_version()} != binding ABI {ABI_VERSION}")
     assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 12 + 8
     assert C.sizeof(MrsimRolloutIO) == 8 + 8 * 11 + 8 + 4 + 4 + 8
+    assert C.sizeof(MrsimStepIO) == 8 * 13
     assert C.sizeof(MrsimActor) == 40 and C.sizeof(MrsimActorWeights) == 48 + 28 + 4
     return L
 

@@ -45,9 +45,11 @@ class MRConfig:
                                           # per episode (utils.run_sim): nominal-law constructor.  Differs only if is_mismatched.
     obs_layout: str = "aos"               # storage of obs: [N,5] rows or [5,N] planes (returned view is [N,5])
     noise_math: str = "fast"              # Box-Muller on hardware transcendentals | "spec": bit-identical to the oracle
-    noise_law: str = "per_stage"          # "per_stage": a fresh normal at every RHS evaluation (MR_simulator.py:73-83, the
-                                          # parity mode); "collapsed": the weighted stage sums of an RK45 attempt drawn
-                                          # directly from their joint Gaussian -- same law, fewer draws (include/mrsim.h)
+    noise_law: str = "collapsed"          # "collapsed" (the library default, = mrsim_default_params): the weighted stage sums
+                                          # of an RK45 attempt drawn directly from their joint Gaussian -- the law of
+                                          # MR_simulator.py:73-83's per-evaluation noise with fewer draws, pinned against the
+                                          # reference's own samples (include/mrsim.h); "per_stage": a fresh normal at every
+                                          # RHS evaluation in the reference's order (the layout of the oracle's tape replays)
     rollout_carry: str = "f32"            # fused rollout: "f32" = carried RK45 state rounded per step (bit-identical to
                                           # step()); "f64" = kept in fp64 registers for the whole launch
     seed: int = 0

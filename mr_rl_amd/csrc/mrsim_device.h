@@ -97,6 +97,7 @@ enum : uint32_t {
     kFResetFresh = 1u << 24,  // auto-reset = a fresh MR_Env (nominal-law constructor) instead of the re-used one
     kFActorBf16 = 1u << 25,   // the actor's 64 x 64 layer in bf16 x 3 arithmetic (mrsim_actor.h: kActBf16x3)
     kFActorBf16s = 1u << 26,  // ... in plain bf16 (kActBf16)
+    kFOutAttempts = 1u << 27, // step kernel: rk_step attempts of the env step (MrsimStepIO.attempts; generic kernels only)
 };
 __device__ __forceinline__ uint32_t live_flags(uint32_t f) {
     asm volatile("" : "+s"(f));
@@ -1312,6 +1313,7 @@ struct StepOut {
     float fobs[5];
     float fret;
     int32_t flen;
+    int32_t attempts;   // rk_step attempts of this env step (diagnostic output of the step kernel; dead code elsewhere)
 };
 
 // MR_Env.reset body for one env (MR_env.py:164-201 -> MR_simulator.py:21-34)
@@ -1450,6 +1452,7 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
     double spx = 0.0, spy = 0.0;
     if constexpr (RK45) {
         bool fast = false;
+        o.attempts = 1;
         // (noise_math = spec is the test-oriented bit-exact mode: its long Box-Muller would only be duplicated)
         if constexpr (nz_fast(NZ) && MRSIM_FAST_STEP != 0) {
             if (!(fl & kFOutStatePrime)) fast = rk45_fast_step<NZ, MIS>(P, C, R, &W.w[0][0], e, lm, fail);
@@ -1462,10 +1465,12 @@ __device__ __forceinline__ void env_step(const KParams& P, const Rng& R, const f
             rk45_construct<NZ, MIS>(P, C, R, kStreamCtor, e.x, e.y, e.f0x, e.f0y, e.h_abs, spx, spy,           // :46-50
                                     (fl & kFOutStatePrime) != 0, NZ != kNoNoise ? &LS : nullptr);
             if (lm != nullptr) lm->kb = lm1_bound(e.f0x, e.f0y);
+            o.attempts = (int32_t)LS.attempt;
         }
     } else {
         fixed_integrate<NZ, MIS>(P, C, R, e.x, e.y, spx, spy);
         e.f0x = spx; e.f0y = spy; e.h_abs = P.dt;
+        o.attempts = P.substeps > 0 ? P.substeps : 1;
     }
     double gx = (double)goal_f.x, gy = (double)goal_f.y;
     const double dx = gx - e.x, dy = gy - e.y;

@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "mrsim.h"
+#include "mrsim_bench.h"
 #include "mrsim_device.h"
 #include "mrsim_actor.h"
 #include "mrsim_learner.h"
@@ -79,6 +80,7 @@ struct IOArgs {
     float* final_ret;
     int32_t* final_len;
     int32_t* status;
+    int32_t* attempts;
 };
 
 // ---------------------------------------------------------------------------
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
                 if (fl & kFOutFinalLen) io.final_len[i] = o.flen;
             }
             if (fail && (fl & kFOutStatus)) atomicOr(io.status, fail);
+            if constexpr (FL == 0) { if (fl & kFOutAttempts) io.attempts[i] = o.attempts; }
             if constexpr (!AOS) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j) io.obs[(long long)j * P.n + i] = o.obs[j];
@@ -996,11 +999,11 @@ static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
     if ((rc = check_device())) return rc;
     const StateArgs S{st->pos, st->aux, st->ep_ret};
     const IOArgs IO{io->actions, io->actions_out, io->goal_table, io->obs, io->rew, io->done, io->state_prime,
-                    io->final_obs, io->final_ret, io->final_len, io->status};
+                    io->final_obs, io->final_ret, io->final_len, io->status, io->attempts};
     K.flags |= (io->actions ? kFActions : 0u) | (io->goal_table ? kFGoalTable : 0u) |
                (io->actions_out ? kFOutActions : 0u) | (io->state_prime ? kFOutStatePrime : 0u) |
                (io->final_obs ? kFOutFinalObs : 0u) | (io->final_ret ? kFOutFinalRet : 0u) |
-               (io->final_len ? kFOutFinalLen : 0u) | (io->status ? kFOutStatus : 0u) | abits;
+               (io->final_len ? kFOutFinalLen : 0u) | (io->status ? kFOutStatus : 0u) | (io->attempts ? kFOutAttempts : 0u) | abits;
     LaunchCfg lc{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
     if (kernel_ms == nullptr) return launch_step(lc, p, K, S, IO, AC);
     // timed variant: events attached to this one dispatch (hipExtLaunchKernelGGL)
@@ -1060,7 +1063,8 @@ int mrsim_default_params(MrsimParams* p) {
     p->obs_layout = MRSIM_OBS_AOS;
     p->noise_math = MRSIM_NOISE_FAST;
     p->auto_reset_fresh_env = 0;            // auto-reset = the same env object re-used (RL/MR_ddpg.py:270)
-    p->noise_law = MRSIM_LAW_PER_STAGE;     // one draw per RHS evaluation, as MR_simulator.py:73-83
+    p->noise_law = MRSIM_LAW_COLLAPSED;     // the law of MR_simulator.py:73-83's per-evaluation noise, drawn through the two
+                                            // weighted stage sums (mrsim.h; MRSIM_LAW_PER_STAGE = one draw per evaluation)
     p->step_base = nullptr;
     return MRSIM_OK;
 }
@@ -1382,12 +1386,12 @@ int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, int32_t n_updat
     if (!(Lr->bn_eps > 0.0f) || !(Lr->beta1 >= 0.0f && Lr->beta1 < 1.0f) || !(Lr->beta2 >= 0.0f && Lr->beta2 < 1.0f)) return MRSIM_EINVAL;
     int rc = check_device();
     if (rc) return rc;
-    static bool attr_set = false;   // one-time: the kernel's LDS image (136 KB) is above the default dynamic limit
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(learner::mr_ddpg_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)sizeof(learner::Lds)) != hipSuccess)
-            return MRSIM_ELAUNCH;
-        attr_set = true;
+    // the kernel's LDS image (sizeof(learner::Lds), ~153 KB) is above the default dynamic limit; the attribute is per device
+    // (and the call is cheap and idempotent), so it is set on every call for whichever device is current
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(learner::mr_ddpg_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(learner::Lds)) != hipSuccess) {
+        (void)hipGetLastError();
+        return MRSIM_ELAUNCH;
     }
     learner::Args A{Lr->online, Lr->target, Lr->adam_m, Lr->adam_v, Lr->grad_scratch, Lr->steps, Lr->bn_stats, s, a, r, done, s2, idx,
                     idx_out, ring_count, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)draw_counter, (uint32_t)(draw_counter >> 32),
@@ -1516,6 +1520,31 @@ int mrsim_stream_destroy(void* stream) {
     if (rc) return rc;
     (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
     return hipStreamDestroy(static_cast<hipStream_t>(stream)) == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+}
+
+int mrsim_host_alloc(int64_t bytes, void** host_ptr_out, void** dev_ptr_out) {
+    if (bytes <= 0 || host_ptr_out == nullptr || dev_ptr_out == nullptr) return MRSIM_EINVAL;
+    int rc = check_device();
+    if (rc) return rc;
+    void* h = nullptr;
+    if (hipHostMalloc(&h, (size_t)bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return MRSIM_ELAUNCH; }
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return MRSIM_ELAUNCH; }
+    std::memset(h, 0, (size_t)bytes);
+    *host_ptr_out = h;
+    *dev_ptr_out = d;
+    return MRSIM_OK;
+}
+
+int mrsim_host_free(void* host_ptr) {
+    if (host_ptr == nullptr) return MRSIM_EINVAL;
+    return hipHostFree(host_ptr) == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+}
+
+int mrsim_stream_synchronize(void* stream) {
+    int rc = check_device();
+    if (rc) return rc;
+    return hipStreamSynchronize(static_cast<hipStream_t>(stream)) == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 
 int mrsim_debug_normals(int64_t n, uint32_t env_id0, uint64_t seed, uint64_t step_idx, uint32_t c0, int32_t noise_math,

@@ -46,7 +46,7 @@ class MRVecEnv:
     metadata = {"render.modes": []}
 
     def __init__(self, num_envs, cfg=None, device="cuda", seed=None, env_id0=0, goal_table=None,
-                 track_state_prime=False, track_actions=False):
+                 track_state_prime=False, track_actions=False, track_attempts=False):
         torch = _torch()
         self._L = _lib.lib()  # raises ImportError if the HIP extension is not built
         if not torch.cuda.is_available() or self._L.mrsim_device_count() <= 0:
@@ -98,6 +98,8 @@ class MRVecEnv:
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self._state_prime = torch.zeros((n, 2), dtype=torch.float32, device=dev) if track_state_prime else None
         self._actions_out = torch.zeros((n, 2), dtype=torch.float32, device=dev) if track_actions else None
+        # rk_step attempts of the latest step() per env (MrsimStepIO.attempts; = (integrator.nfev after - before) / 6)
+        self.attempts = torch.zeros(n, dtype=torch.int32, device=dev) if track_attempts else None
         self.last_action = None
         self._prev_mismatched = False  # what Simulator.is_mismatched was before the latest reset (MR_env.py:181-183)
         self._params = None
@@ -207,7 +209,7 @@ class MRVecEnv:
         io = _lib.MrsimStepIO(
             self._p(act_t), self._p(self._actions_out), self._p(self.goal_table), self._p(self._obs),
             self._p(self.rew), self._p(self._done_u8), self._p(self._state_prime), self._p(self._final_obs),
-            self._p(self.final_ret), self._p(self.final_len), self._p(self.status))
+            self._p(self.final_ret), self._p(self.final_len), self._p(self.status), None, self._p(self.attempts))
         if actor is not None:
             self._actor_struct = actor.struct(self.num_envs)   # keeps the ctypes block alive through the call
             io.actor = C.pointer(self._actor_struct)
@@ -257,7 +259,7 @@ class MRVecEnv:
         st = _lib.MrsimState(off(self.pos, 16), off(self.aux, 16), off(self.ep_ret, 4))
         io = _lib.MrsimStepIO(act_ptr, off(self._actions_out, 8), self._p(self.goal_table), off(self._obs, 20),
                               off(self.rew, 4), off(self._done_u8, 1), off(self._state_prime, 8), off(self._final_obs, 20),
-                              off(self.final_ret, 4), off(self.final_len, 4), self._p(self.status))
+                              off(self.final_ret, 4), off(self.final_len, 4), self._p(self.status), None, off(self.attempts, 4))
         _lib.check(L.mrsim_step(C.byref(self._params), n, self.env_id0 + first, C.byref(st), C.byref(io), self.seed_value,
                                 step_idx, sp), "mrsim_step")
 

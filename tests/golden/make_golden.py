@@ -27,11 +27,14 @@ them is copied.  What is committed is data: inputs and the reference's outputs.
   ref_sim_f64.npz  the ref_sim scenarios with the reference's own float64 action tables (not rounded to float32).
   ref_experiment.npz  MR_data.MRExperiment's dictionaries after three recorded MR_Env episodes (8f-3).
   ref_circle_fm.npz  utils.run_sim on main_2d.py:137-160's frequency-modulated circle learning set (nominal and mismatched).
-  ref_increments.npz  sigma > 0 STATISTICS of the reference itself: 20 000 per-step noise increments of Simulator.step at sigma = 1
-                in the DDPG regime (start (110, 115), random actions in the actor range, 200 restarts of 100 steps), nominal and
-                mismatched law: Delta - dt (b1 K0 + (1 - b1) V(action)) normalised to unit variance (/ dt cB sqrt(g^2 + sigma^2)).  The kernels' and the
-                oracle's increments (per-stage and collapsed noise law, fast and spec Box-Muller) are tested against these SAMPLES
-                (two-sample KS, variance ratio), not only against the formula of SURVEY 3.3.
+  ref_increments.npz  sigma > 0 STATISTICS of the reference itself (schema 2, round 5): per-step noise increments of Simulator.step at
+                sigma = 1, random actions in the actor range, nominal and mismatched law -- 1e6 env steps per law in the DDPG regime
+                (start (110, 115), 10 000 restarts of 100 steps), 1e6 per law at start (8, -6) (first-attempt error_norm ~ 1) and 4e5 per
+                law and start where SciPy's error controller splits every step (starts (0, 0) and (0.5, -0.2); episodes of 8 steps), with the rk_step attempts of every step (integrator.nfev):
+                Delta - dt (b1 K0 + (1 - b1) V(action)) in units of dt cB sqrt(g^2 + sigma^2), stored as sorted-sample quantiles at
+                fixed ranks + moments + attempts histograms (pooled, per step index, per episode).  The oracle's and the kernels'
+                samples (per-stage and collapsed noise law, fast and spec Box-Muller) are tested against these (KS on the stored
+                ECDF points, |std ratio - 1| < 0.005, chi-square on the attempts), not only against the formula of SURVEY 3.3.
 
 Usage:  python tests/golden/make_golden.py   (writes next to this file)
 """
@@ -444,43 +447,138 @@ def gen_circle_fm():
     print("ref_circle_fm.npz written")
 
 
-def gen_increments():
-    """Per-step noise increments of the reference Simulator at sigma = 1, far from the origin (no step splitting)."""
-    dt, b1, cB = 0.030, 35.0 / 384, float(np.sqrt((500 / 1113) ** 2 + (125 / 192) ** 2 + (2187 / 6784) ** 2 + (11 / 84) ** 2))
-    flat = {}
-    for name, mis, seed in (("inc_nominal_s1", False, 4242), ("inc_mismatched_s1", True, 4243)):
-        rng = np.random.default_rng(seed)
-        np.random.seed(seed)
-        res, resn, nev = [], [], []
-        for ep in range(200):
-            s = MR_simulator.Simulator()
-            s.noise_var = 1.0
-            s.a0 = 1.0
-            s.reset_start_pos(np.array([110.0, 115.0]))
-            s.is_mismatched = mis
-            acts = f32(actions_random(100, rng, idle_frac=0.0, wide=True))
-            for f_t, al in acts:
-                k0 = np.array(s.integrator.f, dtype=np.float64)
-                p0 = np.array(s.integrator.y, dtype=np.float64)
-                n0 = s.integrator.nfev
-                p1 = np.array(s.step(f_t, al), dtype=np.float64)
-                if mis:
-                    a0b = 1.0 + (f_t / 4) * 0.8
-                    V = np.array([a0b * f_t * np.cos(al + 0.1) + 0.2, a0b * f_t * np.sin(al - 0.15) - 0.1])
-                    g = 0.25 * f_t * np.array([np.cos(al + 0.1), np.sin(al - 0.15)])
-                else:
-                    V = np.array([f_t * np.cos(al), f_t * np.sin(al)])
-                    g = np.zeros(2)
-                r = p1 - p0 - dt * (b1 * k0 + (1 - b1) * V)
-                res.append(r)
-                resn.append(r / (dt * cB * np.sqrt(g * g + 1.0)))
-                nev.append(6)      # one rk_step attempt per env step in this regime (checked below through the variance)
-        res, resn = np.asarray(res), np.asarray(resn)
-        flat[f"{name}/res_norm"] = resn.astype(np.float32)
-        flat[f"{name}/sigma"] = np.float64(1.0)
-        flat[f"{name}/mismatched"] = np.int64(mis)
-        print(f"  {name}: {len(res)} increments, std of the normalised residual {resn.std(axis=0)} (1 = SURVEY 3.3's law)")
+# --------------------------------------------------------------------------
+# sigma > 0 statistics of the reference itself, at scale (round 5)
+# --------------------------------------------------------------------------
+INC_DT, INC_B1 = 0.030, 35.0 / 384
+INC_CB = float(np.sqrt((500 / 1113) ** 2 + (125 / 192) ** 2 + (2187 / 6784) ** 2 + (11 / 84) ** 2))
+INC_ATT_BINS = 128
+# name -> (start, steps per episode, episodes, quantile points).  "far" = the DDPG regime (steps are never split, the pooled
+# increments are iid); "origin" / "near" = starts where the error controller of SciPy's RK45 rejects and splits steps
+# (MR_simulator.py:42-43 under the noise of :79-83): episodes are SHORT and many, statistics are kept per step index.
+INC_REGIMES = {
+    "far": ((110.0, 115.0), 100, 10000, 8193),
+    "mid": ((8.0, -6.0), 8, 125000, 1025),      # error_norm of the first attempt ~ 1: accept / reject is a coin flip
+    "origin": ((0.0, 0.0), 8, 50000, 1025),     # 20 .. 50 attempts per env step
+    "near": ((0.5, -0.2), 8, 50000, 1025),
+}
+
+
+def inc_normalised_residual(p0, p1, k0, actions, mis, sigma, a0=1.0):
+    """(Delta - dt (b1 K0 + (1 - b1) V(action))) / (dt cB sqrt(g^2 + sigma^2)) for arrays [..., 2]: the part of an env step's
+    displacement that the noise (and, where the step is split, the splitting) is responsible for, in units of the unsplit
+    step's noise std.  Shared by this script and the tests (tests/test_noise_law_cpu.py imports the formula's twin)."""
+    f, al = actions[..., 0], actions[..., 1]
+    if mis:
+        a0b = a0 + (f / 4) * 0.8
+        V = np.stack([a0b * f * np.cos(al + 0.1) + 0.2, a0b * f * np.sin(al - 0.15) - 0.1], -1)
+        g = 0.25 * sigma * f[..., None] * np.stack([np.cos(al + 0.1), np.sin(al - 0.15)], -1)
+    else:
+        V = np.stack([a0 * f * np.cos(al), a0 * f * np.sin(al)], -1)
+        g = np.zeros_like(V)
+    return (p1 - p0 - INC_DT * (INC_B1 * k0 + (1 - INC_B1) * V)) / (INC_DT * INC_CB * np.sqrt(g * g + sigma * sigma))
+
+
+def _inc_chunk(task):
+    """One chunk of episodes of the imported reference Simulator (a worker process; seeds fixed per chunk, so the fixture does
+    not depend on how chunks are scheduled).  Attempts of an env step = rk_step calls = (nfev after - nfev before) / 6 of the
+    RK45 object that integrates it (5 stages + f_new per attempt; MR_simulator.py:42-43)."""
+    start, steps, n_ep, mis, sigma, seed = task
+    rng = np.random.default_rng(seed)
+    np.random.seed(seed % (2 ** 32))
+    resn = np.zeros((n_ep, steps, 2))
+    att = np.zeros((n_ep, steps), dtype=np.int32)
+    for ep in range(n_ep):
+        s = MR_simulator.Simulator()
+        s.noise_var = sigma
+        s.a0 = 1.0
+        s.reset_start_pos(np.array(start, dtype=np.float64))
+        s.is_mismatched = mis          # MR_env.py:181-183: set AFTER the integrator was built
+        acts = f32(actions_random(steps, rng, idle_frac=0.0, wide=True))
+        for k in range(steps):
+            integ = s.integrator
+            k0 = np.array(integ.f, dtype=np.float64)
+            p0 = np.array(integ.y, dtype=np.float64)
+            n0 = integ.nfev
+            p1 = np.array(s.step(acts[k, 0], acts[k, 1]), dtype=np.float64)
+            dn = integ.nfev - n0
+            assert dn % 6 == 0 and dn >= 6
+            att[ep, k] = dn // 6
+            resn[ep, k] = inc_normalised_residual(p0, p1, k0, acts[k], mis, sigma)
+    return resn, att
+
+
+def inc_summary(resn, att, n_q, per_step):
+    """The committed summary of a sample resn [E, S, 2], att [E, S]: sorted-sample quantiles at fixed ranks (the ECDF is exact at
+    those points: F(q[i]) = (rank[i] + 1) / n), central moments, attempts histograms; pooled over all env steps and -- per_step --
+    for every step index; plus per-EPISODE reductions (episodes are independent, steps of one episode are not)."""
+    E, S, _ = resn.shape
+
+    def one(x, nq):          # x [m, 2]
+        m = x.shape[0]
+        ranks = np.round(np.linspace(0.0, 1.0, nq) * (m - 1)).astype(np.int64)
+        xs = np.sort(x, axis=0)
+        mu = x.mean(axis=0)
+        c = x - mu
+        return dict(q=xs[ranks].T.astype(np.float32), ranks=ranks, n=np.int64(m), mean=mu, var=(c ** 2).mean(axis=0),
+                    m3=(c ** 3).mean(axis=0), m4=(c ** 4).mean(axis=0), cov_xy=np.float64((c[:, 0] * c[:, 1]).mean()))
+
+    out = {}
+    for k, v in one(resn.reshape(-1, 2), n_q if not per_step else 4097).items():
+        out["pooled/" + k] = v
+    out["pooled/att_hist"] = np.bincount(np.minimum(att.ravel(), INC_ATT_BINS - 1), minlength=INC_ATT_BINS).astype(np.int64)
+    # per episode: mean square of the episode's residuals (the variance estimator whose standard error is honest under
+    # within-episode dependence), the episode's summed residual and its total attempts
+    ssq = (resn ** 2).mean(axis=1)                                  # [E, 2]
+    out["episode/sumsq_mean"] = ssq.mean(axis=0)
+    out["episode/sumsq_var"] = ssq.var(axis=0)
+    out["episode/n"] = np.int64(E)
+    if per_step:
+        per = [one(resn[:, k], n_q) for k in range(S)]
+        for key in per[0]:
+            out["step/" + key] = np.stack([np.asarray(p[key]) for p in per])
+        out["step/att_hist"] = np.stack([np.bincount(np.minimum(att[:, k], INC_ATT_BINS - 1), minlength=INC_ATT_BINS)
+                                         for k in range(S)]).astype(np.int64)
+        for k, v in one(resn.sum(axis=1), 4097).items():
+            out["episode/sum_" + k] = v
+        tot = att.sum(axis=1)
+        out["episode/att_total_hist"] = np.bincount(np.minimum(tot, 1023), minlength=1024).astype(np.int64)
+    return out
+
+
+def gen_increments(workers=None):
+    """ref_increments.npz (schema 2): statistics of the noise increments of the imported Simulator.step at sigma = 1, nominal and
+    mismatched law, random actions in the DDPG actor range -- 1e6 env steps per law in the far regime (start (110, 115), restarts
+    of 100 steps), 1e6 per law where the first attempt's error_norm is about 1 (start (8, -6), 125 000 episodes of 8 steps) and
+    4e5 per law and start where every step is split into 20 .. 50 attempts (starts (0, 0) and (0.5, -0.2), 50 000 episodes of
+    8 steps), with the rk_step attempts of every env step (from integrator.nfev).  Stored as sorted-sample quantiles at fixed
+    ranks + moments + attempts histograms so that the fixture stays small; the tests compare the oracle's and the kernels'
+    samples (per-stage and collapsed noise law) against these: KS on the stored ECDF points, |std ratio - 1| < 0.005,
+    chi-square on the attempts histograms."""
+    import multiprocessing as mp
+    import time
+    workers = workers or min(8, os.cpu_count() or 1)
+    flat = {"schema": np.int64(2), "sigma": np.float64(1.0), "a0": np.float64(1.0), "att_bins": np.int64(INC_ATT_BINS)}
+    with mp.Pool(workers) as pool:
+        for regime, (start, steps, n_ep, n_q) in INC_REGIMES.items():
+            for mis in (False, True):
+                name = f"{regime}_{'mismatched' if mis else 'nominal'}_s1"
+                chunk = 500 if regime == "far" else 2500
+                base = 50000 + 1000 * list(INC_REGIMES).index(regime) + (500 if mis else 0)
+                tasks = [(start, steps, chunk, mis, 1.0, base * 1000 + c) for c in range(n_ep // chunk)]
+                t0 = time.time()
+                parts = pool.map(_inc_chunk, tasks, chunksize=1)
+                resn = np.concatenate([p[0] for p in parts])
+                att = np.concatenate([p[1] for p in parts])
+                for k, v in inc_summary(resn, att, n_q, per_step=(regime != "far")).items():
+                    flat[f"{name}/{k}"] = v
+                flat[f"{name}/start"] = np.asarray(start)
+                flat[f"{name}/steps"] = np.int64(steps)
+                flat[f"{name}/mismatched"] = np.int64(mis)
+                print(f"  {name}: {resn.shape[0] * steps} env steps in {time.time() - t0:.0f} s; pooled std {resn.reshape(-1, 2).std(axis=0)}, "
+                      f"mean attempts {att.mean():.4f} (max {att.max()}), nfev per step = 6 attempts + 2", flush=True)
     np.savez_compressed(os.path.join(HERE, "ref_increments.npz"), **flat)
+    print("ref_increments.npz written")
 
 
 if __name__ == "__main__":

@@ -9,20 +9,38 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    h = open(os.path.join(ROOT, "include", "mrsim.h")).read()
+def _declared_symbols(header="mrsim.h"):
+    h = open(os.path.join(ROOT, "include", header)).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)          # declarations only, not the prose around them
     return sorted(set(re.findall(r"\b(mrsim_[a-z_0-9]+)\s*\(", h)))
 
 
 def test_library_loads_and_exports_header_symbols():
+    """include/mrsim.h = the product ABI, include/mrsim_bench.h = measurement / test aids: the library exports every symbol
+    either declares, the binding lists exactly those, and the two sets are disjoint."""
     from mr_rl_amd import _lib
     L = _lib.lib()
-    declared = _declared_symbols()
-    assert declared, "no declarations parsed"
-    for s in declared:
+    product, bench = _declared_symbols("mrsim.h"), _declared_symbols("mrsim_bench.h")
+    assert product and bench, "no declarations parsed"
+    for s in product + bench:
         assert hasattr(L, s), f"libmrsim.so does not export {s}"
-    assert sorted(_lib.SYMBOLS) == declared
-    assert L.mrsim_abi_version() == _lib.ABI_VERSION
+    assert sorted(_lib.PRODUCT_SYMBOLS) == product
+    assert sorted(_lib.BENCH_SYMBOLS) == bench
+    assert not set(product) & set(bench)
+    assert L.mrsim_abi_version() == _lib.ABI_VERSION == 5
+
+
+def test_product_modules_do_not_call_the_measurement_aids():
+    """mrsim_*_timed / *_events / debug_normals are bound for bench.py, tools/ and tests/; the product path (env, collector,
+    rollout, recorder, learner, dist, partition) does not call them.  (MRVecEnv keeps thin wrappers that bench.py drives:
+    step_timed, rollout(timed= / events=) -- those are the only call sites.)"""
+    pkg = os.path.join(ROOT, "mr_rl_amd")
+    for name in sorted(os.listdir(pkg)):
+        if not name.endswith(".py") or name in ("_lib.py", "vec_env.py"):
+            continue
+        src = open(os.path.join(pkg, name)).read()
+        for sym in ("mrsim_step_timed", "mrsim_rollout_timed", "mrsim_rollout_events", "mrsim_step_events", "mrsim_debug_normals"):
+            assert sym not in src, (name, sym)
 
 
 def test_default_params_match_reference_constants():
@@ -67,8 +85,16 @@ def test_no_device_is_an_error_not_a_fallback():
     assert L.mrsim_step(C.byref(p), 4, 0, C.byref(st), C.byref(io), 0, 0, None) == _lib.ENODEVICE
     assert L.mrsim_reset(C.byref(p), 4, 0, C.byref(st), None, None, None, None, 0, 0, 0, None) == _lib.ENODEVICE
     assert L.mrsim_random_policy(C.byref(p), 4, 0, buf.ctypes.data, 0, 0, None) == _lib.ENODEVICE
+    h, d = C.c_void_p(), C.c_void_p()
+    assert L.mrsim_host_alloc(192, C.byref(h), C.byref(d)) == _lib.ENODEVICE and not h.value
+    assert L.mrsim_host_alloc(0, C.byref(h), C.byref(d)) == _lib.EINVAL
+    assert L.mrsim_host_free(None) == _lib.EINVAL
+    assert L.mrsim_stream_synchronize(None) == _lib.ENODEVICE
     with pytest.raises(RuntimeError):
         MRVecEnv(4)
+    from mr_rl_amd import MR_Env
+    with pytest.raises(RuntimeError):
+        MR_Env()
 
 
 def test_c_demo_program_builds_and_refuses_without_a_device():
@@ -141,7 +167,7 @@ def test_abi4_entry_points_validate_their_arguments_and_have_no_cpu_path():
     from mr_rl_amd import _lib
     L = _lib.lib()
     p = _lib.default_params()
-    assert p.noise_law == _lib.LAW_PER_STAGE           # the library's default is the reference's per-evaluation noise
+    assert p.noise_law == _lib.LAW_COLLAPSED           # the library default since ABI 5 (include/mrsim.h: MRSIM_LAW_*)
     buf = np.zeros(4096, dtype=np.float64)
     st = _lib.MrsimState(buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)
     io = _lib.MrsimStepIO(None, None, None, buf.ctypes.data, buf.ctypes.data, buf.ctypes.data)

@@ -416,34 +416,7 @@ def test_ddpg_loop_learns_a_one_step_goal_task(fused):
     assert learnt >= 3, ends
 
 
-# ---------------------------------------------------------------------------
-# sigma > 0 statistics of the KERNEL against the reference's own increment samples (tests/golden/ref_increments.npz)
-# ---------------------------------------------------------------------------
-class _KernelSteps:
-    def __init__(self, n, law, mis, math, seed):
-        from mr_rl_amd import MRConfig, MRVecEnv
-        self.env = MRVecEnv(n, cfg=MRConfig(noise_var=1.0, is_mismatched=mis, noise_law=law, noise_math=math), seed=seed)
-        self.env.reset(init=np.tile([[110.0, 115.0]], (n, 1)), is_mismatched=mis)
-
-    def pos(self):
-        return self.env.pos.cpu().numpy()
-
-    def k0(self):
-        return self.env.aux[:, :2].cpu().numpy().astype(np.float64)
-
-    def step(self, a):
-        self.env.step(a)
-
-
-@pytest.mark.parametrize("law", ["per_stage", "collapsed"])
-@pytest.mark.parametrize("math", ["fast", "spec"])
-@pytest.mark.parametrize("mis", [False, True])
-def test_kernel_increments_match_the_reference_sample(law, math, mis):
-    """two-sample KS + variance ratio of the kernel's per-step noise increments (both noise laws, both Box-Muller flavours, both
-    model laws) against 20 000 increments sampled from the reference's own Simulator.step (make_golden.py: gen_increments)"""
-    from tests.test_noise_law_cpu import check_against_reference_increments, normalised_increments
-    r = normalised_increments(_KernelSteps(8192, law, mis, math, seed=33), 8192, 8, mis)
-    check_against_reference_increments(r, mis)
+# (sigma > 0 statistics of the kernel against the reference's own samples: tests/test_gpu_round5.py, schema-2 fixture)
 
 
 # ---------------------------------------------------------------------------

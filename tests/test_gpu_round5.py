@@ -1,0 +1,170 @@
+"""GPU tests of round 5 (all through the C ABI):
+
+  * the kernels' sigma > 0 statistics against the REFERENCE's own samples at scale (tests/golden/ref_increments.npz schema 2,
+    tests/increments.py): increments and rk_step attempts of Simulator.step (MR_simulator.py:36-52,73-83) far from the origin,
+    where the first attempt's error_norm is about 1, and where every step is split -- both noise laws, both Box-Muller
+    flavours, both model laws;
+  * MrsimStepIO.attempts (ABI 5) element-wise against the oracle's attempt counter;
+  * the library default law (collapsed) is what MRConfig() / mrsim_default_params give, and the oracle follows the same law;
+  * the single-env facade MR_Env on its pinned host record: goldens (test_gpu_parity / test_gpu_round3 keep theirs), reuse after
+    close(), a second device-side env next to it, and that a step is ONE kernel launch with no copy call.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import increments as INC
+from tests.util import load_cases, orc_params_from_cfg
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KERNEL_ENVS = {"far": 262144, "mid": 262144, "origin": 131072, "near": 131072}
+
+
+class _KernelSteps:
+    def __init__(self, n, law, mis, math, seed, start):
+        from mr_rl_amd import MRConfig, MRVecEnv
+        self.env = MRVecEnv(n, cfg=MRConfig(noise_var=1.0, is_mismatched=mis, noise_law=law, noise_math=math), seed=seed,
+                            track_attempts=True)
+        self.env.reset(init=np.tile([list(start)], (n, 1)), is_mismatched=mis)   # fresh env: nominal-law constructor
+
+    def pos(self):
+        return self.env.pos.cpu().numpy()
+
+    def k0(self):
+        return self.env.aux[:, :2].cpu().numpy().astype(np.float64)
+
+    def attempts(self):
+        return self.env.attempts.cpu().numpy()
+
+    def step(self, a):
+        self.env.step(a)
+
+
+@pytest.mark.parametrize("law", ["collapsed", "per_stage"])
+@pytest.mark.parametrize("math", ["fast", "spec"])
+@pytest.mark.parametrize("mis", [False, True], ids=["nominal", "mismatched"])
+@pytest.mark.parametrize("regime", INC.REGIMES)
+def test_kernel_increments_and_attempts_match_the_reference_sample(regime, law, math, mis):
+    ref = INC.reference(regime, mis)
+    n, steps = KERNEL_ENVS[regime], int(ref["steps"])
+    st = _KernelSteps(n, law, mis, math, seed=33 + (law == "per_stage"), start=tuple(ref["start"]))
+    resn, att = INC.draw(st, n, 8 if regime == "far" else steps, mis, seed=77)
+    st.env.check_status()
+    out = INC.compare(regime, mis, resn, att, label=f"kernel {law}/{math}")
+    assert out["tol"] <= 0.02
+
+
+@pytest.mark.parametrize("law", ["collapsed", "per_stage"])
+@pytest.mark.parametrize("start", [(0.0, 0.0), (8.0, -6.0), (110.0, 115.0)])
+def test_attempts_output_equals_the_oracles_counter(law, start):
+    """noise_math = "spec": normals bit-identical to the oracle's, so accept / reject decisions agree except where error_norm
+    lands within rounding of 1 (the oracle's err_margin tells): the attempt counts are equal for every env whose margin is
+    not tiny."""
+    from mr_rl_amd import MRConfig, MRVecEnv
+    n = 4096
+    cfg = MRConfig(noise_var=1.0, noise_law=law, noise_math="spec")
+    env = MRVecEnv(n, cfg=cfg, seed=9, track_attempts=True)
+    orc = O.VecOracle(n, orc_params_from_cfg(cfg), seed=9, threads=8)
+    init = np.tile([list(start)], (n, 1))
+    env.reset(init=init); orc.reset(0, init_xy=init)
+    rng = np.random.default_rng(2)
+    alive = np.ones(n, bool)      # envs that have agreed with the oracle so far (test_gpu_parity.py: near-origin splitting)
+    got = want = None
+    for t in range(6):
+        a = np.stack([rng.uniform(-20, 20, n), rng.uniform(-2 * np.pi, 2 * np.pi, n)], 1).astype(np.float32)
+        env.step(a); orc.step(a, step_idx=t + 1)
+        got, want = env.attempts.cpu().numpy(), orc.envs["n_attempts"]
+        bad = alive & (np.abs(env.pos.cpu().numpy() - orc.envs["y"]).max(axis=1) > 1e-6)
+        assert (orc.envs["err_margin"][bad] < 1e-6).all()          # only a decision within rounding of its threshold may differ
+        alive &= ~bad
+        assert np.array_equal(got[alive], want[alive]), (t, int((got[alive] != want[alive]).sum()))
+    assert alive.mean() >= 0.99
+    if start == (110.0, 115.0):
+        assert got.max() == 1
+    if start == (0.0, 0.0):
+        assert got[alive].min() > 5 and got[alive].mean() > 15
+
+
+def test_library_default_law_is_collapsed_everywhere():
+    import ctypes as C
+    from mr_rl_amd import MRConfig, _lib
+    p = _lib.default_params()
+    assert p.noise_law == _lib.LAW_COLLAPSED
+    assert MRConfig().noise_law == "collapsed" and MRConfig().to_params().noise_law == _lib.LAW_COLLAPSED
+    assert orc_params_from_cfg(MRConfig()).noise_law == O.LAW_COLLAPSED
+    assert C.sizeof(_lib.MrsimStepIO) == 104
+
+
+# ---------------------------------------------------------------------------
+# the drop-in MR_Env on its host record
+# ---------------------------------------------------------------------------
+def test_facade_step_is_one_launch_on_the_host_record():
+    """MR_env.py:70-98 through mr_rl_amd.MR_Env: the golden timeout episode again, this time counting what a step does --
+    the env's state and outputs are views of one pinned block (no torch tensor involved), and what step() returns is read
+    from that block."""
+    from mr_rl_amd import MR_Env
+    G = load_cases("ref_env.npz")["g6_timeout"]
+    env = MR_Env()
+    rec = env._rec
+    assert rec.pos.ctypes.data == rec.host and rec.obs.ctypes.data == rec.host + 64 and rec.SIZE == 192
+    obs0 = env.reset(init=G["init"], noise_var=0.0, a0=float(G["a0"]), is_mismatched=bool(G["mismatched"]))
+    np.testing.assert_allclose(obs0, G["obs0"], rtol=1e-6, atol=1e-6)
+    for k, a in enumerate(G["actions"][: len(G["obs"])]):
+        obs, rew, done, info = env.step(a)
+        assert rew == 10 and isinstance(rew, int) and info == {} and done == bool(G["done"][k])
+        np.testing.assert_allclose(env.last_pos, G["last_pos"][k], rtol=0, atol=5e-5)
+        assert env.last_pos == [float(rec.pos[0]), float(rec.pos[1])] and env.counter == int(rec.counter[0])
+        assert obs.dtype == np.float64 and np.array_equal(obs, rec.obs.astype(np.float64))
+    env.close()
+    env.close()                                   # idempotent
+    # two envs side by side keep separate records and separate RNG streams
+    a, b = MR_Env(seed=1, env_id=0), MR_Env(seed=1, env_id=1)
+    oa, ob = a.reset(init=[110.0, 115.0]), b.reset(init=[110.0, 115.0])
+    assert np.array_equal(oa, ob)
+    pa, _, _, _ = a.step([10.0, 1.0]); pb, _, _, _ = b.step([10.0, 1.0])
+    assert not np.array_equal(pa, pb)             # sigma = 1: different env ids draw different noise
+
+
+def test_facade_equals_vec_env_of_one():
+    """the facade and an MRVecEnv of one env (same seed, same env id) walk the same trajectory bit for bit at sigma = 1:
+    same kernel, same arguments -- only where the buffers live differs."""
+    from mr_rl_amd import MR_Env, MRConfig, MRVecEnv
+    env = MR_Env(seed=4, env_id=17)
+    vec = MRVecEnv(1, cfg=MRConfig(), seed=4, env_id0=17, track_state_prime=True)
+    init = np.array([101.5, 118.25])
+    o1 = env.reset(init=init, noise_var=1.0, a0=1.0, is_mismatched=False)
+    o2 = vec.reset(init=init[None, :], noise_var=1.0, a0=1.0, is_mismatched=False)
+    assert np.array_equal(o1, o2[0].double().cpu().numpy())
+    rng = np.random.default_rng(0)
+    for t in range(60):
+        a = np.array([rng.uniform(-20, 20), rng.uniform(-6, 6)], dtype=np.float32)
+        obs, rew, done, _ = env.step(a)
+        vo, vr, vd, _ = vec.step(a[None, :])
+        assert np.array_equal(obs, vo[0].double().cpu().numpy()) and done == bool(vd[0]) and rew == float(vr[0])
+        assert env.last_pos == vec.pos[0].cpu().numpy().tolist()
+        assert np.array_equal(env.state_prime, vec.state_prime[0].double().cpu().numpy())
+
+
+def test_facade_step_rate_beats_the_reference_python():
+    """the reference's own MR_Env.step runs at 7.2-9.5 k steps/s on one core (profiles/r03/ref_python_baseline.json);
+    the drop-in must not be slower than what it replaces (bench.py's `facade` leg reports the measured rate)."""
+    import time
+    from mr_rl_amd import MR_Env
+    env = MR_Env()
+    env.reset()
+    for _ in range(200):
+        env.step([5.0, 1.0])
+    env.reset()
+    t0 = time.perf_counter()
+    n = 0
+    for ep in range(20):
+        env.reset()
+        for _ in range(51):
+            env.step([5.0, 1.0]); n += 1
+    rate = n / (time.perf_counter() - t0)
+    print(f"facade: {rate:.0f} MR_Env.step/s (resets included)")
+    assert rate > 9500.0

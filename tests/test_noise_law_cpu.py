@@ -35,13 +35,7 @@ def test_collapsed_constants_match_the_tableau():
     assert abs(np.sqrt(cb * cb + (35 / 384) ** 2) - 0.868937) < 1e-6
 
 
-def _rhs_mean(a, a0, mis):
-    """noise-free part of Simulator.simulate (MR_simulator.py:76-83) for actions [n,2]"""
-    f, al = a[:, 0], a[:, 1]
-    if mis:
-        a0b = a0 + (f / 4) * 0.8
-        return np.stack([a0b * f * np.cos(al + 0.1) + 0.2, a0b * f * np.sin(al - 0.15) - 0.1], axis=1)
-    return np.stack([a0 * f * np.cos(al), a0 * f * np.sin(al)], axis=1)
+from tests.increments import rhs_mean as _rhs_mean  # noqa: E402
 
 
 def _run(law, sigma, start, mis, seed=11):
@@ -123,48 +117,20 @@ def test_collapsed_law_equals_per_stage_law_in_distribution(sigma, start, mis):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # sigma > 0 statistics against the REFERENCE's own samples (tests/golden/ref_increments.npz, written by make_golden.py from the
-# imported MR_simulator.Simulator), not only against the formula of SURVEY 3.3
+# imported MR_simulator.Simulator; tests/increments.py holds the comparison): increments AND rk_step attempts, far from the
+# origin, where the first attempt's error_norm is about 1, and where every step is split into 20-50 attempts -- both noise laws
 # ---------------------------------------------------------------------------------------------------------------------
-def normalised_increments(step_fn, n, steps, mis, sigma=1.0, a0=1.0, seed=0):
-    """[steps * n, 2] noise increments Delta - dt (b1 K0 + (1 - b1) V) / (dt cB sqrt(g^2 + sigma^2)) of `step_fn`, an object with
-    .pos() -> [n,2], .k0() -> [n,2] and .step(actions [n,2] float32); shared by the CPU (oracle) and GPU (kernel) tests"""
-    dt, b1, cB = 0.030, 35.0 / 384, 0.8641431770614779
-    rng = np.random.default_rng(seed)
-    out = []
-    for _ in range(steps):
-        a = np.stack([rng.uniform(-20, 20, n), rng.uniform(-2 * np.pi, 2 * np.pi, n)], 1).astype(np.float32)
-        p0, k0 = step_fn.pos().copy(), step_fn.k0().copy()
-        step_fn.step(a)
-        a64 = a.astype(np.float64)
-        V = _rhs_mean(a64, a0, mis)
-        if mis:
-            g = 0.25 * sigma * a64[:, :1] * np.stack([np.cos(a64[:, 1] + 0.1), np.sin(a64[:, 1] - 0.15)], 1)
-        else:
-            g = np.zeros((n, 2))
-        out.append((step_fn.pos() - p0 - dt * (b1 * k0 + (1 - b1) * V)) / (dt * cB * np.sqrt(g * g + sigma * sigma)))
-    return np.concatenate(out)
+from tests import increments as INC  # noqa: E402
 
-
-def check_against_reference_increments(r, mis):
-    """two-sample KS and variance ratio of normalised increments r [m,2] against the reference's sample"""
-    import os
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_increments.npz"))
-    ref = g[("inc_mismatched_s1" if mis else "inc_nominal_s1") + "/res_norm"].astype(np.float64)
-    for j in range(2):
-        p = stats.ks_2samp(r[:, j], ref[:, j]).pvalue
-        ratio = r[:, j].std() / ref[:, j].std()
-        assert p > 1e-3, (mis, j, p)
-        assert abs(ratio - 1.0) < 0.02, (mis, j, ratio)                # the reference sample's own standard error: 0.5 %
-        assert abs(r[:, j].mean()) < 0.02
-    # x-y correlation: none under the nominal law; the mismatched law's shared a0 draw correlates them (about -0.11 over the actor range)
-    assert abs(np.corrcoef(r[:, 0], r[:, 1])[0, 1] - np.corrcoef(ref[:, 0], ref[:, 1])[0, 1]) < 0.03
+# sample sizes of the oracle's side (envs = independent episodes, steps per episode as in the fixture)
+ORACLE_ENVS = {"far": 100000, "mid": 250000, "origin": 100000, "near": 100000}
 
 
 class _OracleSteps:
-    def __init__(self, n, law, mis, seed):
+    def __init__(self, n, law, mis, seed, start=(110.0, 115.0)):
         p = O.default_params(sigma=1.0, mismatched=int(mis), noise_law=law)
         self.orc = O.VecOracle(n, p, seed=seed, threads=8)
-        self.orc.reset(0, init_xy=np.tile([[110.0, 115.0]], (n, 1)))
+        self.orc.reset(0, init_xy=np.tile([list(start)], (n, 1)))    # a fresh env: nominal-law constructor (MR_env.py:181-183)
         self.t = 0
 
     def pos(self):
@@ -173,13 +139,23 @@ class _OracleSteps:
     def k0(self):
         return self.orc.envs["f"]
 
+    def attempts(self):
+        return self.orc.envs["n_attempts"]
+
     def step(self, a):
         self.t += 1
         self.orc.step(a, step_idx=self.t)
 
 
-@pytest.mark.parametrize("law", [O.LAW_PER_STAGE, O.LAW_COLLAPSED])
-@pytest.mark.parametrize("mis", [False, True])
-def test_oracle_increments_match_the_reference_sample(law, mis):
-    r = normalised_increments(_OracleSteps(4000, law, mis, seed=21), 4000, 10, mis)
-    check_against_reference_increments(r, mis)
+@pytest.mark.parametrize("law", [O.LAW_PER_STAGE, O.LAW_COLLAPSED], ids=["per_stage", "collapsed"])
+@pytest.mark.parametrize("mis", [False, True], ids=["nominal", "mismatched"])
+@pytest.mark.parametrize("regime", INC.REGIMES)
+def test_oracle_increments_and_attempts_match_the_reference_sample(regime, law, mis):
+    ref = INC.reference(regime, mis)
+    n, steps = ORACLE_ENVS[regime], int(ref["steps"])
+    if regime == "far":
+        steps = 20        # iid steps: pooled (the fixture's 100-step restarts are pooled the same way)
+    st = _OracleSteps(n, law, mis, seed=21 + 7 * law, start=tuple(ref["start"]))
+    resn, att = INC.draw(st, n, steps, mis, seed=5 + law)
+    out = INC.compare(regime, mis, resn, att, label=f"oracle law={law}")
+    assert out["tol"] <= 0.02
