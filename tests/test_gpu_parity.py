@@ -24,9 +24,29 @@ POS_TOL = 1e-6
 POS_TOL_FAST = 5e-6
 
 
+# The library's default noise law is the collapsed one (ABI 5); the per-stage law (one draw per RHS evaluation, the layout of the
+# oracle's tape replays) keeps its element-wise coverage: tests marked with the `both_laws` fixture run once per law, _mk() builds
+# env and oracle under the law of the running test unless the test names one itself.
+_LAW = {"current": None}
+
+
+@pytest.fixture(params=["collapsed", "per_stage"])
+def both_laws(request):
+    _LAW["current"] = request.param
+    yield request.param
+    _LAW["current"] = None
+
+
+def _law():
+    """MRConfig keyword of the running test's noise law ({} outside a both_laws test: the library default)"""
+    return {} if _LAW["current"] is None else {"noise_law": _LAW["current"]}
+
+
 def _mk(n, seed=0, goal_table=None, **cfg_kw):
     import torch
     from mr_rl_amd import MRConfig, MRVecEnv
+    if _LAW["current"] is not None:
+        cfg_kw.setdefault("noise_law", _LAW["current"])
     cfg = MRConfig(**cfg_kw)
     env = MRVecEnv(n, cfg=cfg, seed=seed, goal_table=goal_table, track_state_prime=True, track_actions=True)
     gK, gT = (1, 1) if goal_table is None else (env._gK, env._gT)
@@ -157,7 +177,7 @@ def test_step_vs_oracle_sigma0(mis, layout):
 
 @pytest.mark.parametrize("math", ["spec", "fast"])
 @pytest.mark.parametrize("mis", [False, True])
-def test_step_vs_oracle_noise_far(mis, math):
+def test_step_vs_oracle_noise_far(mis, math, both_laws):
     """sigma = 1 in the DDPG regime (|y| ~ 100): identical seeds => identical normals => same
     trajectories up to the fp32 carry of f0."""
     n, T = 2048 + 37, 60
@@ -176,7 +196,7 @@ def test_step_vs_oracle_noise_far(mis, math):
 
 
 @pytest.mark.parametrize("mis", [False, True])
-def test_step_vs_oracle_noise_near_origin(mis):
+def test_step_vs_oracle_noise_near_origin(mis, both_laws):
     """sigma > 0 near the origin: the error controller splits steps (tens of rk_step attempts, a data-dependent
     loop).  The accept / reject decision is discontinuous in error_norm at 1, and the kernel carries K0 / h_abs in
     fp32 (6e-8 relative), so an attempt whose error_norm lies within ~1e-7 of 1 may be decided differently; from
@@ -211,7 +231,7 @@ def test_step_vs_oracle_noise_near_origin(mis):
 
 
 @pytest.mark.parametrize("math", ["spec", "fast"])
-def test_random_policy_and_autoreset_vs_oracle(math):
+def test_random_policy_and_autoreset_vs_oracle(math, both_laws):
     """BASELINE config 4 shape at a size the oracle finishes in seconds: random policy drawn on
     device, sigma = 1, reward + done on device, auto-reset (every 51 steps), 2 episodes."""
     n, T = 4096, 110
@@ -263,7 +283,7 @@ def test_goal_reward_and_termination_cases():
     assert int(np.argmax(g["done"])) + 1 == 17 and g["calc_reward"][16] == 100
 
 
-def test_goal_table_mixed_trajectories():
+def test_goal_table_mixed_trajectories(both_laws):
     """BASELINE config 5 'mixed trajectory set': goal = reference trajectory table[env_id mod K][counter]."""
     K, T = 3, 40
     tab = np.zeros((K, T, 2), dtype=np.float32)
@@ -327,7 +347,7 @@ def test_euler_bit_stability_config2():
 
 
 @pytest.mark.parametrize("mis", [False, True])
-def test_rollout_equals_steps(mis):
+def test_rollout_equals_steps(mis, both_laws):
     """The fused rollout kernel is bit-identical to T single-step launches (sigma > 0, auto-reset).  The
     rollout does not ask for state_prime, so it takes the lazy K6 / F1 paths that the step path (which
     always evaluates F1) does not: equal bits prove the laziness changes no outcome, for both noise laws."""
@@ -350,7 +370,7 @@ def test_rollout_equals_steps(mis):
     assert (e1.final_len == 51).all() and (e1.final_ret == 510).all()
 
 
-def test_sharding_invariance():
+def test_sharding_invariance(both_laws):
     """Global-env-id RNG keys: a shard [k, k+m) reproduces exactly the rows of the unsharded run."""
     n = 2048
     torch, full, _ = _mk(n, seed=42, noise_var=1.0, auto_reset=True)
@@ -359,7 +379,7 @@ def test_sharding_invariance():
         full.step(None)
     import mr_rl_amd
     for lo, m in [(0, 512), (512, 1024), (1536, 512)]:
-        sh = mr_rl_amd.MRVecEnv(m, cfg=mr_rl_amd.MRConfig(noise_var=1.0, auto_reset=True), seed=42, env_id0=lo)
+        sh = mr_rl_amd.MRVecEnv(m, cfg=mr_rl_amd.MRConfig(noise_var=1.0, auto_reset=True, **_law()), seed=42, env_id0=lo)
         sh.reset()
         for _ in range(60):
             sh.step(None)
@@ -537,7 +557,7 @@ def test_learn_a0_from_simulated_circles():
     assert abs(float(a0.mean()) / (1.5 * 0.9) - 1) < 0.02
 
 
-def test_graph_replay_draws_fresh_noise_and_matches_eager():
+def test_graph_replay_draws_fresh_noise_and_matches_eager(both_laws):
     """hipGraph-captured steps: kernel arguments are frozen at capture, the RNG step index lives in a device
     word (MrsimParams.step_base) advanced inside the graph -> every replay draws new noise, and the sequence
     is bit-identical to the same steps launched eagerly."""
@@ -545,8 +565,8 @@ def test_graph_replay_draws_fresh_noise_and_matches_eager():
     from mr_rl_amd import MRConfig, MRVecEnv
     n, G = 2048, 17
     cfg = dict(noise_var=1.0, auto_reset=True)
-    e1 = MRVecEnv(n, cfg=MRConfig(**cfg), seed=5); e1.reset()
-    e2 = MRVecEnv(n, cfg=MRConfig(**cfg), seed=5); e2.reset()
+    e1 = MRVecEnv(n, cfg=MRConfig(**cfg, **_law()), seed=5); e1.reset()
+    e2 = MRVecEnv(n, cfg=MRConfig(**cfg, **_law()), seed=5); e2.reset()
     g = e1.capture_steps(G, policy="kernel")     # warm-up inside capture_steps already ran G real steps
     for _ in range(G):
         e2.step(e2.random_policy())
@@ -563,17 +583,17 @@ def test_graph_replay_draws_fresh_noise_and_matches_eager():
     assert int(e1._step_base.item()) == 1 + 4 * G
 
 
-def test_state_dict_roundtrip_resumes_bitwise():
+def test_state_dict_roundtrip_resumes_bitwise(both_laws):
     import torch
     from mr_rl_amd import MRConfig, MRVecEnv
     n = 1000
-    a = MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=9); a.reset()
+    a = MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True, **_law()), seed=9); a.reset()
     for _ in range(30):
         a.step(None)
     sd = a.state_dict()
     for _ in range(40):
         a.step(None)
-    b = MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True), seed=0)
+    b = MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True, **_law()), seed=0)
     b.load_state_dict(sd)
     for _ in range(40):
         b.step(None)
@@ -666,7 +686,7 @@ def test_event_attached_launch_times_the_kernel_without_blocking():
 @pytest.mark.parametrize("math", ["fast", "spec"])
 @pytest.mark.parametrize("mis", [False, True])
 @pytest.mark.parametrize("mixed", [False, True, "soa"])
-def test_flag_specialised_rollout_kernels_equal_the_step_path(mixed, mis, math):
+def test_flag_specialised_rollout_kernels_equal_the_step_path(mixed, mis, math, both_laws):
     """When a launch's flags word is the DDPG-rollout pattern (or the same on a goal table with the goal reward) the
     host picks a compile-time-specialised mr_rollout_kernel<.., FL>.  Same source, `fl &` tests folded: it has to give
     the bits of the generic step kernel.  want=(obs, rew, done, actions) is exactly that pattern."""
@@ -697,13 +717,13 @@ def test_flag_specialised_rollout_kernels_equal_the_step_path(mixed, mis, math):
 
 
 @pytest.mark.parametrize("mis", [False, True])
-def test_flag_specialised_step_kernel_equals_the_generic_one(mis):
+def test_flag_specialised_step_kernel_equals_the_generic_one(mis, both_laws):
     """The gym loop's launch pattern (actions from a policy, no state_prime / actions_out tracking) selects
     mr_step_kernel<.., FL>; a tracking env takes the generic instantiation.  Same bits, also across auto-resets."""
     import torch
     from mr_rl_amd import MRConfig, MRVecEnv
     n, T = 3000, 60
-    mk = lambda **kw: MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True, is_mismatched=mis), seed=33, **kw)  # noqa: E731
+    mk = lambda **kw: MRVecEnv(n, cfg=MRConfig(noise_var=1.0, auto_reset=True, is_mismatched=mis, **_law()), seed=33, **kw)  # noqa: E731
     e1, e2 = mk(), mk(track_state_prime=True, track_actions=True)
     e1.reset(); e2.reset()
     for t in range(T):
@@ -722,7 +742,7 @@ def test_flag_specialised_step_kernel_equals_the_generic_one(mis):
 
 
 @pytest.mark.parametrize("mis", [False, True])
-def test_full_size_properties_config5_mixed_set(mis):
+def test_full_size_properties_config5_mixed_set(mis, both_laws):
     """BASELINE config 5's per-GPU shard (N = 262 144, mixed trajectory set, goal reward) through the fused rollout,
     checked by properties that do not need the oracle at this size: the recorded rewards add up to the episode
     returns the kernel reports, observations are consistent (obs[4] = |goal - pos|, goal = table[env mod 3][counter]),
@@ -738,7 +758,7 @@ def test_full_size_properties_config5_mixed_set(mis):
     th = 2 * np.pi * k / 52
     tab[1, :, 0] = 110 + 8 * np.sin(th); tab[1, :, 1] = 110 + 8 * np.sin(th) * np.cos(th)
     tab[2] = rng.uniform(100, 120, (52, 2))
-    cfg = lambda: MRConfig(noise_var=1.0, auto_reset=True, reward_mode="goal", min_dist2goal=1.0, is_mismatched=mis)  # noqa: E731
+    cfg = lambda: MRConfig(noise_var=1.0, auto_reset=True, reward_mode="goal", min_dist2goal=1.0, is_mismatched=mis, **_law())  # noqa: E731
     env = MRVecEnv(n, cfg=cfg(), seed=7, goal_table=tab)
     env.reset()
     out = env.rollout(T, actions=None, want=("obs", "rew", "done", "actions"))
@@ -780,7 +800,7 @@ def test_full_size_properties_config5_mixed_set(mis):
 
 @pytest.mark.parametrize("math,mis,carry", [("fast", False, "f32"), ("spec", False, "f32"), ("fast", True, "f32"),
                                             ("fast", False, "f64"), ("fast", True, "f64")])
-def test_full_size_rollout_vs_oracle_config4(math, mis, carry):
+def test_full_size_rollout_vs_oracle_config4(math, mis, carry, both_laws):
     """BASELINE config 4 at its FULL size against the oracle itself (the GPU box's host cores make that a matter of
     seconds): 262 144 envs, sigma = 1, random policy drawn on device, one whole episode + the auto-reset step through
     the fused (flag-specialised) rollout kernel; the oracle steps the same envs with the same Philox policy.
@@ -810,7 +830,7 @@ def test_full_size_rollout_vs_oracle_config4(math, mis, carry):
     env.check_status()
 
 
-def test_full_size_rollout_vs_oracle_config5_shard():
+def test_full_size_rollout_vs_oracle_config5_shard(both_laws):
     """One rank's shard of BASELINE config 5 (262 144 envs of the mixed trajectory set, goal reward, global env ids
     offset as on rank 3 of 8) element-wise against the oracle over one episode + the auto-reset step."""
     n, T, id0 = 262144, 52, 3 * 262144
@@ -823,7 +843,7 @@ def test_full_size_rollout_vs_oracle_config5_shard():
     tab[2] = np.random.default_rng(7).uniform(100, 120, (52, 2))
     import torch
     from mr_rl_amd import MRConfig, MRVecEnv
-    cfg = MRConfig(noise_var=1.0, auto_reset=True, reward_mode="goal", min_dist2goal=1.0)
+    cfg = MRConfig(noise_var=1.0, auto_reset=True, reward_mode="goal", min_dist2goal=1.0, **_law())
     env = MRVecEnv(n, cfg=cfg, seed=7, env_id0=id0, goal_table=tab)
     orc = O.VecOracle(n, orc_params_from_cfg(cfg, 3, 52), seed=7, env_id0=id0, goal_table=tab, threads=threads)
     og = env.reset(); oo = orc.reset(0)

@@ -67,7 +67,7 @@ def test_collapsed_step_vs_oracle_far(mis, math):
 def test_collapsed_law_differs_from_per_stage_law():
     """same seed, different law: different numbers (the two are equal in distribution only), same exploration actions"""
     n = 4096
-    torch, e1, _ = _mk(n, seed=3, noise_var=1.0, auto_reset=True)
+    torch, e1, _ = _mk(n, seed=3, noise_var=1.0, auto_reset=True, noise_law="per_stage")
     _, e2, _ = _mk(n, seed=3, noise_var=1.0, auto_reset=True, noise_law="collapsed")
     e1.reset(); e2.reset()
     o1 = e1.rollout(20, want=("obs", "actions"))
