@@ -136,8 +136,9 @@ def parse(argv=None):
     ap.add_argument("--no-facade-leg", action="store_true", help="skip the single-env MR_Env.step() drop-in measurement")
     ap.add_argument("--no-streaming-point", action="store_true", help="skip the N = 2 097 152 single-GPU streaming point (SURVEY H4)")
     ap.add_argument("--no-partition-row", action="store_true",
-                    help="learner leg without its compute-unit-partition row (rocprofv3's kernel trace of ROCm 7.2 crashes at exit "
-                         "when the process has created CU-masked streams)")
+                    help="learner leg without its compute-unit-partition row (round 4 needed this under rocprofv3 --kernel-trace: "
+                         "CU-masked streams left alive at interpreter exit crash the profiler's exit path; they are destroyed in "
+                         "order now -- profiles/r05/partition_kt.txt -- and the flag is no longer used by tools/profile_round.sh)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--master-port", type=int, default=0, help="--gpus N launcher: rendezvous port (0 = pick a free one)")
@@ -728,10 +729,23 @@ def measure_learner(args, n_local, dev, seed, streams):
     ups["fused_kernel"] = rate(lambda n: [ag.update() for _ in range(n)], 3000)
     # the form train_collected uses: a burst of updates per launch (the kernel loops; one host call per burst)
     ups["fused_kernel_8_per_launch"] = rate(lambda n: [ag.update_graphed(8) for _ in range(n // 8)], 3200)
+    # large batches: batch / 64 workgroups on as many compute units (two launches per update) against the single workgroup looping
+    # over the tiles -- what lets a 262 144-env collector's data be used at more than one 64-row batch per ~40 us
+    big = {}
+    for B in (64, 256, 1024, 4096):
+        row = {}
+        for multi in ((True, False) if B > 64 else (False,)):
+            agb = filled(fused=True, min_batch=B)
+            agb.fused.multi_workgroup = multi
+            n_upd = 400 if (multi or B <= 256) else 60
+            r_ = rate(lambda n: [agb.update() for _ in range(n)], n_upd)
+            row["multi_workgroup" if multi else "single_workgroup"] = {"updates_per_s": round(r_, 1), "us_per_update": round(1e6 / r_, 1),
+                                                                       "transitions_per_s": round(r_ * B, 1)}
+        big[str(B)] = row
     out = {"what": "the DDPG learner: updates/s on a filled ring (batch 64, the reference's) and env-steps/s of the whole loop "
                    "(collection with the actor in the kernel + learner) at a stated update : transition ratio",
            "batch": 64, "updates_per_s": {k: round(v, 1) for k, v in ups.items()},
-           "us_per_update": {k: round(1e6 / v, 1) for k, v in ups.items()}, "end_to_end": []}
+           "us_per_update": {k: round(1e6 / v, 1) for k, v in ups.items()}, "by_batch": big, "end_to_end": []}
     ep = cfg.max_timesteps + 1
     # learner_cus = 1: the learner's launches on 8 compute units of their own (one per XCC), the collection on the other 248
     # (mr_rl_amd.partition) -- reported beside the shared-device rows
@@ -743,9 +757,7 @@ def measure_learner(args, n_local, dev, seed, streams):
         st = {}
         rets = agent.train_collected(episodes, updates_per_episode=U, sample=4096, streams=streams, math=math, stats=st, warm_episodes=10,
                                      learner_cus=cus)
-        if getattr(agent, "partition", None) is not None:
-            torch.cuda.synchronize(dev)
-            agent.partition.close()
+        agent.close()    # the partition's streams go last, after everything that names them (DDPG.close; profiles/r05/partition_kt.txt)
         out["end_to_end"].append({
             "actor_math": math, "updates_per_episode": U, "learner_compute_units": 8 * cus if cus else "shared",
             "transitions_per_episode": n_local * ep,

@@ -251,11 +251,20 @@ typedef struct MrsimDdpgLearner {
     float critic_lr;         /* 1e-2   :342                                                                               */
     float beta1, beta2, adam_eps; /* 0.9, 0.999, 1e-8 (Adam defaults)                                                     */
     float action_bound[2];   /* :345 env.action_space.high                                                                */
+    float* batch_scratch;    /* DEVICE, 16-byte aligned, ZERO-INITIALISED once by the caller, or NULL (ABI 5): work space of the  */
+                             /*   multi-workgroup form -- with it, a batch of more than 64 transitions runs as batch / 64         */
+                             /*   workgroups on as many compute units (two launches per update: the critic's step needs the      */
+                             /*   whole batch's gradient, the actor's gradient the updated critic) instead of one workgroup      */
+                             /*   looping over the tiles; results are deterministic (partial gradients summed in tile order)     */
+    int64_t batch_scratch_floats; /* its size in floats: >= MRSIM_DDPG_BATCH_SCRATCH_FLOATS(batch)                                 */
 } MrsimDdpgLearner;
-/* One update on `batch` transitions (a multiple of 64, <= MRSIM_DDPG_MAX_BATCH; the reference uses 64).  s / s2 [.][5], a [.][2],
+#define MRSIM_DDPG_BATCH_SCRATCH_FLOATS(batch) ((int64_t)((batch) / 64) * (MRSIM_DDPG_PARAMS + 4) + (batch) + 64)
+/* One update on `batch` transitions (a multiple of 64, <= MRSIM_DDPG_MAX_BATCH; the reference uses 64; batches above 64 spread over
+ * batch / 64 compute units when learner->batch_scratch is given, see there).  s / s2 [.][5], a [.][2],
  * r [.], done [.] are DEVICE arrays (e.g. the replay ring).  Which rows: idx (DEVICE [batch] int32) if given; else, with
  * ring_count > 0, drawn IN the kernel from [0, ring_count) by Philox4x32-10 keyed by (seed, draw_counter) -- without
- * repetition, the law of random.sample (RL/MR_ddpg.py:37-44), for batch <= 256 <= ring_count, with repetition otherwise;
+ * repetition, the law of random.sample (RL/MR_ddpg.py:37-44), for batch <= 256 and batch <= ring_count (a partial Fisher-Yates
+ * shuffle while the ring holds fewer than two batches, redrawn duplicates beyond), with repetition otherwise;
  * else rows 0 .. batch-1.  n_updates >= 1 consecutive updates run in this ONE launch (update i draws with draw_counter + i; with idx
  * or fixed rows every update sees the same batch): the learner then occupies one compute unit for the whole burst instead of
  * queueing n launches behind a device full of env kernels.  idx_out: optional DEVICE [batch] int32, the rows of the last update.

@@ -17,6 +17,11 @@ ACTOR_HIDDEN, ACTOR_BLOB_FLOATS = 64, 10888
 ACTOR_F32, ACTOR_BF16X3, ACTOR_BF16 = 0, 1, 2
 DDPG_PARAMS, DDPG_MAX_BATCH = 7680, 4096
 
+
+def ddpg_batch_scratch_floats(batch):
+    """MRSIM_DDPG_BATCH_SCRATCH_FLOATS(batch) of include/mrsim.h"""
+    return (int(batch) // 64) * (DDPG_PARAMS + 4) + int(batch) + 64
+
 # every symbol include/mrsim.h declares -- the product ABI (tests check the .so exports exactly these + BENCH_SYMBOLS)
 PRODUCT_SYMBOLS = (
     "mrsim_abi_version", "mrsim_strerror", "mrsim_default_params", "mrsim_reset", "mrsim_step",
@@ -68,7 +73,8 @@ class MrsimDdpgLearner(C.Structure):
     _fields_ = [("online", C.c_void_p), ("target", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p),
                 ("grad_scratch", C.c_void_p), ("steps", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_eps", C.c_float),
                 ("gamma", C.c_float), ("tau", C.c_float), ("actor_lr", C.c_float), ("critic_lr", C.c_float), ("beta1", C.c_float),
-                ("beta2", C.c_float), ("adam_eps", C.c_float), ("action_bound", C.c_float * 2)]
+                ("beta2", C.c_float), ("adam_eps", C.c_float), ("action_bound", C.c_float * 2),
+                ("batch_scratch", C.c_void_p), ("batch_scratch_floats", C.c_int64)]
 
 
 class MrsimStepIO(C.Structure):

@@ -1386,19 +1386,45 @@ int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, int32_t n_updat
     if (!(Lr->bn_eps > 0.0f) || !(Lr->beta1 >= 0.0f && Lr->beta1 < 1.0f) || !(Lr->beta2 >= 0.0f && Lr->beta2 < 1.0f)) return MRSIM_EINVAL;
     int rc = check_device();
     if (rc) return rc;
-    // the kernel's LDS image (sizeof(learner::Lds), ~153 KB) is above the default dynamic limit; the attribute is per device
-    // (and the call is cheap and idempotent), so it is set on every call for whichever device is current
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(learner::mr_ddpg_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(learner::Lds)) != hipSuccess) {
-        (void)hipGetLastError();
-        return MRSIM_ELAUNCH;
+    const int tiles = batch / learner::kTile;
+    const bool multi = tiles > 1 && Lr->batch_scratch != nullptr;
+    if (multi) {
+        if (!aligned16(Lr->batch_scratch)) return MRSIM_EALIGN;
+        if (Lr->batch_scratch_floats < MRSIM_DDPG_BATCH_SCRATCH_FLOATS(batch)) return MRSIM_EINVAL;
     }
+    // the kernels' LDS image (sizeof(learner::Lds), ~153 KB) is above the default dynamic limit; the attribute is per device
+    // (and the call is cheap and idempotent), so it is set on every call for whichever device is current
+    const void* kerns[3] = {reinterpret_cast<const void*>(learner::mr_ddpg_update_kernel), reinterpret_cast<const void*>(learner::mr_ddpg_mw_critic_kernel),
+                            reinterpret_cast<const void*>(learner::mr_ddpg_mw_actor_kernel)};
+    for (int k = multi ? 1 : 0; k < (multi ? 3 : 1); ++k)
+        if (hipFuncSetAttribute(kerns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(learner::Lds)) != hipSuccess) {
+            (void)hipGetLastError();
+            return MRSIM_ELAUNCH;
+        }
     learner::Args A{Lr->online, Lr->target, Lr->adam_m, Lr->adam_v, Lr->grad_scratch, Lr->steps, Lr->bn_stats, s, a, r, done, s2, idx,
                     idx_out, ring_count, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)draw_counter, (uint32_t)(draw_counter >> 32),
                     losses_out, batch, n_updates, Lr->bn_eps, Lr->gamma, Lr->tau, Lr->actor_lr, Lr->critic_lr, Lr->beta1, Lr->beta2, Lr->adam_eps,
-                    Lr->action_bound[0], Lr->action_bound[1]};
-    hipLaunchKernelGGL(learner::mr_ddpg_update_kernel, dim3(1), dim3(learner::kThreads), sizeof(learner::Lds),
-                       static_cast<hipStream_t>(stream), A);
+                    Lr->action_bound[0], Lr->action_bound[1], nullptr, nullptr, nullptr, nullptr};
+    if (!multi) {
+        hipLaunchKernelGGL(learner::mr_ddpg_update_kernel, dim3(1), dim3(learner::kThreads), sizeof(learner::Lds),
+                           static_cast<hipStream_t>(stream), A);
+        return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+    }
+    // scratch layout: [tiles][kParams] partial gradients | [batch] rows | [tiles][2] partial losses | [2] arrival counters
+    float* sc = Lr->batch_scratch;
+    A.partial = sc;
+    A.rows_scratch = reinterpret_cast<int32_t*>(sc + (size_t)tiles * learner::kParams);
+    A.loss_partial = sc + (size_t)tiles * learner::kParams + batch;
+    A.counter = reinterpret_cast<unsigned int*>(sc + (size_t)tiles * learner::kParams + batch + 2 * (size_t)tiles);
+    A.n_updates = 1;
+    for (int u = 0; u < n_updates; ++u) {
+        const uint64_t c = draw_counter + (uint64_t)u;
+        A.ctr_lo = (uint32_t)c; A.ctr_hi = (uint32_t)(c >> 32);
+        hipLaunchKernelGGL(learner::mr_ddpg_mw_critic_kernel, dim3(tiles), dim3(learner::kThreads), sizeof(learner::Lds),
+                           static_cast<hipStream_t>(stream), A);
+        hipLaunchKernelGGL(learner::mr_ddpg_mw_actor_kernel, dim3(tiles), dim3(learner::kThreads), sizeof(learner::Lds),
+                           static_cast<hipStream_t>(stream), A);
+    }
     return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 

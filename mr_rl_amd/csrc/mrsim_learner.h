@@ -50,6 +50,11 @@ struct Args {
     int32_t n_updates;              // consecutive updates in this one launch (each draws its own rows: draw counter + i)
     float bn_eps, gamma, tau, actor_lr, critic_lr, beta1, beta2, adam_eps;
     float bound0, bound1;
+    // multi-workgroup form (batch > 64 with MrsimDdpgLearner.batch_scratch): one workgroup per tile of 64 samples
+    float* partial;                 // [tiles][kParams]: every workgroup's gradients of its tile
+    int32_t* rows_scratch;          // [batch]: the rows of this update (critic half -> actor half)
+    float* loss_partial;            // [tiles][2]
+    unsigned int* counter;          // [2]: arrival tickets of the two halves (zero between launches)
 };
 
 // C[m0 .. m0+TM)[n0 .. n0+TN) = sum_k A(m, k) B(k, n).  B is k-major ([K][ldb], n contiguous).  A is k-major ([K][lda], m
@@ -274,11 +279,54 @@ __device__ __forceinline__ void adam_soft(const Args& A, float lr, float bc1, fl
 #define LPROBE(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    Lds& L = *reinterpret_cast<Lds*>(lds_raw);
+// Large batches across compute units.  One update has two grid-wide dependencies -- the critic's Adam step needs the gradient of
+// the WHOLE batch, and the actor's gradient is taken against the UPDATED critic (RL/MR_ddpg.py:297-302) -- so the multi-workgroup
+// form is two launches of batch / 64 workgroups: MODE 1 = targets + critic forward / backward of the workgroup's tile, MODE 2 = actor
+// forward, critic forward, backward through both.  Every workgroup leaves its tile's gradients in its own row of `partial`; the
+// workgroup that ARRIVES LAST (a ticket from one atomic; nobody spins, so the grid needs no co-residency and cannot deadlock on a
+// partitioned or busy device) sums the rows in workgroup order -- deterministic -- and does the Adam step and the soft update.
+// MODE 0 = the single-workgroup kernel: all tiles in a loop, n_updates per launch.
+enum { kModeAll = 0, kModeCriticHalf = 1, kModeActorHalf = 2 };
+
+// the last workgroup to arrive: true for it alone, after the other workgroups' rows of `partial` have become visible
+__device__ __forceinline__ bool mw_arrive_last(const Args& A, Lds& L, int slot, int tid) {
+    __threadfence();                      // this workgroup's gradients, device-wide (L2 write-back across XCDs)
+    __syncthreads();
+    if (tid == 0) L.rows[0] = atomicAdd(A.counter + slot, 1u) == gridDim.x - 1u ? 1 : 0;
+    __syncthreads();
+    const bool last = L.rows[0] != 0;
+    __syncthreads();
+    if (last) __threadfence();            // acquire side: nothing of `partial` is read from a stale line
+    return last;
+}
+
+// grad[P0, P1) = sum over the workgroups' rows, in workgroup order; loss likewise
+template <int P0, int P1>
+__device__ __forceinline__ void mw_reduce(const Args& A, Lds& L, int which_loss, int tid) {
+    const int G = (int)gridDim.x;
+    for (int p = P0 + tid * 4; p < P1; p += kThreads * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < G; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(A.partial + (size_t)g * kParams + p);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(A.grad + p) = acc;
+    }
+    if (tid == 0) {
+        float l = 0.f;
+        for (int g = 0; g < G; ++g) l += A.loss_partial[g * 2 + which_loss];
+        L.loss[which_loss] = l;
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+template <int MODE>
+__device__ __forceinline__ void ddpg_update_body(const Args& A, Lds& L) {
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int ntiles = A.batch / kTile;
+    const int t0 = MODE == kModeAll ? 0 : (int)blockIdx.x, t1 = MODE == kModeAll ? ntiles : (int)blockIdx.x + 1;   // this workgroup's tiles
+    float* const G_ = MODE == kModeAll ? A.grad : A.partial + (size_t)blockIdx.x * kParams;                        // where its gradients go
     const float invB = 1.0f / (float)A.batch;
     float* X0 = L.X[0]; float* X1 = L.X[1]; float* X2 = L.X[2]; float* X3 = L.X[3]; float* X4 = L.X[4];
 
@@ -290,8 +338,9 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
         return (int)(((unsigned long long)o[0] * (unsigned long long)(uint32_t)A.ring_count) >> 32);
     };
     const bool sampled = A.idx == nullptr && A.ring_count > 0;
-    const bool one_tile = ntiles == 1;
-  for (int upd = 0; upd < A.n_updates; ++upd) {   // (body not re-indented: one update = everything down to the closing brace)
+    const bool one_tile = t1 - t0 == 1;
+    const int n_upd = MODE == kModeAll ? A.n_updates : 1;     // (the host launches the two halves once per update)
+  for (int upd = 0; upd < n_upd; ++upd) {   // (body not re-indented: one update = everything down to the closing brace)
 #ifdef MRSIM_LEARNER_PROBE
     const unsigned long long lprobe_t0 = __builtin_readcyclecounter();
 #endif
@@ -299,12 +348,40 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
         const unsigned long long c = (((unsigned long long)A.ctr_hi << 32) | A.ctr_lo) + (unsigned long long)upd;
         c_lo = (uint32_t)c; c_hi = (uint32_t)(c >> 32);
     }
-    if (sampled) {
-        for (int q = tid; q < A.batch; q += kThreads) L.sel[q] = draw(q, 0u);
+    if (sampled && MODE != kModeActorHalf) {
+        // (multi-workgroup form: every workgroup draws the same list -- the duplicate check below needs all of it up to 256 rows;
+        // beyond, rows are independent and a workgroup draws its own tile's)
+        const int q0 = (MODE == kModeAll || A.batch <= 256) ? 0 : t0 * kTile, q1 = (MODE == kModeAll || A.batch <= 256) ? A.batch : t1 * kTile;
+        for (int q = q0 + tid; q < q1; q += kThreads) L.sel[q] = draw(q, 0u);
         __syncthreads();
-        if (A.batch <= 256 && A.ring_count >= A.batch) {
+        if (A.batch <= 256 && A.ring_count >= A.batch && A.ring_count < 2 * A.batch) {
+            // random.sample's law (RL/MR_ddpg.py:37-44) on a ring that holds fewer than two batches (the first updates of a run:
+            // DDPG.train starts learning at min_batch = 64 stored transitions): redrawing duplicates would need ~ring_count rounds
+            // when nearly every row must be taken, so the rows come from a partial Fisher-Yates shuffle of [0, ring_count)
+            // instead -- exact, no rejection.  perm (< 512 entries) and the batch's Philox words live in the unused tail of sel;
+            // the swaps are sequential (one lane, <= 256 LDS swaps: a few microseconds on a path a run takes a handful of times).
+            int* const perm = &L.sel[1024];
+            uint32_t* const uw = reinterpret_cast<uint32_t*>(&L.sel[2048]);
+            for (int q = tid; q < A.ring_count; q += kThreads) perm[q] = q;
+            for (int q = tid; q < A.batch; q += kThreads) {
+                uint32_t o[4];
+                philox4x32_10((uint32_t)q, 0x46595348u /* "FYSH" */, c_lo, c_hi, A.seed_lo, A.seed_hi, o);
+                uw[q] = o[0];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int j = 0; j < A.batch; ++j) {
+                    const int r = j + (int)(((unsigned long long)uw[j] * (unsigned long long)(uint32_t)(A.ring_count - j)) >> 32);
+                    const int pj = perm[j], pr = perm[r];
+                    perm[j] = pr; perm[r] = pj;
+                    L.sel[j] = pr;
+                }
+            }
+            __syncthreads();
+        } else if (A.batch <= 256 && A.ring_count >= A.batch) {
             // random.sample's law (RL/MR_ddpg.py:37-44): no row twice.  A draw that repeats an EARLIER one is redrawn until the set
-            // is distinct (rejection keeps the joint law uniform over ordered samples without repetition); bounded rounds.
+            // is distinct (rejection keeps the joint law uniform over ordered samples without repetition).  With ring_count >= 2 batch
+            // a redraw collides with probability < 1/2: 63 rounds leave a duplicate with probability < 2^-55.
             for (uint32_t round = 1; round < 64u; ++round) {
                 int dup = 0;
                 if (tid < A.batch) {
@@ -326,8 +403,10 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
         if (one_tile && !force) return;            // a single tile stays in LDS for all three phases
         if (tid < kTile) {
             const int q = tile * kTile + tid;
-            L.rows[tid] = A.idx != nullptr ? A.idx[q] : (sampled ? L.sel[q] : q);
-            if (A.idx_out != nullptr) A.idx_out[q] = L.rows[tid];
+            if constexpr (MODE == kModeActorHalf) L.rows[tid] = A.rows_scratch[q];        // what the critic half trained on
+            else L.rows[tid] = A.idx != nullptr ? A.idx[q] : (sampled ? L.sel[q] : q);
+            if constexpr (MODE == kModeCriticHalf) A.rows_scratch[q] = L.rows[tid];
+            if (MODE != kModeActorHalf && A.idx_out != nullptr) A.idx_out[q] = L.rows[tid];
         }
         __syncthreads();
         for (int q = tid; q < kTile * 5; q += kThreads) {
@@ -361,10 +440,11 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
         L.bc[tid * 2 + 1] = (float)sqrt(1.0 - ipow((double)A.beta2, t));
     }
     // ------------------------------------------------------------------------------------------------ targets y
+  if constexpr (MODE != kModeActorHalf) {
     stage_params(L, A.target, A.bn + 3 * 2 * 64, A.bn_eps, tid);
     __syncthreads();
     LPROBE(1);   // target networks staged
-    for (int tile = 0; tile < ntiles; ++tile) {
+    for (int tile = t0; tile < t1; ++tile) {
         load_tile(tile, true);
         layer1(L, L.s2, A_W1, A_B1, A_G1, A_BE1, 0, X0, nullptr, tid);                      // mu'(s2): layer 1
         __syncthreads();
@@ -409,7 +489,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
         if (tid < kTile) {
             float q2 = L.P[C_BO];
             for (int q = 0; q < 16; ++q) q2 += X2[q * 64 + tid];
-            L.y[tile * kTile + tid] = __builtin_fmaf(A.gamma * q2, 1.0f - L.d[tid], L.r[tid]);   // :294
+            L.y[(tile - t0) * kTile + tid] = __builtin_fmaf(A.gamma * q2, 1.0f - L.d[tid], L.r[tid]);   // :294
         }
         __syncthreads();
     }
@@ -418,8 +498,8 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
     stage_params(L, A.online, A.bn, A.bn_eps, tid);
     __syncthreads();
     LPROBE(3);   // online networks staged
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const bool first = tile == 0;
+    for (int tile = t0; tile < t1; ++tile) {
+        const bool first = tile == t0;
         load_tile(tile, false);
         layer1(L, L.s, C_W1, C_B1, C_G1, C_BE1, 2, X0, X1, tid);                            // hc1: feature-major X0, sample-major X1
         __syncthreads();
@@ -442,11 +522,11 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
         if (tid < kTile) {
             float q = L.P[C_BO];
             for (int w = 0; w < 16; ++w) q += X3[w * 64 + tid];
-            const float e = q - L.y[tile * kTile + tid];
+            const float e = q - L.y[(tile - t0) * kTile + tid];
             L.dq[tid] = 2.0f * e * invB;                                                    // d mean (y - q)^2 / dq
             const float le = wave_sum(e * e * invB);        // (tid < kTile is exactly wave 0: one writer instead of 64 LDS atomics)
             const float sdq = wave_sum(2.0f * e * invB);    // output bias gradient
-            if (tid == 0) { L.loss[0] += le; A.grad[C_BO] = first ? sdq : A.grad[C_BO] + sdq; }
+            if (tid == 0) { L.loss[0] += le; G_[C_BO] = first ? sdq : G_[C_BO] + sdq; }
         }
         __syncthreads();
         {   // output layer and T2 / bt2 gradients; delta of hidden layer 2 in place of hc2
@@ -471,7 +551,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             float v = 0.f;
             for (int part = 0; part < 8; ++part) v += X3[2048 + (part * 32 + f) * 4 + q];
             const int p = q == 0 ? C_WO + f : q == 1 ? C_BT2 + f : C_T2 + f * 2 + (q - 2);
-            A.grad[p] = first ? v : A.grad[p] + v;
+            G_[p] = first ? v : G_[p] + v;
         }
         {   // dT1[f][k] = sum_i delta2[i][f] hc1[i][k]
             float g[2][4];
@@ -481,7 +561,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int p = C_T1 + (ty * 2 + u) * 64 + tx * 4 + v;
-                    A.grad[p] = first ? g[u][v] : A.grad[p] + g[u][v];
+                    G_[p] = first ? g[u][v] : G_[p] + g[u][v];
                 }
         }
         {   // d hc1[i][k] = sum_f delta2[i][f] T1[f][k]  ->  dL/dn of layer 1 (sample-major, X4)
@@ -496,22 +576,31 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
                 }
         }
         __syncthreads();
-        layer1_backward(L, X4, L.s, C_W1, C_B1, C_G1, C_BE1, 2, X3, A.grad, first, tid);
+        layer1_backward(L, X4, L.s, C_W1, C_B1, C_G1, C_BE1, 2, X3, G_, first, tid);
     }
     __threadfence_block();
     __syncthreads();
     LPROBE(4);   // critic forward + backward
+    if constexpr (MODE == kModeCriticHalf) {
+        if (tid == 0) A.loss_partial[blockIdx.x * 2 + 0] = L.loss[0];
+        if (!mw_arrive_last(A, L, 0, tid)) return;       // (uniform: the whole workgroup leaves)
+        mw_reduce<C_W1, kParams>(A, L, 0, tid);
+        if (tid == 0) { A.counter[0] = 0u; if (A.losses != nullptr) A.losses[0] = L.loss[0]; }
+    }
     adam_soft<C_W1, kParams>(A, A.critic_lr, L.bc[0], L.bc[1], tid);
     __threadfence_block();
     __syncthreads();
     LPROBE(5);   // critic Adam + soft update
+    if constexpr (MODE == kModeCriticHalf) return;
+  }
     // ------------------------------------------------------------------------------------------------ actor step (against the UPDATED critic)
-    stage_range(L, A.online, C_W1, tid);
+    if constexpr (MODE == kModeActorHalf) stage_params(L, A.online, A.bn, A.bn_eps, tid);   // a launch of its own: everything is staged here
+    else stage_range(L, A.online, C_W1, tid);
     __syncthreads();
     LPROBE(6);   // updated critic re-staged
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const bool first = tile == 0;
-        load_tile(tile, false);
+    for (int tile = t0; tile < t1; ++tile) {
+        const bool first = tile == t0;
+        load_tile(tile, MODE == kModeActorHalf);
         layer1(L, L.s, A_W1, A_B1, A_G1, A_BE1, 0, X0, X1, tid);                            // h1: X0 feature-major, X1 sample-major
         __syncthreads();
         LPROBE(9);
@@ -587,7 +676,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             L.dz3[tid * 2] = g0;
             L.dz3[tid * 2 + 1] = g1;
             const float s0 = wave_sum(g0), s1 = wave_sum(g1);                               // output bias gradients
-            if (tid < 2) { const float v = tid ? s1 : s0; A.grad[A_B3 + tid] = first ? v : A.grad[A_B3 + tid] + v; }
+            if (tid < 2) { const float v = tid ? s1 : s0; G_[A_B3 + tid] = first ? v : G_[A_B3 + tid] + v; }
         }
         __syncthreads();
         LPROBE(14);
@@ -615,7 +704,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
             const int k = o / 5, q = o - 5 * k;
             const float v = X4[(0 * 64 + k) * 5 + q] + X4[(1 * 64 + k) * 5 + q] + X4[(2 * 64 + k) * 5 + q] + X4[(3 * 64 + k) * 5 + q];
             const int p = q == 0 ? A_G2 + k : q == 1 ? A_BE2 + k : q == 2 ? A_B2 + k : A_W3 + (q - 3) * 64 + k;
-            A.grad[p] = first ? v : A.grad[p] + v;
+            G_[p] = first ? v : G_[p] + v;
         }
         {   // dW2[f][k] = sum_i dz2[i][f] h1[i][k]
             float g[4][4];
@@ -625,7 +714,7 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int p = A_W2 + (ty * 4 + u) * 64 + tx * 4 + v;
-                    A.grad[p] = first ? g[u][v] : A.grad[p] + g[u][v];
+                    G_[p] = first ? g[u][v] : G_[p] + g[u][v];
                 }
         }
         __syncthreads();
@@ -643,18 +732,39 @@ __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) 
         }
         __syncthreads();
         LPROBE(17);
-        layer1_backward(L, X2, L.s, A_W1, A_B1, A_G1, A_BE1, 0, X4, A.grad, first, tid);
+        layer1_backward(L, X2, L.s, A_W1, A_B1, A_G1, A_BE1, 0, X4, G_, first, tid);
     }
     __threadfence_block();
     __syncthreads();
     LPROBE(7);   // actor forward, critic forward, backward through both
+    if constexpr (MODE == kModeActorHalf) {
+        if (tid == 0) A.loss_partial[blockIdx.x * 2 + 1] = L.loss[1];
+        if (!mw_arrive_last(A, L, 1, tid)) return;
+        mw_reduce<A_W1, C_W1>(A, L, 1, tid);
+        if (tid == 0) A.counter[1] = 0u;
+    }
     adam_soft<A_W1, C_W1>(A, A.actor_lr, L.bc[2], L.bc[3], tid);
     if (tid < 2) A.steps[tid] += 1;
-    if (A.losses != nullptr && tid < 2) A.losses[tid] = L.loss[tid];
+    if constexpr (MODE == kModeActorHalf) { if (A.losses != nullptr && tid == 0) A.losses[1] = L.loss[1]; }
+    else { if (A.losses != nullptr && tid < 2) A.losses[tid] = L.loss[tid]; }
     __threadfence_block();
     __syncthreads();    // the next update of this launch stages the parameters this one wrote
     LPROBE(8);   // actor Adam + soft update
   }
+}
+
+__global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ddpg_update_body<kModeAll>(A, *reinterpret_cast<Lds*>(lds_raw));
+}
+// the multi-workgroup form: grid = batch / 64 workgroups, the two halves of ONE update (see ddpg_update_body)
+__global__ __launch_bounds__(kThreads) void mr_ddpg_mw_critic_kernel(const Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ddpg_update_body<kModeCriticHalf>(A, *reinterpret_cast<Lds*>(lds_raw));
+}
+__global__ __launch_bounds__(kThreads) void mr_ddpg_mw_actor_kernel(const Args A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ddpg_update_body<kModeActorHalf>(A, *reinterpret_cast<Lds*>(lds_raw));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -422,10 +422,9 @@ class DDPG:
                                          warm_episodes, None)
         from .partition import CuPartition
         key = (int(learner_cus), int(streams))
-        if getattr(self, "_partition_key", None) != key:
-            if getattr(self, "partition", None) is not None:
-                torch.cuda.synchronize(env.device)
-                self.partition.close()
+        part = getattr(self, "partition", None)
+        if getattr(self, "_partition_key", None) != key or part is None or part.closed:
+            self.close()                              # the previous partition, with everything that refers to its streams
             self.partition, self._partition_key = CuPartition(env.device, per_xcc=int(learner_cus), collection_streams=int(streams)), key
         part = self.partition
         outer = torch.cuda.current_stream(env.device)
@@ -435,6 +434,25 @@ class DDPG:
                                         warm_episodes, part.collection_streams)
         outer.wait_stream(part.learner_stream)
         return out
+
+    def close(self):
+        """Release what train_collected(learner_cus=k) keeps beyond its return: the collector (its ExternalStream wrappers and the
+        events recorded on them), the in-kernel policy block, the update graph captured on the learner's stream, the allocator's
+        cached blocks -- and only then the CU-masked streams themselves (CuPartition.close()).  Destroying a stream that a live
+        wrapper, event or cached block still names is a use-after-destroy at teardown.  Safe to call repeatedly; the agent can
+        train again afterwards (a new partition is built on demand)."""
+        part = getattr(self, "partition", None)
+        if part is None:
+            return
+        col = getattr(self, "collector", None)
+        if col is not None:
+            col.join()
+        torch.cuda.synchronize(self.env.device)
+        self.collector = None                         # built on the partition's streams
+        del col
+        self._graph = None                            # captured while the learner's stream was current
+        self.partition, self._partition_key = None, None
+        part.close()
 
     def _train_collected(self, episodes, updates_per_episode, sample, streams, math, graphed, on_episode, stats, warm_episodes,
                          stream_list):

@@ -54,11 +54,22 @@ class FusedLearner:
         self.bn_stats = torch.stack(stats).contiguous()           # [2][3][2][64]: constants of the update (reference BN mode)
         bound = agent.actor.action_bound.detach().cpu().tolist()
         opt = agent.opt_a.defaults
+        # work space of the multi-workgroup form (batches above 64 on batch / 64 compute units): sized for the largest batch, zeroed
+        # once; multi_workgroup=False (a test / measurement switch) keeps the single workgroup looping over the tiles
+        self.batch_scratch = torch.zeros(_lib.ddpg_batch_scratch_floats(_lib.DDPG_MAX_BATCH), dtype=torch.float32, device=dev)
         self.struct = _lib.MrsimDdpgLearner(
             self.online.data_ptr(), self.target.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.grad.data_ptr(),
             self.steps.data_ptr(), self.bn_stats.data_ptr(), float(agent.actor.bn1.eps), float(agent.gamma), float(agent.tau),
             float(agent.actor_lr), float(agent.critic_lr), float(opt["betas"][0]), float(opt["betas"][1]), float(opt["eps"]),
-            (C.c_float * 2)(float(bound[0]), float(bound[1])))
+            (C.c_float * 2)(float(bound[0]), float(bound[1])), self.batch_scratch.data_ptr(), self.batch_scratch.numel())
+
+    @property
+    def multi_workgroup(self):
+        return bool(self.struct.batch_scratch)
+
+    @multi_workgroup.setter
+    def multi_workgroup(self, on):
+        self.struct.batch_scratch = self.batch_scratch.data_ptr() if on else None
 
     @staticmethod
     def _alias(module, layout, flat):

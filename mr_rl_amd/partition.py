@@ -49,6 +49,13 @@ class CuPartition:
         self.learner_units = int(per_xcc) * self.xccs
         self.learner_mask, self.collection_mask = learner, collect
         self._handles = []
+        # Streams still alive when the interpreter exits crash `rocprofv3 --kernel-trace` in a static destructor after its tool
+        # finalisation (profiles/r05/partition_kt.txt: SIGSEGV under __cxa_finalize; destroyed in order -> clean exit): a safety
+        # net for callers that never call close() -- atexit handlers run before static destructors
+        import atexit
+        import weakref
+        ref = weakref.ref(self)
+        atexit.register(lambda: ref() is not None and ref().close())
         try:
             self.learner_stream = self._stream(learner)
             self.collection_streams = [self._stream(collect) for _ in range(int(collection_streams))]
@@ -64,12 +71,29 @@ class CuPartition:
         self._handles.append(h)
         return torch.cuda.ExternalStream(h.value, device=self.device)
 
+    @property
+    def closed(self):
+        return not self._handles
+
     def close(self):
-        """synchronise and destroy the streams (the torch wrappers must not be used afterwards)"""
-        for h in self._handles:
-            self._L.mrsim_stream_destroy(h)
-        self._handles = []
+        """Destroy the streams.  ORDER MATTERS: everything that still refers to them must be gone first -- the torch
+        ExternalStream wrappers handed out by this object (a RolloutCollector built on `collection_streams` keeps them and the
+        events it recorded on them), tensors allocated while one of them was the current stream (the caching allocator files a
+        block under the stream it was allocated on) and graphs captured on them.  DDPG.close() does that for the training loop;
+        a caller that used the streams directly drops its own references, then calls this.  The device is synchronised first,
+        the allocator's cached blocks are returned, and only then are the streams destroyed; idempotent."""
+        if not self._handles:
+            return
+        import gc
+        import torch
         self.learner_stream, self.collection_streams = None, []
+        gc.collect()                                   # wrappers / events that only cycles kept alive
+        with torch.cuda.device(self.index):
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()                   # cached blocks filed under the streams about to go
+            for h in self._handles:
+                self._L.mrsim_stream_destroy(h)
+        self._handles = []
 
     def __enter__(self):
         return self

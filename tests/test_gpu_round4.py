@@ -385,35 +385,36 @@ def test_device_side_policy_upload_and_replay_push_match_the_host_paths():
     assert len({tuple(x.tolist()) for x in s2[:64]}) > 60            # different transitions, not one repeated
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_ddpg_loop_learns_a_one_step_goal_task(fused):
-    """Smoke-level learning check of the whole loop on the device env, goal reward (tools/learning_check.py): envs start 10 .. 14
-    units beside a goal of radius 10 and every episode is one step; the untrained actor does not move (return -100), a constant
-    action "f ~ -7, cos(alpha) ~ 1" reaches the goal.  Collection with the actor in the kernel, replay push, fused / graph-replayed
-    learner, device-side policy upload.  DDPG on this task is seed-sensitive with EVERY learner (an early critic error drives tanh
-    into saturation and the actor's gradient vanishes: 3-4 of 11 seeds end at -100 with the PyTorch learner and with the fused one,
-    profiles/r04/learning_check_seeds.txt), so the check is over 8 seeds: at least 3 must rise from below -60 (first episode,
-    collected before any update) to a plateau above +15 (set by the exploration noise that stays on: ~ +30) with a learnt action
-    that moves the robot into the goal's radius."""
+def test_ddpg_loop_learns_a_one_step_goal_task_on_every_seed_with_both_learners():
+    """Learning check of the whole loop on the device env, goal reward (tools/learning_check.py, task "C"): envs start 4 .. 16 units
+    beside a goal of radius 10 and every episode is one step; the untrained actor does not move (mean return ~ 0: a third of the
+    envs start inside the radius), a constant action "f cos(alpha) ~ -8" takes nearly all of them in.  Collection with the actor in
+    the kernel, replay push, fused / graph-replayed learner, device-side policy upload -- seeds 0 .. 7 with the fused kernel AND with
+    the PyTorch learner.  No voting: EVERY seed must learn with BOTH learners (plateau >= 30 from a first episode within +-10; the
+    sweep behind this setting, profiles/r05/learning_sweep.txt, had 64 .. 88 fused and 50 .. 86 eager), the learnt action must
+    move the robot into the radius, and the two learners' plateaus, averaged over the seeds, must lie within 15 of each other
+    (81 and 76 in the sweep).  (Task "A" of round 4 -- every env outside the radius -- is learnt on 5-6 of 8 seeds by either
+    learner: a property of DDPG on a step-function reward, documented there; not a pass criterion any more.)"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("learning_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                                                 "tools", "learning_check.py"))
     lc = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lc)
     import torch
-    learnt, ends = 0, []
-    for seed in range(8):
-        agent, rets = lc.run(fused, 200, 16, seed=seed)
-        assert len(rets) == 200 and np.isfinite(rets).all()
-        assert rets[0] < -30.0, (seed, rets[:3])
-        with torch.no_grad():
-            a = agent.actor(torch.tensor([[12.0, 0.0, 0.0, 0.0, 12.0]], device="cuda") * 0.1)[0]
-        moved = 1.5 * float(a[0]) * float(torch.cos(a[1])) < -2.0
-        end = float(np.mean(rets[-20:]))
-        ends.append(round(end, 1))
-        learnt += int(end > 15.0 and end - rets[0] > 60.0 and moved)
-    print("plateau per seed:", ends)
-    assert learnt >= 3, ends
+    plateaus = {True: [], False: []}
+    for fused in (True, False):
+        for seed in range(8):
+            agent, rets = lc.run(fused, 200, 16, ou_sigma=5.0, seed=seed, task="C")
+            assert len(rets) == 200 and np.isfinite(rets).all()
+            assert abs(rets[0]) < 10.0, (fused, seed, rets[:3])            # collected before any update: the untrained policy
+            with torch.no_grad():
+                a = agent.actor(torch.tensor([[12.0, 0.0, 0.0, 0.0, 12.0]], device="cuda") * 0.1)[0]
+            step = 1.5 * float(a[0]) * float(torch.cos(a[1]))
+            end = float(np.mean(rets[-20:]))
+            plateaus[fused].append(round(end, 1))
+            assert end >= 30.0 and step < -3.0, (fused, seed, end, step, plateaus)
+    print("plateau per seed: fused", plateaus[True], "eager", plateaus[False])
+    assert abs(np.mean(plateaus[True]) - np.mean(plateaus[False])) < 15.0, plateaus
 
 
 # (sigma > 0 statistics of the kernel against the reference's own samples: tests/test_gpu_round5.py, schema-2 fixture)

@@ -168,3 +168,109 @@ def test_facade_step_rate_beats_the_reference_python():
     rate = n / (time.perf_counter() - t0)
     print(f"facade: {rate:.0f} MR_Env.step/s (resets included)")
     assert rate > 9500.0
+
+
+# ---------------------------------------------------------------------------
+# the learner across compute units for large batches (RL/MR_ddpg.py:288-305; mrsim_learner.h: multi-workgroup form)
+# ---------------------------------------------------------------------------
+def _learner_pair(B, seed=3):
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.ddpg import DDPG
+    from tests.test_gpu_round4 import _randomise
+    env = MRVecEnv(256, cfg=MRConfig(auto_reset=True), seed=0)
+    a, b = DDPG(env, seed=seed, min_batch=B, fused=True), DDPG(env, seed=seed, min_batch=B, fused=True)
+    _randomise(a, 5); _randomise(b, 5)
+    return a, b
+
+
+@pytest.mark.parametrize("B", [128, 256, 1024, 4096])
+def test_multi_workgroup_update_equals_the_single_workgroup_loop_bitwise(B):
+    """batch / 64 workgroups, each on its tile, gradients summed in tile order by the last workgroup to arrive == ONE workgroup
+    looping over the tiles (which adds them in the same order): parameters, Adam moments, targets, losses and step counts are
+    equal bit for bit after three updates on given batches -- and after three more with the rows drawn in the kernel."""
+    import torch
+    from tests.test_gpu_round4 import _batch
+    multi, single = _learner_pair(B)
+    single.fused.multi_workgroup = False
+    assert multi.fused.multi_workgroup and not single.fused.multi_workgroup
+    for k in range(3):
+        batch = _batch(B, 200 + k)
+        lm, ls = multi.update(batch), single.update(batch)
+        assert float(lm[0]) == float(ls[0]) and float(lm[1]) == float(ls[1]), (k, float(lm[0]), float(ls[0]))
+    for name in ("online", "target", "adam_m", "adam_v", "grad"):
+        assert torch.equal(getattr(multi.fused, name), getattr(single.fused, name)), name
+    assert multi.fused.steps.tolist() == single.fused.steps.tolist() == [3, 3]
+    # rows drawn in the kernel from a filled ring (B <= 256: without repetition; beyond: every workgroup draws its own tile's rows)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    n = 10000
+    for ag in (multi, single):
+        g.manual_seed(1)
+        s = torch.randn(n, 5, device="cuda", generator=g)
+        ag.buffer.add(s, torch.randn(n, 2, device="cuda", generator=g), torch.randn(n, device="cuda", generator=g),
+                      (torch.rand(n, device="cuda", generator=g) < 0.02).float(), s + 0.01 * torch.randn(n, 5, device="cuda", generator=g))
+        ag.fused.idx_out = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    for k in range(3):
+        multi.update(); single.update()
+        assert torch.equal(multi.fused.idx_out, single.fused.idx_out)
+        rows = multi.fused.idx_out
+        assert int(rows.min()) >= 0 and int(rows.max()) < n
+        if B <= 256:
+            assert len(set(rows.tolist())) == B
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(multi.fused, name), getattr(single.fused, name)), name
+    torch.cuda.synchronize()
+    sc = multi.fused.batch_scratch
+    tiles = B // 64
+    counters = sc[tiles * 7680 + B + 2 * tiles: tiles * 7680 + B + 2 * tiles + 2].view(torch.int32)
+    assert counters.tolist() == [0, 0]            # the arrival tickets are back at zero between launches
+
+
+@pytest.mark.parametrize("B", [1024, 4096])
+def test_multi_workgroup_update_equals_the_eager_pytorch_update(B):
+    """the large-batch form against the PyTorch twin on the same batches (as test_gpu_round4 does for 64 and 256)"""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.ddpg import DDPG
+    from mr_rl_amd.learner import ACTOR_LAYOUT, CRITIC_LAYOUT
+    from tests.test_gpu_round4 import _batch, _randomise
+    env = MRVecEnv(256, cfg=MRConfig(auto_reset=True), seed=0)
+    eager, fused = DDPG(env, seed=3, min_batch=B), DDPG(env, seed=3, min_batch=B, fused=True)
+    _randomise(eager, 5); _randomise(fused, 5)
+    for k in range(3):
+        batch = _batch(B, 100 + k)
+        le, lf = eager.update(batch), fused.update(batch)
+        assert abs(float(le[0]) - float(lf[0])) <= 2e-5 * max(1.0, abs(float(le[0])))
+        assert abs(float(le[1]) - float(lf[1])) <= 2e-5 * max(1.0, abs(float(le[1])))
+    for net_e, net_f, layout in ((eager.actor, fused.actor, ACTOR_LAYOUT), (eager.critic, fused.critic, CRITIC_LAYOUT),
+                                 (eager.actor_t, fused.actor_t, ACTOR_LAYOUT), (eager.critic_t, fused.critic_t, CRITIC_LAYOUT)):
+        for path, off in layout:
+            pe, pf = net_e.get_parameter(path).detach(), net_f.get_parameter(path).detach()
+            scale = float(pe.abs().max())
+            err = (pe - pf).abs()
+            assert float((err <= 5e-6 * scale + 5e-7).float().mean()) >= 0.95, (path, float(err.max()), scale)
+            assert float(err.max()) <= 1e-3, (path, float(err.max()))
+    assert fused.fused.steps.tolist() == [3, 3]
+
+
+@pytest.mark.parametrize("ring,B", [(64, 64), (65, 64), (100, 64), (127, 64), (128, 64), (256, 256), (300, 256)])
+def test_in_kernel_sampler_never_repeats_a_row_on_a_nearly_empty_ring(ring, B):
+    """random.sample's law (RL/MR_ddpg.py:37-44) when the ring holds fewer than two batches -- the first updates of DDPG.train with
+    64 envs draw 64 of 64: a partial Fisher-Yates shuffle, no rejection rounds to run out of."""
+    import torch
+    multi, _ = _learner_pair(B)
+    ag = multi
+    g = torch.Generator(device="cuda").manual_seed(2)
+    s = torch.randn(ring, 5, device="cuda", generator=g)
+    ag.buffer.add(s, torch.randn(ring, 2, device="cuda", generator=g), torch.randn(ring, device="cuda", generator=g),
+                  torch.zeros(ring, device="cuda"), s.clone())
+    ag.fused.idx_out = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    seen = torch.zeros(ring, device="cuda")
+    for k in range(40):
+        ag.update()
+        rows = ag.fused.idx_out.clone()
+        assert int(rows.min()) >= 0 and int(rows.max()) < ring
+        assert len(set(rows.tolist())) == B, (k, sorted(rows.tolist()))
+        seen[rows.long()] += 1
+    if ring > B:                # every row gets its turn (uniform over the ring: 40 x B / ring expected visits)
+        assert int((seen == 0).sum()) == 0
+        assert float(seen.max()) <= 40 and float(seen.float().std()) < 0.45 * 40 * B / ring + 3

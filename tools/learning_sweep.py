@@ -18,8 +18,12 @@ lc = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(lc)
 
 
-def run(fused, episodes, updates, seed, critic_lr, actor_lr, ou_sigma, envs=4096):
-    env = MRVecEnv(envs, cfg=lc.task_cfg(), seed=seed)
+def task_cfg(task):
+    return lc.task_cfg(task)
+
+
+def run(fused, episodes, updates, seed, critic_lr, actor_lr, ou_sigma, envs=4096, task="A"):
+    env = MRVecEnv(envs, cfg=task_cfg(task), seed=seed)
     agent = DDPG(env, seed=seed, obs_scale=[0.1] * 5, fused=bool(fused), critic_lr=critic_lr, actor_lr=actor_lr)
     agent.noise.sigma = ou_sigma
     rets = agent.train_collected(episodes, updates_per_episode=updates, sample=4096)
@@ -35,12 +39,12 @@ if __name__ == "__main__":
     ap.add_argument("--updates", type=int, default=16)
     ap.add_argument("--seeds", type=int, default=8)
     a = ap.parse_args()
-    for critic_lr, actor_lr, ou in ((1e-2, 1e-3, 10.0), (1e-3, 1e-3, 10.0), (1e-3, 1e-4, 10.0), (3e-3, 3e-4, 10.0), (1e-3, 1e-4, 5.0)):
+    for task, critic_lr, actor_lr, ou in (("B", 1e-2, 1e-3, 10.0), ("C", 1e-2, 1e-3, 10.0), ("D", 1e-2, 1e-3, 10.0), ("B", 1e-2, 1e-3, 5.0),
+                                          ("C", 1e-2, 1e-3, 5.0), ("B", 1e-2, 1e-4, 10.0)):
         for fused in (1, 0):
             row = []
             for seed in range(a.seeds):
-                first, end, moved = run(fused, a.episodes, a.updates, seed, critic_lr, actor_lr, ou)
+                first, end, moved = run(fused, a.episodes, a.updates, seed, critic_lr, actor_lr, ou, task=task)
                 row.append((round(first, 1), round(end, 1), round(moved, 1)))
-            learnt = sum(1 for f, e, m in row if e > 15.0 and e - f > 60.0 and m < -2.0)
-            print(f"critic_lr {critic_lr:g} actor_lr {actor_lr:g} ou {ou:g} fused {fused}: learnt {learnt}/{a.seeds}  "
+            print(f"task {task} critic_lr {critic_lr:g} actor_lr {actor_lr:g} ou {ou:g} fused {fused}: min plateau {min(e for _, e, _ in row):.1f}  "
                   f"(first, plateau, step) = {row}", flush=True)

@@ -19,7 +19,7 @@ pass() {  # pass <name> <cmd...>: run, record the exit code
   echo "$name $?" >> $O/status.txt
 }
 PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --no-actor-leg --no-learner-leg --no-other-law --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
-pass kt rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-power --no-partition-row
+pass kt rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-power
 pass kt_s1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1 -- python3 $R/bench.py --no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg
 pass kt_s1_ps rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1_ps -- python3 $R/bench.py --no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg --noise-law per_stage
 pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --no-power --mode step
