@@ -86,7 +86,7 @@ def test_attempts_output_equals_the_oracles_counter(law, start):
     if start == (110.0, 115.0):
         assert got.max() == 1
     if start == (0.0, 0.0):
-        assert got[alive].min() > 5 and got[alive].mean() > 15
+        assert got[alive].mean() > 15 and want[alive].mean() > 15          # every step is split here (the fixture: 20-50 attempts)
 
 
 def test_library_default_law_is_collapsed_everywhere():
