@@ -408,6 +408,9 @@ template <bool MIS>
 struct RhsCtx {
     double vx, vy;
     double gx, gy;  // mismatched only
+    // mismatched model under the collapsed law: fp32 copies of g and c = 1 / (sigma + sqrt(sigma^2 + |g|^2)), the coefficient of
+    // the 2-D noise map M(u) = sigma u + c g (g . u) (see "collapsed law" below); dead code elsewhere
+    float gxf, gyf, cg;
 };
 
 template <bool MIS>
@@ -433,6 +436,9 @@ __device__ __forceinline__ RhsCtx<MIS> make_ctx(const KParams& P, double f_t, do
         C.vy = af * sB - 0.1;
         C.gx = (P.sigma4 * f_t) * cA;
         C.gy = (P.sigma4 * f_t) * sB;
+        C.gxf = (float)C.gx; C.gyf = (float)C.gy;
+        const float sf = (float)P.sigma;
+        C.cg = __builtin_amdgcn_rcpf(sf + __builtin_amdgcn_sqrtf(__builtin_fmaf(sf, sf, __builtin_fmaf(C.gxf, C.gxf, C.gyf * C.gyf))));
     } else {
         double s, c;
 #if MRSIM_ROLLOUT_TABLE
@@ -444,6 +450,7 @@ __device__ __forceinline__ RhsCtx<MIS> make_ctx(const KParams& P, double f_t, do
         C.vx = af * c;
         C.vy = af * s;
         C.gx = C.gy = 0.0;
+        C.gxf = C.gyf = C.cg = 0.f;
     }
     return C;
 }
@@ -455,6 +462,7 @@ __device__ __forceinline__ RhsCtx<MIS> zero_ctx(const KParams&) {
     C.vx = MIS ? 0.2 : 0.0;
     C.vy = MIS ? -0.1 : 0.0;
     C.gx = C.gy = 0.0;
+    C.gxf = C.gyf = C.cg = 0.f;
     return C;
 }
 
@@ -480,6 +488,15 @@ __device__ __forceinline__ void rhs_value(const KParams& P, const RhsCtx<MIS>& C
         kx = __builtin_fma(C.gx, (double)za, kx);
         ky = __builtin_fma(C.gy, (double)za, ky);
     }
+}
+
+// Mismatched model under the collapsed law: the a0 draw is not a normal of its own -- the evaluation's noise 2-vector is
+// M(u) = sigma u + c g (g . u) for a standard normal pair u (exact in law: its covariance is sigma^2 I + g g^T, what the three
+// normals of MR_simulator.py:55-56,77-80 give).  In the (z_a, z_x, z_y) form every formula of this file uses, that is
+// z_x = u_x, z_y = u_y and the DERIVED  z_a = c (g . u):
+template <bool MIS>
+__device__ __forceinline__ float derived_za(const RhsCtx<MIS>& C, float ux, float uy) {
+    return C.cg * __builtin_fmaf(C.gxf, ux, C.gyf * uy);
 }
 
 // progress of the sub-step loop of one env step (+ what the constructor needs from its last attempt)
@@ -531,14 +548,14 @@ __device__ __forceinline__ bool construct_level0(const KParams& P, double x, dou
 
 // the three normals (z_a, z_x, z_y) of the constructor's F0 from what the attempt kept: the words of one Box-Muller pair
 // (f0a, f0b) and, under the mismatched law, a third normal f0k already evaluated with its pair partner
-//   per-stage law: pair = (F0a, F0x), f0k = F0y        collapsed law: pair = (F0x, F0y), f0k = F0a
+//   per-stage law: pair = (F0a, F0x), f0k = F0y        collapsed law: pair = (F0x, F0y), z_a derived from the pair (derived_za)
 template <int NZ, bool MIS>
-__device__ __forceinline__ void f0_normals(uint32_t f0a, uint32_t f0b, float f0k, float& za, float& zx, float& zy,
+__device__ __forceinline__ void f0_normals(const RhsCtx<MIS>& C, uint32_t f0a, uint32_t f0b, float f0k, float& za, float& zx, float& zy,
                                            float* radius = nullptr) {
     float p, q;
     box_muller<NZ>(f0a, f0b, p, q, radius);
     if constexpr (!MIS) { za = 0.f; zx = p; zy = q; }
-    else if constexpr (nz_coll(NZ)) { za = f0k; zx = p; zy = q; }
+    else if constexpr (nz_coll(NZ)) { zx = p; zy = q; za = derived_za<MIS>(C, p, q); }
     else { za = p; zx = q; zy = f0k; }
 }
 
@@ -572,10 +589,14 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
                 return;
             }
             if (!LS->have3) {
-                philox_call(R, c0_of(kStreamDyn, LS->last_attempt, nz_coll(NZ) ? (MIS ? 3u : 2u) : (MIS ? 5u : 3u)), LS->w3);
+                philox_call(R, c0_of(kStreamDyn, LS->last_attempt, nz_coll(NZ) ? 2u : (MIS ? 5u : 3u)), LS->w3);
                 LS->have3 = true;
             }
-            if constexpr (MIS) {
+            if constexpr (MIS && nz_coll(NZ)) {      // F1 = the pair of words 2,3 of call 2, through M
+                float zx, zy;
+                box_muller<NZ>(LS->w3[2], LS->w3[3], zx, zy);
+                noise_vec<MIS>(P, C, derived_za<MIS>(C, zx, zy), zx, zy, n1x, n1y);
+            } else if constexpr (MIS) {
                 float za, zx, zy, zs;
                 box_muller<NZ>(LS->w3[0], LS->w3[1], za, zx);
                 box_muller<NZ>(LS->w3[2], LS->w3[3], zy, zs);
@@ -590,7 +611,7 @@ __device__ __forceinline__ void rk45_construct(const KParams& P, const RhsCtx<MI
     if constexpr (NZ != kNoNoise) {
         if (LS != nullptr) {
             float za, zx, zy;
-            f0_normals<NZ, MIS>(LS->f0a, LS->f0b, LS->f0y, za, zx, zy);
+            f0_normals<NZ, MIS>(C, LS->f0a, LS->f0b, LS->f0y, za, zx, zy);
             noise_vec<MIS>(P, C, za, zx, zy, n0x, n0y);  // n0 itself only feeds the fp32 fallback test
             rhs_value<MIS>(P, C, za, zx, zy, f0x, f0y);
             have1 = need_f1;
@@ -697,11 +718,17 @@ constexpr float kE2f = (float)(71.0 / 16695), kE3f = (float)(-71.0 / 1920), kE4f
 // directly.  K6, F0, F1 keep their own draws.  Equal in law to the per-stage noise of MR_simulator.py:73-83 for everything a
 // step returns or carries (tests/test_noise_law_cpu.py), not draw for draw.  Philox layout of block DYN(attempt):
 //   nominal:     call 0 = [policy words | z1],  call 1 = [F0 | z2],  call 2 = [K6 | F1]          (eager: calls 0, 1; 2 pairs)
-//   mismatched:  call 0 = [policy | z1a z1x],  call 1 = [z1y F0a | F0x F0y],  call 2 = [z2a z2x | z2y K6a],
-//                call 3 = [F1a F1x | F1y -],  call 4 = [K6x K6y | - -]                          (eager: calls 0..2; 5 pairs)
+//   mismatched:  call 0 = [policy words | u1],  call 1 = [F0 | u2'],  call 2 = [w | F1]         (eager: calls 0, 1; 3 pairs)
+//                -- pairs through M (derived_za), f_new's noise folded into the error sum (kCE2Pf); w only when a sub-step follows
 constexpr float kCBf = 0.8641431770614779f;     // sqrt(sum_{2..5} B_i^2)
 constexpr float kCE1f = -0.05097452091652899f;  // sum_{2..5} B_i E_i / cB
 constexpr float kCE2f = 0.05594888714408681f;   // sqrt(sum_{2..5} E_i^2 - cE1^2)
+// mismatched model (oracle/mrsim_oracle.c: COL_CE2P): f_new's noise folded into the error sum, S_E' = S_E + E6 N_6 = M(cE1 u1 +
+// cE2' u2'); when N_6 itself is needed (another sub-step follows) it comes from its conditional law given S_E':
+// N_6 = M(kK6u u2' + kK6w w), w a fresh pair
+constexpr float kCE2Pf = 0.06128032288313894f;                          // sqrt(cE2^2 + E6^2)
+constexpr float kK6uf = (float)((1.0 / 40) / 0.06128032288313894);      // E6 / cE2'
+constexpr float kK6wf = (float)(0.05594888714408681 / 0.06128032288313894);   // cE2 / cE2'
 constexpr int kMaxAttempts = 4096;  // every lane leaves the loop: bounded spin
 // |z| of this generator never exceeds sqrt(-2 ln 2^-33) = 6.763 (u >= 2^-33); bound with margin
 constexpr double kZmaxE6 = 6.78 * (1.0 / 40);  // Zmax * E6
@@ -731,6 +758,7 @@ struct AttemptNoise {
     // R32 = Zmax (E6 + cE2) + |cE1| r1
     float kz[8], R32;
     bool lazyE;
+    bool need6;   // mismatched model, collapsed law: f_new's normals (z6*) have not been formed yet (finish_k6 does, from kz[2..3] = u2' and w)
 };
 
 template <int NZ, bool MIS, bool FIRST>
@@ -743,7 +771,7 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         A.ex32 = A.ey32 = A.ea32 = 0.f; A.lazy6 = false;
         A.f0a = A.f0b = A.k6a = A.k6b = 0u; A.f0y = 0.f;
         A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u; A.have3 = false;
-        A.R32 = 0.f; A.lazyE = false;
+        A.R32 = 0.f; A.lazyE = false; A.need6 = false;
 #pragma unroll
         for (int j = 0; j < 8; ++j) A.kz[j] = 0.f;
         return A;
@@ -777,37 +805,44 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         A.lazyE = true;
         A.ex32 = A.ey32 = 0.f;
         A.nex = A.ney = 0.0; A.z6a = A.z6x = A.z6y = 0.f;
-        A.lazy6 = true;
+        A.lazy6 = true; A.need6 = false;
         return A;
     } else if constexpr (nz_coll(NZ)) {
-        // collapsed mismatched law: calls 0..2 eager (five pairs: z1a z1x | z1y F0a | z2a z2x | z2y K6a here, F0x F0y in the
-        // constructor); K6's (x, y) pair (call 4) and F1 (call 3) stay lazy
+        // collapsed law, mismatched model: call 0 = [policy | u1], call 1 = [F0 | u2'] eager -- TWO Philox calls and three
+        // Box-Muller pairs (u1, u2' here, F0 in the constructor) per step in the common case; call 2 = [w | F1] only when f_new's
+        // noise or F1 is ever needed.  The error sums are formed eagerly (they include f_new's E6 N_6: nothing about the accept
+        // decision is left to a bound): under this model error_norm sits near 0.5 and a one-sided test would fail half the time.
         uint32_t wl[3][4];
         const uint32_t (*w)[4];
         if constexpr (FIRST) {
             w = reinterpret_cast<const uint32_t (*)[4]>(d0);
+            A.have3 = false;
+            A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u;
         } else {
             const uint32_t c0s[3] = {c0_of(kStreamDyn, attempt, 0), c0_of(kStreamDyn, attempt, 1), c0_of(kStreamDyn, attempt, 2)};
             philox_multi<3>(R, c0s, wl);
             w = wl;
+            A.have3 = true;
+            A.w3[0] = wl[2][0]; A.w3[1] = wl[2][1]; A.w3[2] = wl[2][2]; A.w3[3] = wl[2][3];
         }
-        A.have3 = false;
-        A.w3[0] = A.w3[1] = A.w3[2] = A.w3[3] = 0u;
-        A.f0a = w[1][2]; A.f0b = w[1][3]; A.k6a = A.k6b = 0u;
-        float z1a, z1x, z1y, z2a, z2x, z2y;
-        box_muller<NZ>(w[0][2], w[0][3], z1a, z1x);
-        box_muller<NZ>(w[1][0], w[1][1], z1y, A.f0y);      // f0y := F0's z_a (f0_normals)
-        box_muller<NZ>(w[2][0], w[2][1], z2a, z2x);
-        box_muller<NZ>(w[2][2], w[2][3], z2y, A.z6a);
-        A.ba32 = kCBf * z1a; A.bx32 = kCBf * z1x; A.by32 = kCBf * z1y;
-        A.ea32 = __builtin_fmaf(kE6f, A.z6a, __builtin_fmaf(kCE2f, z2a, kCE1f * z1a));
-        A.ex32 = __builtin_fmaf(kCE2f, z2x, kCE1f * z1x);
-        A.ey32 = __builtin_fmaf(kCE2f, z2y, kCE1f * z1y);
-        A.nex = A.ney = 0.0; A.z6x = A.z6y = 0.f;
-        A.lazy6 = true;
+        A.f0a = w[1][0]; A.f0b = w[1][1]; A.k6a = A.k6b = 0u; A.f0y = 0.f;
+        float u1x, u1y, u2x, u2y;
+        box_muller<NZ>(w[0][2], w[0][3], u1x, u1y);
+        box_muller<NZ>(w[1][2], w[1][3], u2x, u2y);
+        A.bx32 = kCBf * u1x; A.by32 = kCBf * u1y;
+        A.ba32 = derived_za<MIS>(C, A.bx32, A.by32);                  // M is linear: the a-term of cB u1
+        A.ex32 = __builtin_fmaf(kCE2Pf, u2x, kCE1f * u1x);
+        A.ey32 = __builtin_fmaf(kCE2Pf, u2y, kCE1f * u1y);
+        A.ea32 = derived_za<MIS>(C, A.ex32, A.ey32);
+        // the exact error-noise terms (f_new included): rk45_attempt's decision needs nothing more
+        A.nex = __builtin_fma(C.gx, (double)A.ea32, P.sigma * (double)A.ex32);
+        A.ney = __builtin_fma(C.gy, (double)A.ea32, P.sigma * (double)A.ey32);
+        A.z6a = A.z6x = A.z6y = 0.f;
+        A.lazy6 = false; A.need6 = true;
         A.R32 = 0.f; A.lazyE = false;
 #pragma unroll
         for (int j = 0; j < 8; ++j) A.kz[j] = 0.f;
+        A.kz[2] = u2x; A.kz[3] = u2y;
         return A;
     } else if constexpr (!MIS) {
         // nominal law: call 0 = [K1 (dead) | K2], call 1 = [K3 | K4], call 2 = [K5 | F0], call 3 = [K6 | F1].
@@ -848,7 +883,7 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         A.bx32 = bx; A.by32 = by; A.ba32 = 0.f;
         A.ex32 = A.ey32 = 0.f;
         A.nex = A.ney = 0.0; A.z6a = A.z6x = A.z6y = 0.f;
-        A.lazy6 = true;
+        A.lazy6 = true; A.need6 = false;
         return A;
     } else {
         // mismatched law, draws (z_a, z_x, z_y) per evaluation, draw index = 4*call + lane:
@@ -892,7 +927,7 @@ __device__ __forceinline__ AttemptNoise attempt_noise(const KParams& P, const Rh
         A.bx32 = bx; A.by32 = by; A.ba32 = ba;
         A.ex32 = ex; A.ey32 = ey; A.ea32 = ea;
         A.nex = A.ney = 0.0; A.z6x = A.z6y = 0.f;
-        A.lazy6 = true;
+        A.lazy6 = true; A.need6 = false;
         A.R32 = 0.f; A.lazyE = false;
 #pragma unroll
         for (int j = 0; j < 8; ++j) A.kz[j] = 0.f;
@@ -925,12 +960,18 @@ __device__ __forceinline__ void finish_e(AttemptNoise& A) {
 template <int NZ, bool MIS>
 __device__ __forceinline__ void finish_k6(const KParams& P, const RhsCtx<MIS>& C, const Rng& R, uint32_t attempt,
                                           AttemptNoise& A) {
-    if constexpr (MIS) {
-        if constexpr (nz_coll(NZ)) {  // K6's (x, y) pair lives in call 4 of the block
-            uint32_t w4[4];
-            philox_call(R, c0_of(kStreamDyn, attempt, 4), w4);
-            A.k6a = w4[0]; A.k6b = w4[1];
-        }
+    if constexpr (MIS && nz_coll(NZ)) {
+        // f_new's noise given the error sum it is already part of: N_6 = M(kK6u u2' + kK6w w), w = the pair of words 0,1 of call 2.
+        // Only a following sub-step sees it (as its K0); the error sums stay as they are.
+        if (!A.have3) { philox_call(R, c0_of(kStreamDyn, attempt, 2u), A.w3); A.have3 = true; }
+        float wx, wy;
+        box_muller<NZ>(A.w3[0], A.w3[1], wx, wy);
+        A.z6x = __builtin_fmaf(kK6wf, wx, kK6uf * A.kz[2]);
+        A.z6y = __builtin_fmaf(kK6wf, wy, kK6uf * A.kz[3]);
+        A.z6a = derived_za<MIS>(C, A.z6x, A.z6y);
+        A.need6 = false;
+        return;
+    } else if constexpr (MIS) {
         box_muller<NZ>(A.k6a, A.k6b, A.z6x, A.z6y);
         A.nex = __builtin_fma(C.gx, (double)A.ea32, P.sigma * (double)__builtin_fmaf(kE6f, A.z6x, A.ex32));
         A.ney = __builtin_fma(C.gy, (double)A.ea32, P.sigma * (double)__builtin_fmaf(kE6f, A.z6y, A.ey32));
@@ -960,7 +1001,7 @@ __device__ __forceinline__ bool accept_level0(const KParams& P, const AttemptNoi
     return h * eb <= 0.99 * fmin(l0, l1);
 }
 // level 1 (rms norm with the exact stage sums ex32 / ey32 / ea32 and the worst-case K6): sqrt(2) less pessimistic
-template <bool MIS>
+template <bool MIS, int NZ>
 __device__ __forceinline__ bool accept_level1(const KParams& P, const RhsCtx<MIS>& C, const AttemptNoise& A, double dfx,
                                               double dfy, double h, double l0, double l1) {
     double pex = __builtin_fma(P.sigma, (double)A.ex32, kE0 * dfx);
@@ -969,7 +1010,8 @@ __device__ __forceinline__ bool accept_level1(const KParams& P, const RhsCtx<MIS
         pex = __builtin_fma(C.gx, (double)A.ea32, pex);
         pey = __builtin_fma(C.gy, (double)A.ea32, pey);
     }
-    const double b6 = h * P.zmax_e6_sigma;
+    // (mismatched model under the collapsed law: f_new's term is part of the sums -- nothing is left to bound)
+    const double b6 = (MIS && nz_coll(NZ)) ? 0.0 : h * P.zmax_e6_sigma;
     const double l00 = l0 * l0, l11 = l1 * l1;
     const double axw = __builtin_fabs(h * pex) + b6;
     const double ayw = __builtin_fabs(h * pey) + b6;
@@ -1013,7 +1055,7 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
                 }
                 if (!decided) {
                     finish_e<NZ>(A);
-                    if (accept_level1<MIS>(P, C, A, dfx, dfy, h, l0, l1)) { accepted = true; decided = true; }
+                    if (accept_level1<MIS, NZ>(P, C, A, dfx, dfy, h, l0, l1)) { accepted = true; decided = true; }
                 }
             }
             if (!decided) finish_e<NZ>(A);
@@ -1062,6 +1104,7 @@ __device__ __forceinline__ bool rk45_attempt(const KParams& P, const RhsCtx<MIS>
         }
         if (!last) {  // f = f_new = K[6]; after the last sub-step the constructor replaces f anyway
             double n6x = 0.0, n6y = 0.0;
+            if constexpr (NZ != kNoNoise && MIS && nz_coll(NZ)) { if (A.need6) finish_k6<NZ, MIS>(P, C, R, S.attempt - 1, A); }
             if constexpr (NZ != kNoNoise) noise_vec<MIS>(P, C, A.z6a, A.z6x, A.z6y, n6x, n6y);
             f0x = C.vx + n6x; f0y = C.vy + n6y;
         }
@@ -1143,7 +1186,7 @@ __device__ __forceinline__ bool rk45_fast_step(const KParams& P, const RhsCtx<MI
     const double yn = __builtin_fma(h, sy, e.y);
     // RungeKutta.__init__ of the next step: f0 = simulate() with the F0 draws of this attempt's block
     float za, zx, zy, rF0 = 0.f;
-    f0_normals<NZ, MIS>(A.f0a, A.f0b, A.f0y, za, zx, zy, &rF0);
+    f0_normals<NZ, MIS>(C, A.f0a, A.f0b, A.f0y, za, zx, zy, &rF0);
     double f0x, f0y;
     rhs_value<MIS>(P, C, za, zx, zy, f0x, f0y);
     // ---- level -1 (nominal law, fused rollout): the first-level tests below hold for EVERY admissible value of the quantities
@@ -1191,7 +1234,7 @@ __device__ __forceinline__ bool rk45_fast_step(const KParams& P, const RhsCtx<MI
     if constexpr (!MIS) {
         acc = accept_level0(P, A, dfx, dfy, h, l0, l1);
     } else {
-        acc = accept_level1<MIS>(P, C, A, dfx, dfy, h, l0, l1);  // the mismatched attempt forms its E sums eagerly
+        acc = accept_level1<MIS, NZ>(P, C, A, dfx, dfy, h, l0, l1);  // the mismatched attempt forms its E sums eagerly
     }
     const double sc0 = __builtin_fma(__builtin_fabs(xn), P.rtol, P.atol);
     const double sc1 = __builtin_fma(__builtin_fabs(yn), P.rtol, P.atol);
@@ -1367,7 +1410,7 @@ __device__ __forceinline__ void action_from_words(const KParams& P, const uint32
 // carries the exploration policy's two words.  Later attempts (rare) and resets draw their own.
 template <bool RK45, int NZ, bool MIS>
 struct StepWords {
-    static constexpr int NDYN = (RK45 && NZ != kNoNoise) ? (nz_coll(NZ) ? (MIS ? 3 : 2) : (MIS ? 5 : 3)) : 0;
+    static constexpr int NDYN = (RK45 && NZ != kNoNoise) ? (nz_coll(NZ) ? 2 : (MIS ? 5 : 3)) : 0;
     static constexpr int N = NDYN > 0 ? NDYN : 1;  // the constructor's F0/F1 live in the DYN block too
     uint32_t w[N][4];
 };

@@ -278,22 +278,31 @@ static const double RK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 172
  * / 11 (mismatched) eager normals per attempt instead of 10 / 16.  A tape replay (the reference pin) ignores it.
  *   NOMINAL, block DYN(attempt a), draw = 4*call + lane, Box-Muller pairs = consecutive even/odd draws:
  *     0,1 policy words (dead as normals)   2,3 z1 (x, y)   4,5 F0   6,7 z2   8,9 K6   10,11 F1
- *   MISMATCHED (z_a, z_x, z_y per evaluation):
- *     0,1 policy   2,3,4 z1 (a, x, y)   5,6,7 F0   8,9,10 z2   11 K6a   12,13,14 F1   16,17 K6 (x, y)          */
+ *   MISMATCHED (round 5).  Two more steps of the same idea, both exact in law:
+ *   (i) the noise of one RHS evaluation, (g z_a + sigma z_x, g' z_a + sigma z_y) with three normals (MR_simulator.py:55-56,
+ *       77-80), is a 2-vector with covariance sigma^2 I + g g^T.  Its symmetric square root is sigma I + c g g^T with
+ *       c = 1 / (sigma + sqrt(sigma^2 + |g|^2)), so N = M(u) = sigma u + c g (g . u) for a standard normal PAIR u has exactly
+ *       that law: two normals per evaluation instead of three;
+ *   (ii) f_new's noise N_6 reaches the attempt's accept / reject decision only through E6 N_6 inside the error estimate, and
+ *       anything else (the next sub-step's K0) only when another sub-step follows.  S_E' = S_E + E6 N_6 is drawn directly,
+ *       S_E' = M(cE1 u1 + cE2' u2'), cE2' = sqrt(cE2^2 + E6^2); when N_6 itself is needed it is drawn from its conditional
+ *       law given S_E':  N_6 = M((E6 / cE2') u2' + (cE2 / cE2') w),  w a fresh pair.
+ *   The block then has the nominal law's layout and needs two Philox calls in the common case instead of three:
+ *     0,1 policy   2,3 u1   4,5 F0   6,7 u2'   8,9 w   10,11 F1                                                          */
 #define COL_CB  0.8641431770614779      /* sqrt(sum_{2..5} B_i^2)                         */
 #define COL_CE1 (-0.05097452091652899)  /* sum_{2..5} B_i E_i / cB                        */
 #define COL_CE2 0.05594888714408681     /* sqrt(sum_{2..5} E_i^2 - cE1^2)                 */
+#define COL_CE2P 0.06128032288313894    /* sqrt(cE2^2 + E6^2): f_new's noise folded into the error sum (mismatched model) */
 #define CNOM_POS_Z1 2
 #define CNOM_POS_F0 4
 #define CNOM_POS_Z2 6
 #define CNOM_POS_K6 8
 #define CNOM_POS_F1 10
-#define CMIS_POS_Z1 2
-#define CMIS_POS_F0 5
-#define CMIS_POS_Z2 8
-#define CMIS_POS_K6A 11
-#define CMIS_POS_F1 12
-#define CMIS_POS_K6XY 16
+#define CMIS_POS_U1 2
+#define CMIS_POS_F0 4
+#define CMIS_POS_U2 6
+#define CMIS_POS_W 8
+#define CMIS_POS_F1 10
 
 void orc_collapsed_constants(double out[3]) {
     /* from the tableau, for the test that pins the literals above */
@@ -320,14 +329,35 @@ static void rhs_mean(const OrcParams* p, int mismatched, const double act[2], do
     }
 }
 
-static void rk45_construct(const OrcParams* p, int mismatched, OrcEnv* e, const double act[2], OrcNoise* nz,
-                           uint32_t env_id, int stream, uint32_t block, int pos_f0, int pos_f1, int stream_f1) {
+/* N = M(u) = sigma u + c g (g . u): the mismatched model's per-evaluation noise from a standard normal pair (see COL_* above) */
+static void noise_2d(const OrcParams* p, const double G[2], const double u[2], double N[2]) {
+    const double c = 1.0 / (p->sigma + sqrt(p->sigma * p->sigma + G[0] * G[0] + G[1] * G[1]));
+    const double t = c * (G[0] * u[0] + G[1] * u[1]);
+    N[0] = p->sigma * u[0] + G[0] * t;
+    N[1] = p->sigma * u[1] + G[1] * t;
+}
+
+/* one RHS evaluation of the mismatched model under the collapsed law: V + M(u), u = the next two draws */
+static void simulate_2d(const OrcParams* p, OrcEnv* e, const double act[2], NStream* ns, double fx[2]) {
+    double V[2], G[2], u[2], N[2];
+    rhs_mean(p, 1, act, V, G);
+    u[0] = ns_normal(ns, 1.0); u[1] = ns_normal(ns, 1.0);
+    noise_2d(p, G, u, N);
+    fx[0] = V[0] + N[0]; fx[1] = V[1] + N[1];
+    e->state_prime[0] = fx[0]; e->state_prime[1] = fx[1];
+    e->n_rhs++;
+}
+
+/* law2d: the constructor's two evaluations draw pairs through M (mismatched model under the collapsed law, after a step) */
+static void rk45_construct_ex(const OrcParams* p, int mismatched, OrcEnv* e, const double act[2], OrcNoise* nz,
+                              uint32_t env_id, int stream, uint32_t block, int pos_f0, int pos_f1, int stream_f1, int law2d) {
     NStream ns;
     ns_open(&ns, nz, env_id, stream, block);
     const double t0 = e->t, t_bound = e->t + p->time_span;
     double f0[2], f1[2];
     if (pos_f0 >= 0) ns_seek(&ns, pos_f0);
-    simulate(p, mismatched, e, act, &ns, f0);
+    if (law2d) simulate_2d(p, e, act, &ns, f0);
+    else simulate(p, mismatched, e, act, &ns, f0);
     e->f[0] = f0[0]; e->f[1] = f0[1];
     /* select_initial_step(fun, t0, y0, t_bound, max_step=inf, f0, direction=1, order=4, rtol, atol) */
     const double interval_length = fabs(t_bound - t0);
@@ -340,12 +370,17 @@ static void rk45_construct(const OrcParams* p, int mismatched, OrcEnv* e, const 
     /* y1 = y0 + h0*f0 is formed and passed to fun, which ignores it */
     if (stream_f1 >= 0) ns_open(&ns, nz, env_id, stream_f1, block); /* F1 lives in another stream's block */
     if (pos_f1 >= 0) ns_seek(&ns, pos_f1);
-    simulate(p, mismatched, e, act, &ns, f1);
+    if (law2d) simulate_2d(p, e, act, &ns, f1);
+    else simulate(p, mismatched, e, act, &ns, f1);
     const double d2 = rms2((f1[0] - f0[0]) / sc0, (f1[1] - f0[1]) / sc1) / h0;
     double h1;
     if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
     else h1 = pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
     e->h_abs = fmin(fmin(100 * h0, h1), interval_length); /* max_step = inf */
+}
+static void rk45_construct(const OrcParams* p, int mismatched, OrcEnv* e, const double act[2], OrcNoise* nz,
+                           uint32_t env_id, int stream, uint32_t block, int pos_f0, int pos_f1, int stream_f1) {
+    rk45_construct_ex(p, mismatched, e, act, nz, env_id, stream, block, pos_f0, pos_f1, stream_f1, 0);
 }
 
 /* Simulator.reset_start_pos.  MR_simulator.py:21-34: state, zero action, fresh RK45 at t0 = 0. */
@@ -432,16 +467,31 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
                  * B1 = E1 = 0:  dot(K[:-1].T, B) = B0 K0 + (1 - B0) V + S_B,  dot(K.T, E) = E0 (K0 - V) + S_E + E6 N_6 */
                 double V[2], G[2], z1[3], z2[3], z6[3];
                 rhs_mean(p, mis, act, V, G);
-                ns_seek(&ns, mis ? CMIS_POS_Z1 : CNOM_POS_Z1);
-                z1[0] = mis ? ns_normal(&ns, 1.0) : 0.0; z1[1] = ns_normal(&ns, 1.0); z1[2] = ns_normal(&ns, 1.0);
-                ns_seek(&ns, mis ? CMIS_POS_Z2 : CNOM_POS_Z2);
-                z2[0] = mis ? ns_normal(&ns, 1.0) : 0.0; z2[1] = ns_normal(&ns, 1.0); z2[2] = ns_normal(&ns, 1.0);
-                if (mis) {
-                    ns_seek(&ns, CMIS_POS_K6A); z6[0] = ns_normal(&ns, 1.0);
-                    ns_seek(&ns, CMIS_POS_K6XY); z6[1] = ns_normal(&ns, 1.0); z6[2] = ns_normal(&ns, 1.0);
-                } else {
-                    ns_seek(&ns, CNOM_POS_K6); z6[0] = 0.0; z6[1] = ns_normal(&ns, 1.0); z6[2] = ns_normal(&ns, 1.0);
+              if (mis) {
+                /* mismatched model: pairs through M, f_new's noise folded into the error sum (COL_* above) */
+                double u1[2], u2[2], w[2], v[2], SB[2], SE[2], N6[2];
+                ns_seek(&ns, CMIS_POS_U1); u1[0] = ns_normal(&ns, 1.0); u1[1] = ns_normal(&ns, 1.0);
+                ns_seek(&ns, CMIS_POS_U2); u2[0] = ns_normal(&ns, 1.0); u2[1] = ns_normal(&ns, 1.0);
+                ns_seek(&ns, CMIS_POS_W);  w[0] = ns_normal(&ns, 1.0);  w[1] = ns_normal(&ns, 1.0);
+                v[0] = COL_CB * u1[0]; v[1] = COL_CB * u1[1];
+                noise_2d(p, G, v, SB);
+                v[0] = COL_CE1 * u1[0] + COL_CE2P * u2[0]; v[1] = COL_CE1 * u1[1] + COL_CE2P * u2[1];
+                noise_2d(p, G, v, SE);                                              /* S_E + E6 N_6 */
+                v[0] = (RK_E[6] / COL_CE2P) * u2[0] + (COL_CE2 / COL_CE2P) * w[0];
+                v[1] = (RK_E[6] / COL_CE2P) * u2[1] + (COL_CE2 / COL_CE2P) * w[1];
+                noise_2d(p, G, v, N6);                                              /* N_6 given S_E' (only a following sub-step sees it) */
+                for (int c = 0; c < 2; ++c) {
+                    fn[c] = V[c] + N6[c];
+                    const double sB = RK_B[0] * K[0][c] + (1.0 - RK_B[0]) * V[c] + SB[c];
+                    const double sE = RK_E[0] * (K[0][c] - V[c]) + SE[c];
+                    if (c == 0) { s0 = sB; e0 = sE; } else { s1 = sB; e1 = sE; }
                 }
+              } else {
+                ns_seek(&ns, CNOM_POS_Z1);
+                z1[0] = 0.0; z1[1] = ns_normal(&ns, 1.0); z1[2] = ns_normal(&ns, 1.0);
+                ns_seek(&ns, CNOM_POS_Z2);
+                z2[0] = 0.0; z2[1] = ns_normal(&ns, 1.0); z2[2] = ns_normal(&ns, 1.0);
+                ns_seek(&ns, CNOM_POS_K6); z6[0] = 0.0; z6[1] = ns_normal(&ns, 1.0); z6[2] = ns_normal(&ns, 1.0);
                 for (int c = 0; c < 2; ++c) {
                     const double sb = G[c] * (COL_CB * z1[0]) + p->sigma * (COL_CB * z1[1 + c]);
                     const double se = G[c] * (COL_CE1 * z1[0] + COL_CE2 * z2[0]) +
@@ -452,6 +502,7 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
                     const double sE = RK_E[0] * (K[0][c] - V[c]) + se + RK_E[6] * n6;
                     if (c == 0) { s0 = sB; e0 = sE; } else { s1 = sB; e1 = sE; }
                 }
+              }
                 e->state_prime[0] = fn[0]; e->state_prime[1] = fn[1];            /* last RHS evaluation of rk_step */
                 e->n_rhs += 6;
             } else {
@@ -494,8 +545,8 @@ int orc_sim_step(const OrcParams* p, OrcEnv* e, double f_t, double alpha_t, OrcN
     }
     /* last_state = integrator.y (:45); new RK45 from (t, y) to t + time_span (:46-50) */
     if (collapsed)
-        rk45_construct(p, mis, e, act, nz, env_id, STREAM_DYN, attempt ? attempt - 1 : 0,
-                       mis ? CMIS_POS_F0 : CNOM_POS_F0, mis ? CMIS_POS_F1 : CNOM_POS_F1, -1);
+        rk45_construct_ex(p, mis, e, act, nz, env_id, STREAM_DYN, attempt ? attempt - 1 : 0,
+                          mis ? CMIS_POS_F0 : CNOM_POS_F0, mis ? CMIS_POS_F1 : CNOM_POS_F1, -1, mis);
     else
     rk45_construct(p, mis, e, act, nz, env_id, STREAM_DYN, attempt ? attempt - 1 : 0,
                    mis ? MIS_POS_F0 : NOM_POS_F0, mis ? MIS_POS_F1 : NOM_POS_F1, -1);
