@@ -278,10 +278,11 @@ def newest_profile(name):
 
 
 def profiled_config_matches(args, n_local):
-    """PMC counters cannot be read from inside the timed process: the committed passes describe ONE configuration
-    (the default one); any other run gets null instead of somebody else's counters."""
-    return (args.sigma == 1.0 and args.noise_math == "fast" and n_local == 262144 and args.obs_layout == "aos"
-            and args.workload == "ddpg" and not args.mismatched and (args.mode == "step" or args.rollout_len == 51))
+    """PMC counters cannot be read from inside the timed process: the committed passes describe a few configurations (the default
+    one; the mismatched model; N = 2 097 152 -- matched per record by committed_traffic / committed_valu); any other run gets
+    null instead of somebody else's counters."""
+    return (args.sigma == 1.0 and args.noise_math == "fast" and n_local in (262144, 2097152) and args.obs_layout == "aos"
+            and args.workload == "ddpg" and (args.mode == "step" or args.rollout_len == 51))
 
 
 def loaded_lib_sha16():
@@ -316,8 +317,9 @@ def committed_traffic(args, n_local, law=None):
         if not ok:
             return None, None, why
         for name, k in d["kernels"].items():
-            if name.startswith(key) and (args.mode == "step" or (k.get("carry", "f32") == args.carry and
-                                                                 k.get("noise_law", "per_stage") == law)):
+            if not (name.startswith(key) and bool(k.get("mismatched", False)) == bool(args.mismatched) and int(k.get("N", 262144)) == n_local):
+                continue
+            if args.mode == "step" or (k.get("carry", "f32") == args.carry and k.get("noise_law", "per_stage") == law):
                 return int(k["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT), None
     except Exception as exc:
         return None, None, "unreadable %s: %s" % (f, exc)
@@ -339,13 +341,13 @@ def committed_valu(args, n_local, T, law=None):
     -- shader cycles on both sides, so the clock the chip holds under load cancels.  Only for the profiled configuration."""
     law = law or args.noise_law
     f = newest_profile("pmc_valu.json")
-    if f is None or args.mode != "rollout" or not profiled_config_matches(args, n_local):
+    if f is None or args.mode != "rollout" or not profiled_config_matches(args, n_local) or n_local != 262144:
         return None
     try:
         d = json.load(open(f))
         if not counters_describe_this_build(d)[0]:
             return None
-        k = d["kernels"]["rollout_" + args.carry + ("" if law == "per_stage" else "_" + law)]
+        k = d["kernels"]["rollout_" + args.carry + ("" if law == "per_stage" else "_" + law) + ("_mismatched" if args.mismatched else "")]
         return {"valu_issue_frac": k["valu_issue_frac"], "valu_issue_frac_at_spec_rates": k.get("valu_issue_frac_at_spec_rates"),
                 "insts_valu_per_wave_step": k["insts_valu_per_wave_step"],
                 "issue_floor_cycles_per_wave_step": k["issue_floor_cycles_per_wave_step"],
@@ -952,10 +954,12 @@ def measure_streaming_point(args, cfg, dev, seed, n=2097152, episodes=60):
         avg_us, med_us = stats_us([e.elapsed_ms() for e in used])
         for e in pool:
             e.close()
-        moved = modelled_traffic(n, ep)
+        traffic, traffic_src, _why = committed_traffic(args, n, law)     # this size's own PMC passes, when committed for this build
+        moved = traffic if traffic else modelled_traffic(n, ep)
         gbs = moved / (avg_us * 1e-6) / 1e9
         out["rollout"][law] = {"value": n * episodes * ep / el, "unit": "env-steps/s", "avg_kernel_us": round(avg_us, 2),
                                "median_kernel_us": round(med_us, 2), "bytes_per_launch": moved,
+                               "bytes_source": traffic_src or "model N (33 T + 80)", "traffic": traffic,
                                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": round(gbs / HBM_PEAK_GBS, 4)},
                                "in_kernel_env_steps_per_s": n * ep / (avg_us * 1e-6)}

@@ -35,9 +35,10 @@ def sha16(path):
 
 # bench.py's default noise law is "collapsed" (kernel template argument NZ = 4); "_ps" passes = the per-stage law (NZ = 2)
 LAW_NZ = {"collapsed": 4, "per_stage": 2}
-EXPECTED = ["kt", "kt_s1", "kt_s1_ps", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
-                                             for p in ("pmc_f64", "pmc_f32", "pmc_ps_f64", "pmc_step", "cal", "cal262k")] + \
-           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32", "ps")] + \
+EXPECTED = ["kt", "kt_s1", "kt_s1_ps", "kt_s1_mis", "kt_step", "kt_2m", "kt_2m_ps", "kt_2m_step", "instbench"] + \
+           [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
+            for p in ("pmc_f64", "pmc_f32", "pmc_ps_f64", "pmc_mis_f64", "pmc_2m_f64", "pmc_2m_ps_f64", "pmc_2m_step", "pmc_step", "cal", "cal262k")] + \
+           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32", "ps", "mis")] + \
            ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed",
             "kt_actor_bf", "pmc_actor_bf_a", "kt_actor_b1", "pmc_actor_b1_a"]
 if not os.path.exists(f"{src}/status.txt"):
@@ -95,6 +96,14 @@ if not line_ps:
     die("kt_s1_ps.out holds no bench JSON line")
 files["bench_under_rocprof_rollout_streams1_per_stage.json"] = line_ps[-1] + "\n"
 files["kernel_stats_bench_step.csv"] = open(the_csv("kt_step", "kernel_stats.csv")).read()
+# the mismatched model and the N = 2 097 152 streaming point: rocprofv3 stats + the bench line of each run
+for pname, fname in (("kt_s1_mis", "rollout_streams1_mismatched"), ("kt_2m", "rollout_2m"), ("kt_2m_ps", "rollout_2m_per_stage"),
+                     ("kt_2m_step", "step_2m")):
+    files[f"kernel_stats_bench_{fname}.csv"] = open(the_csv(pname, "kernel_stats.csv")).read()
+    ln = [l for l in open(f"{src}/{pname}.out").read().splitlines() if l.startswith("{")]
+    if not ln:
+        die(f"{pname}.out holds no bench JSON line")
+    files[f"bench_under_rocprof_{fname}.json"] = ln[-1] + "\n"
 line1 = [l for l in open(f"{src}/kt_s1.out").read().splitlines() if l.startswith("{")]
 if not line1:
     die("kt_s1.out holds no bench JSON line")
@@ -146,11 +155,16 @@ for label, d, n in (("membench pattern<256> n=16777216", "cal", 16777216), ("mem
     traffic["calibration"][label] = {"known_read_KiB": n * 44 / 1024, "FETCH_SIZE_raw_KiB": fr["FETCH_SIZE"],
                                      "FETCH_SIZE_x2_KiB": 2 * fr["FETCH_SIZE"], "known_write_KiB": n * 61 / 1024,
                                      "WRITE_SIZE_KiB": wr["WRITE_SIZE"], "source": [prov(f1), prov(f2)]}
-for label, pre, sub, units, carry, law in (
-        (f"mr_rollout_kernel<RK45,fast+collapsed,nominal,carry=f64> T={T} N={N}", "pmc_f64", "mr_rollout_kernel<true, 4, false", N * T, "f64", "collapsed"),
-        (f"mr_rollout_kernel<RK45,fast+collapsed,nominal,carry=f32> T={T} N={N}", "pmc_f32", "mr_rollout_kernel<true, 4, false", N * T, "f32", "collapsed"),
-        (f"mr_rollout_kernel<RK45,fast,nominal,carry=f64> T={T} N={N}", "pmc_ps_f64", "mr_rollout_kernel<true, 2, false", N * T, "f64", "per_stage"),
-        (f"mr_step_kernel<RK45,fast+collapsed,nominal,aos> N={N}", "pmc_step", "mr_step_kernel<true, 4, false, true", N, None, "collapsed")):
+N2M = 2097152
+for label, pre, sub, units, carry, law, mis, n_envs in (
+        (f"mr_rollout_kernel<RK45,fast+collapsed,nominal,carry=f64> T={T} N={N}", "pmc_f64", "mr_rollout_kernel<true, 4, false", N * T, "f64", "collapsed", False, N),
+        (f"mr_rollout_kernel<RK45,fast+collapsed,nominal,carry=f32> T={T} N={N}", "pmc_f32", "mr_rollout_kernel<true, 4, false", N * T, "f32", "collapsed", False, N),
+        (f"mr_rollout_kernel<RK45,fast,nominal,carry=f64> T={T} N={N}", "pmc_ps_f64", "mr_rollout_kernel<true, 2, false", N * T, "f64", "per_stage", False, N),
+        (f"mr_rollout_kernel<RK45,fast+collapsed,mismatched,carry=f64> T={T} N={N}", "pmc_mis_f64", "mr_rollout_kernel<true, 4, true", N * T, "f64", "collapsed", True, N),
+        (f"mr_rollout_kernel<RK45,fast+collapsed,nominal,carry=f64> T={T} N={N2M}", "pmc_2m_f64", "mr_rollout_kernel<true, 4, false", N2M * T, "f64", "collapsed", False, N2M),
+        (f"mr_rollout_kernel<RK45,fast,nominal,carry=f64> T={T} N={N2M}", "pmc_2m_ps_f64", "mr_rollout_kernel<true, 2, false", N2M * T, "f64", "per_stage", False, N2M),
+        (f"mr_step_kernel<RK45,fast+collapsed,nominal,aos> N={N2M}", "pmc_2m_step", "mr_step_kernel<true, 4, false, true", N2M, None, "collapsed", False, N2M),
+        (f"mr_step_kernel<RK45,fast+collapsed,nominal,aos> N={N}", "pmc_step", "mr_step_kernel<true, 4, false, true", N, None, "collapsed", False, N)):
     fr, nf, _, f1 = counters(f"{pre}_FETCH_SIZE", sub)
     wr, nw, _, f2 = counters(f"{pre}_WRITE_SIZE", sub)
     b = (2 * fr["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024
@@ -160,6 +174,8 @@ for label, pre, sub, units, carry, law in (
     if carry:
         k["carry"] = carry
     k["noise_law"] = law
+    k["mismatched"] = mis
+    k["N"] = n_envs
     traffic["kernels"][label] = k
 files["pmc_traffic.json"] = json.dumps(traffic, indent=1) + "\n"
 
@@ -197,10 +213,11 @@ valu = {"what": "rocprofv3 --pmc SQ counters of the fused rollout kernel per wav
                         "w4": {op: {"cycles": cost[op][4]["cycles"], "ns": cost[op][4]["ns"]}
                                for op in sorted(set(CLASS_OP.values()) | {"v_xor_b32"})}},
         "kernels": {}}
-for carry, law, tagp in (("f64", "collapsed", "f64"), ("f32", "collapsed", "f32"), ("f64", "per_stage", "ps")):
+for carry, law, tagp, mis in (("f64", "collapsed", "f64", False), ("f32", "collapsed", "f32", False), ("f64", "per_stage", "ps", False),
+                              ("f64", "collapsed", "mis", True)):
     per, srcs = {}, []
     for g in "abc":
-        c, nd, grid, f = counters(f"valu_{g}_{tagp}", f"mr_rollout_kernel<true, {LAW_NZ[law]}, false")
+        c, nd, grid, f = counters(f"valu_{g}_{tagp}", f"mr_rollout_kernel<true, {LAW_NZ[law]}, {'true' if mis else 'false'}")
         srcs.append(prov(f))
         for k, v in c.items():
             per[k] = v / (grid / 64) / T
@@ -211,11 +228,11 @@ for carry, law, tagp in (("f64", "collapsed", "f64"), ("f32", "collapsed", "f32"
         fl[unit] = sum(per[k] * cost[op][4][unit] for k, op in CLASS_OP.items()) + other * cost["v_xor_b32"][4][unit]
     wave_cycles = 4.0 * per["SQ_WAVE_CYCLES"]
     spec_floor = sum(per[k] * SPEC_CYCLES[k] for k in CLASS_OP) + other * SPEC_CYCLES["other"]
-    valu["kernels"]["rollout_" + carry + ("" if law == "per_stage" else "_" + law)] = {
-        "noise_law": law,
+    valu["kernels"]["rollout_" + carry + ("" if law == "per_stage" else "_" + law) + ("_mismatched" if mis else "")] = {
+        "noise_law": law, "mismatched": mis,
         "issue_floor_cycles_per_wave_step_at_spec_rates": round(spec_floor, 1),
         "valu_issue_frac_at_spec_rates": round(WPS * spec_floor / wave_cycles, 4),
-        "kernel": f"mr_rollout_kernel<RK45,fast{'+collapsed' if law == 'collapsed' else ''},nominal,carry={carry}>", "per_wave_step": {k: round(v, 2) for k, v in sorted(per.items())},
+        "kernel": f"mr_rollout_kernel<RK45,fast{'+collapsed' if law == 'collapsed' else ''},{'mismatched' if mis else 'nominal'},carry={carry}>", "per_wave_step": {k: round(v, 2) for k, v in sorted(per.items())},
         "insts_valu_per_wave_step": round(per["SQ_INSTS_VALU"], 2), "other_valu_per_wave_step": round(other, 2),
         "issue_floor_cycles_per_wave_step": round(fl["cycles"], 1), "wave_cycles_per_wave_step": round(wave_cycles, 1),
         "valu_issue_frac": round(WPS * fl["cycles"] / wave_cycles, 4),

@@ -3,7 +3,8 @@
 # Every pass writes its exit code to $O/status.txt; tools/collect_profiles.py refuses to build profiles/<tag>/ from a
 # round in which a pass failed or whose CSVs are older than the library / bench.py they claim to describe.
 #  1) kernel trace + stats of the default bench command (rollout, 2 sub-shard streams), of `--streams 1` (one launch per
-#     episode: the kernel duration bench.py's roofline quotes) and of --mode step;
+#     episode: the kernel duration bench.py's roofline quotes; also --noise-law per_stage and --mismatched), of --mode step, and of
+#     the N = 2 097 152 streaming point (rollout both laws, step kernel);
 #  2) PMC passes, each counter group in its own run with no trace flags (MI355X_MICROARCH.md, rocprofv3 PMC slots):
 #     FETCH_SIZE / WRITE_SIZE of the rollout kernel (both carries) and of the eager step path, calibrated on
 #     tools/membench whose bytes are known exactly; SQ instruction-mix and busy / wait counters of the rollout kernel;
@@ -18,16 +19,27 @@ pass() {  # pass <name> <cmd...>: run, record the exit code
   "$@" > $O/$name.out 2> $O/$name.log
   echo "$name $?" >> $O/status.txt
 }
-PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --no-actor-leg --no-learner-leg --no-other-law --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
+PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --no-actor-leg --no-learner-leg --no-other-law --no-facade-leg --no-streaming-point --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
+S1ARGS="--no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg --no-facade-leg --no-streaming-point"
 pass kt rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-power
-pass kt_s1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1 -- python3 $R/bench.py --no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg
-pass kt_s1_ps rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1_ps -- python3 $R/bench.py --no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg --noise-law per_stage
-pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --no-power --mode step
+pass kt_s1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1 -- python3 $R/bench.py $S1ARGS
+pass kt_s1_ps rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1_ps -- python3 $R/bench.py $S1ARGS --noise-law per_stage
+pass kt_s1_mis rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1_mis -- python3 $R/bench.py $S1ARGS --mismatched
+pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --no-power --mode step --no-facade-leg
+# ---- SURVEY H4's streaming point: N = 2 097 152 envs on this one GPU (rollout both laws, step kernel)
+BIG="--envs-per-gpu 2097152 --settle-episodes 40 --warmup 510 --steps 2040 --sustained-steps 2040"
+pass kt_2m rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2m -- python3 $R/bench.py $S1ARGS $BIG
+pass kt_2m_ps rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2m_ps -- python3 $R/bench.py $S1ARGS $BIG --noise-law per_stage
+pass kt_2m_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2m_step -- python3 $R/bench.py --no-cpu-baseline --no-power --no-facade-leg --mode step --launch eager --envs-per-gpu 2097152 --settle-episodes 10 --warmup 102 --steps 510
 for c in FETCH_SIZE WRITE_SIZE; do
   for carry in f64 f32; do
     pass pmc_${carry}_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_${carry}_$c -- python3 $R/bench.py $PMCARGS --carry $carry
   done
   pass pmc_ps_f64_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_ps_f64_$c -- python3 $R/bench.py $PMCARGS --carry f64 --noise-law per_stage
+  pass pmc_mis_f64_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_mis_f64_$c -- python3 $R/bench.py $PMCARGS --carry f64 --mismatched
+  pass pmc_2m_f64_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_2m_f64_$c -- python3 $R/bench.py $PMCARGS --carry f64 --envs-per-gpu 2097152
+  pass pmc_2m_ps_f64_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_2m_ps_f64_$c -- python3 $R/bench.py $PMCARGS --carry f64 --envs-per-gpu 2097152 --noise-law per_stage
+  pass pmc_2m_step_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_2m_step_$c -- python3 $R/bench.py $PMCARGS --mode step --launch eager --envs-per-gpu 2097152
   pass pmc_step_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_step_$c -- python3 $R/bench.py $PMCARGS --mode step --launch eager
   pass cal_$c rocprofv3 --pmc $c --output-format csv -d $O/cal_$c -- $R/tools/membench 16777216 20
   pass cal262k_$c rocprofv3 --pmc $c --output-format csv -d $O/cal262k_$c -- $R/tools/membench 262144 20
@@ -41,6 +53,10 @@ done
 pass valu_a_ps rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/valu_a_ps -- python3 $R/bench.py $PMCARGS --carry f64 --noise-law per_stage
 pass valu_b_ps rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VMEM_WR --output-format csv -d $O/valu_b_ps -- python3 $R/bench.py $PMCARGS --carry f64 --noise-law per_stage
 pass valu_c_ps rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD --output-format csv -d $O/valu_c_ps -- python3 $R/bench.py $PMCARGS --carry f64 --noise-law per_stage
+# the mismatched model (collapsed law: two Philox calls, three Box-Muller pairs)
+pass valu_a_mis rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/valu_a_mis -- python3 $R/bench.py $PMCARGS --carry f64 --mismatched
+pass valu_b_mis rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VMEM_WR --output-format csv -d $O/valu_b_mis -- python3 $R/bench.py $PMCARGS --carry f64 --mismatched
+pass valu_c_mis rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD --output-format csv -d $O/valu_c_mis -- python3 $R/bench.py $PMCARGS --carry f64 --mismatched
 # ---- the fused rollout with the DDPG actor as its policy source (tools/actor_probe.py: 262 144 envs, 51 steps per launch)
 pass kt_actor rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_actor -- python3 $R/tools/actor_probe.py --launches 200
 pass pmc_actor_a rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/pmc_actor_a -- python3 $R/tools/actor_probe.py --launches 6 --discard 0
