@@ -1011,8 +1011,9 @@ def verify_ranks(args, cfg, world, rank, dev, seed, n_local, probe_envs=4096):
              "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
              "uuid": str(getattr(pr, "uuid", "")), "pid": os.getpid()}
     if world > 1:
-        every = torch.zeros((world, 5), dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        every = torch.zeros(world * 5, dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_gather_into_tensor(every, mine if args.dist_backend == "nccl" else mine.cpu())
+        every = every.view(world, 5)
         idents = [None] * world
         dist.all_gather_object(idents, ident)
     else:
