@@ -127,6 +127,8 @@ def parse(argv=None):
     ap.add_argument("--settle-episodes", type=int, default=400,
                     help="untimed episodes before the W warm-up steps so that the GPU clocks have settled whatever W "
                          "is (a fixed count, not a time: every rank must issue the same collectives)")
+    ap.add_argument("--queue-depth", type=int, default=32,
+                    help="untimed settle phase: episodes enqueued between two device-wide synchronizes (bounded launch queue; any --steps)")
     ap.add_argument("--sustained-steps", type=int, default=10200, help="length of the `sustained` leg (0 = skip)")
     ap.add_argument("--no-step-path", action="store_true", help="skip the extra one-launch-per-step measurement")
     ap.add_argument("--no-mixed-set", action="store_true", help="skip the extra mixed-trajectory-set measurement")
@@ -1181,7 +1183,14 @@ def main():
 
     # clock settle (tools/clock_ramp_probe.py: ~35 ms of load after idle), independent of the W the caller asks for
     trace("env ready; settle phase: %d episodes" % args.settle_episodes)
-    run(args.settle_episodes * ep)
+    # the untimed phases keep the launch queue BOUNDED, as a loop that consumes its episodes does (every launch group of a real
+    # collection loop is waited for by somebody): a device-wide synchronize every --queue-depth episodes.  Hundreds of launches queued
+    # without a wait leave the HIP runtime a backlog of completed dispatches to retire, which the next launch calls then pay for
+    # (25 - 240 us each instead of ~10, tools/enqueue_profile.py) -- whatever the length of the region that follows.
+    qd = max(1, args.queue_depth)
+    for e0 in range(0, args.settle_episodes, qd):
+        run(min(qd, args.settle_episodes - e0) * ep)
+        torch.cuda.synchronize(dev)
     trace("settle issued; warm-up %d steps" % W)
     run(W)
     barrier()
