@@ -55,6 +55,7 @@ struct Args {
     int32_t* rows_scratch;          // [batch]: the rows of this update (critic half -> actor half)
     float* loss_partial;            // [tiles][2]
     unsigned int* counter;          // [2]: arrival tickets of the two halves (zero between launches)
+    int32_t reduce_in_kernel;       // 1: the last workgroup to arrive reduces and steps (few tiles); 0: mr_ddpg_mw_step_kernel does
 };
 
 // C[m0 .. m0+TM)[n0 .. n0+TN) = sum_k A(m, k) B(k, n).  B is k-major ([K][ldb], n contiguous).  A is k-major ([K][lda], m
@@ -583,6 +584,7 @@ __device__ __forceinline__ void ddpg_update_body(const Args& A, Lds& L) {
     LPROBE(4);   // critic forward + backward
     if constexpr (MODE == kModeCriticHalf) {
         if (tid == 0) A.loss_partial[blockIdx.x * 2 + 0] = L.loss[0];
+        if (!A.reduce_in_kernel) return;                 // many tiles: a launch of its own sums the rows across compute units
         if (!mw_arrive_last(A, L, 0, tid)) return;       // (uniform: the whole workgroup leaves)
         mw_reduce<C_W1, kParams>(A, L, 0, tid);
         if (tid == 0) { A.counter[0] = 0u; if (A.losses != nullptr) A.losses[0] = L.loss[0]; }
@@ -739,6 +741,7 @@ __device__ __forceinline__ void ddpg_update_body(const Args& A, Lds& L) {
     LPROBE(7);   // actor forward, critic forward, backward through both
     if constexpr (MODE == kModeActorHalf) {
         if (tid == 0) A.loss_partial[blockIdx.x * 2 + 1] = L.loss[1];
+        if (!A.reduce_in_kernel) return;
         if (!mw_arrive_last(A, L, 1, tid)) return;
         mw_reduce<A_W1, C_W1>(A, L, 1, tid);
         if (tid == 0) A.counter[1] = 0u;
@@ -751,6 +754,56 @@ __device__ __forceinline__ void ddpg_update_body(const Args& A, Lds& L) {
     __syncthreads();    // the next update of this launch stages the parameters this one wrote
     LPROBE(8);   // actor Adam + soft update
   }
+}
+
+// Many tiles (batch > 256): the sum over the workgroups' rows and the Adam + soft-update step as a launch of their own, four
+// parameters per lane over as many workgroups as the half has parameters / 1024 -- the sum over 64 rows of 30 KB is 2 MB of L2
+// reads, tens of microseconds for ONE workgroup and a few for the device.  Same order of additions (row 0, 1, 2, ...), same Adam
+// arithmetic as adam_soft: bit-identical to the in-kernel form.  HALF 0 = critic (C_W1 .. kParams), 1 = actor (A_W1 .. C_W1).
+template <int HALF>
+__global__ __launch_bounds__(kThreads) void mr_ddpg_mw_step_kernel(const Args A, int tiles) {
+    constexpr int P0 = HALF == 0 ? C_W1 : A_W1, P1 = HALF == 0 ? kParams : C_W1;
+    const int tid = threadIdx.x;
+    const int p = P0 + ((int)blockIdx.x * kThreads + tid) * 4;
+    const int t = A.steps[HALF] + 1;
+    const float bc1 = (float)(1.0 - ipow((double)A.beta1, t)), bc2s = (float)sqrt(1.0 - ipow((double)A.beta2, t));
+    const float lr = HALF == 0 ? A.critic_lr : A.actor_lr;
+    if (p < P1) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < tiles; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(A.partial + (size_t)g * kParams + p);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(A.grad + p) = acc;
+        const float c1 = 1.0f - A.beta1, c2 = 1.0f - A.beta2, step = lr / bc1, omt = 1.0f - A.tau;
+        const float4 m4 = *reinterpret_cast<const float4*>(A.adam_m + p), v4 = *reinterpret_cast<const float4*>(A.adam_v + p),
+                     o4 = *reinterpret_cast<const float4*>(A.online + p), t4 = *reinterpret_cast<const float4*>(A.target + p);
+        const float g[4] = {acc.x, acc.y, acc.z, acc.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w},
+                    oo[4] = {o4.x, o4.y, o4.z, o4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+        float mo[4], vo[4], th[4], tg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mo[q] = __builtin_fmaf(A.beta1, mm[q], c1 * g[q]);
+            vo[q] = __builtin_fmaf(A.beta2, vv[q], c2 * g[q] * g[q]);
+            th[q] = oo[q] - step * (mo[q] / (sqrtf(vo[q]) / bc2s + A.adam_eps));
+            tg[q] = __builtin_fmaf(A.tau, th[q], omt * tt[q]);
+        }
+        *reinterpret_cast<float4*>(A.adam_m + p) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+        *reinterpret_cast<float4*>(A.adam_v + p) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+        *reinterpret_cast<float4*>(A.online + p) = make_float4(th[0], th[1], th[2], th[3]);
+        *reinterpret_cast<float4*>(A.target + p) = make_float4(tg[0], tg[1], tg[2], tg[3]);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        float l = 0.f;
+        for (int g = 0; g < tiles; ++g) l += A.loss_partial[g * 2 + HALF];
+        if (A.losses != nullptr) A.losses[HALF] = l;
+    }
+    // the step counters advance once per update, after BOTH halves have read them: the actor half's step launch is the last
+    // kernel of the update, and every workgroup of it has read steps[] above before any can get here -- not guaranteed across
+    // workgroups, so the increment is left to the launch that follows (mr_ddpg_mw_count_kernel)
+}
+__global__ void mr_ddpg_mw_count_kernel(int32_t* steps) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) steps[threadIdx.x] += 1;
 }
 
 __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) {
