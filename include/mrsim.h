@@ -253,9 +253,9 @@ typedef struct MrsimDdpgLearner {
     float action_bound[2];   /* :345 env.action_space.high                                                                */
     float* batch_scratch;    /* DEVICE, 16-byte aligned, ZERO-INITIALISED once by the caller, or NULL (ABI 5): work space of the  */
                              /*   multi-workgroup form -- with it, a batch of more than 64 transitions runs as batch / 64         */
-                             /*   workgroups on as many compute units (two launches per update: the critic's step needs the      */
-                             /*   whole batch's gradient, the actor's gradient the updated critic) instead of one workgroup      */
-                             /*   looping over the tiles; results are deterministic (partial gradients summed in tile order)     */
+                             /*   workgroups on as many compute units (two to five launches per update: the critic's step needs  */
+                             /*   the whole batch's gradient, the actor's gradient the updated critic) instead of one workgroup  */
+                             /*   looping over the tiles; partial gradients are summed in tile order: bit-identical to that loop */
     int64_t batch_scratch_floats; /* its size in floats: >= MRSIM_DDPG_BATCH_SCRATCH_FLOATS(batch)                                 */
 } MrsimDdpgLearner;
 #define MRSIM_DDPG_BATCH_SCRATCH_FLOATS(batch) ((int64_t)((batch) / 64) * (MRSIM_DDPG_PARAMS + 4) + (batch) + 64)
