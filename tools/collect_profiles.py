@@ -41,22 +41,31 @@ EXPECTED = ["kt", "kt_s1", "kt_s1_ps", "kt_s1_mis", "kt_step", "kt_2m", "kt_2m_p
            [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32", "ps", "mis")] + \
            ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed",
             "kt_actor_bf", "pmc_actor_bf_a", "kt_actor_b1", "pmc_actor_b1_a"]
-if not os.path.exists(f"{src}/status.txt"):
-    die(f"{src}/status.txt not found (did tools/profile_round.sh {tag} run?)")
-status = dict(l.split() for l in open(f"{src}/status.txt").read().splitlines() if l.strip())
+# a round may have been taken in parts (profile_round.sh <tag> a|b|c: one gpurun call each): status_<part>.txt, manifest_<part>.txt,
+# sha_<part>.txt are united; every part must describe the same build
+status_files = sorted(glob.glob(f"{src}/status*.txt"))
+if not status_files:
+    die(f"{src}/status*.txt not found (did tools/profile_round.sh {tag} run?)")
+status = {}
+for sf in status_files:
+    status.update(dict(l.split() for l in open(sf).read().splitlines() if l.strip() and not l.startswith("stopping")))
 bad = [k for k in EXPECTED if status.get(k) != "0"]
 if bad:
     die("passes failed or missing: " + ", ".join(f"{k}={status.get(k, 'absent')}" for k in bad))
-shas = {os.path.basename(l.split()[1]): l.split()[0][:16] for l in open(f"{src}/sha.txt").read().splitlines()}
 here = {"bench.py": sha16("bench.py"), "libmrsim.so": sha16("mr_rl_amd/libmrsim.so")}
-if shas != here:
-    die(f"the round describes bench.py/libmrsim.so {shas}, this tree has {here}")
+sha_files = sorted(glob.glob(f"{src}/sha*.txt"))
+if len(sha_files) != len(status_files):
+    die(f"{len(status_files)} status files but {len(sha_files)} sha files")
+for shf in sha_files:
+    shas = {os.path.basename(l.split()[1]): l.split()[0][:16] for l in open(shf).read().splitlines()}
+    if shas != here:
+        die(f"{shf} describes bench.py/libmrsim.so {shas}, this tree has {here}")
 
-
-if not os.path.exists(f"{src}/manifest.txt"):
-    die(f"{src}/manifest.txt not found")
-MANIFEST = set(open(f"{src}/manifest.txt").read().split())  # files of THIS round (gpurun merges into gpurun_out/: files of
-                                                            # an earlier round of the same tag may still lie beside them)
+MANIFEST = set()
+for mf in sorted(glob.glob(f"{src}/manifest*.txt")):
+    MANIFEST |= set(open(mf).read().split())   # files of THIS round (gpurun merges into gpurun_out/: files of an earlier round of
+if not MANIFEST:                               # the same tag may still lie beside them)
+    die(f"{src}/manifest*.txt not found")
 
 
 def the_csv(dirname, suffix):

@@ -11,13 +11,19 @@
 #  3) tools/instbench --json: per-instruction issue costs that price the instruction mix.
 # The PMC passes use the bench's own flags to skip its hipGraph leg (graph capture under --pmc crashes rocprofv3 on
 # ROCm 7.2 -- bench.py also skips it by itself when it sees ROCPROF_COUNTER_COLLECTION).
-R=$GRAFT_REPO_ROOT; tag=${1:-r02}; O=$R/gpurun_out/prof_$tag; rm -rf $O; mkdir -p $O
+# A round is longer than one gpurun call may last (20 min): `profile_round.sh <tag> a` (kernel traces) and `... b` / `... c` (counter
+# passes) run in separate calls; each part writes status_<part>.txt / manifest_<part>.txt / sha_<part>.txt, which
+# tools/collect_profiles.py unites (and refuses if the parts were taken with different builds).
+R=$GRAFT_REPO_ROOT; tag=${1:-r02}; part=${2:-all}; O=$R/gpurun_out/prof_$tag; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-: > $O/status.txt
-pass() {  # pass <name> <cmd...>: run, record the exit code
+: > $O/status_$part.txt
+want() { [ "$part" = all ] || [ "$part" = "$1" ]; }   # want <part>: does this invocation run the passes of that part?
+PART_OF_NEXT=a
+pass() {  # pass <name> <cmd...>: run (if the pass belongs to this invocation's part), record the exit code
   name=$1; shift
-  "$@" > $O/$name.out 2> $O/$name.log
-  echo "$name $?" >> $O/status.txt
+  want $PART_OF_NEXT || return 0
+  timeout -k 10 400 "$@" > $O/$name.out 2> $O/$name.log
+  echo "$name $?" >> $O/status_$part.txt
 }
 PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --no-actor-leg --no-learner-leg --no-other-law --no-facade-leg --no-streaming-point --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
 S1ARGS="--no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg --no-facade-leg --no-streaming-point"
@@ -31,6 +37,7 @@ BIG="--envs-per-gpu 2097152 --settle-episodes 40 --warmup 510 --steps 2040 --sus
 pass kt_2m rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2m -- python3 $R/bench.py $S1ARGS $BIG
 pass kt_2m_ps rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2m_ps -- python3 $R/bench.py $S1ARGS $BIG --noise-law per_stage
 pass kt_2m_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2m_step -- python3 $R/bench.py --no-cpu-baseline --no-power --no-facade-leg --mode step --launch eager --envs-per-gpu 2097152 --settle-episodes 10 --warmup 102 --steps 510
+PART_OF_NEXT=b
 for c in FETCH_SIZE WRITE_SIZE; do
   for carry in f64 f32; do
     pass pmc_${carry}_$c rocprofv3 --pmc $c --output-format csv -d $O/pmc_${carry}_$c -- python3 $R/bench.py $PMCARGS --carry $carry
@@ -44,6 +51,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pass cal_$c rocprofv3 --pmc $c --output-format csv -d $O/cal_$c -- $R/tools/membench 16777216 20
   pass cal262k_$c rocprofv3 --pmc $c --output-format csv -d $O/cal262k_$c -- $R/tools/membench 262144 20
 done
+PART_OF_NEXT=c
 for carry in f64 f32; do
   pass valu_a_$carry rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/valu_a_$carry -- python3 $R/bench.py $PMCARGS --carry $carry
   pass valu_b_$carry rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VMEM_WR --output-format csv -d $O/valu_b_$carry -- python3 $R/bench.py $PMCARGS --carry $carry
@@ -72,7 +80,7 @@ pass pmc_actor_b1_a rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU 
 # ---- the mixed trajectory set (BASELINE config 5's workload): instruction count per wave-step
 pass valu_a_mixed rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/valu_a_mixed -- python3 $R/bench.py $PMCARGS --workload mixed --carry f64
 pass instbench $R/tools/instbench --json
-sha256sum $R/bench.py $R/mr_rl_amd/libmrsim.so > $O/sha.txt
-(cd $O && find . -type f ! -name manifest.txt | sed 's|^\./||' | sort) > $O/manifest.txt   # what THIS round wrote
-cat $O/status.txt
-echo profile_round done
+sha256sum $R/bench.py $R/mr_rl_amd/libmrsim.so > $O/sha_$part.txt
+(cd $O && find . -type f ! -name "manifest*.txt" | sed 's|^\./||' | sort) > $O/manifest_$part.txt   # what THIS invocation wrote
+cat $O/status_$part.txt
+echo profile_round $part done
