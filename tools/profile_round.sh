@@ -24,6 +24,14 @@ pass() {  # pass <name> <cmd...>: run (if the pass belongs to this invocation's 
   want $PART_OF_NEXT || return 0
   timeout -k 10 400 "$@" > $O/$name.out 2> $O/$name.log
   echo "$name $?" >> $O/status_$part.txt
+  # gpurun copies back at most 64 MiB: per-dispatch traces are kept only where tools/collect_profiles.py reads them (the rollout
+  # kernels' rows of the one-stream run and of the actor probes); everywhere else the --stats summary is what is committed
+  for f in $(find $O/$name -name "*kernel_trace.csv" 2>/dev/null); do
+    case $name in
+      kt_s1|kt_actor|kt_actor_bf|kt_actor_b1) (head -1 $f; grep mr_rollout $f) > $f.tmp; mv $f.tmp $f ;;
+      *) rm -f $f ;;
+    esac
+  done
 }
 PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --no-actor-leg --no-learner-leg --no-other-law --no-facade-leg --no-streaming-point --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
 S1ARGS="--no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg --no-facade-leg --no-streaming-point"
