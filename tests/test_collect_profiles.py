@@ -7,9 +7,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRIPT = os.path.join(ROOT, "tools", "collect_profiles.py")
-EXPECTED = ["kt", "kt_s1", "kt_s1_ps", "kt_step", "instbench"] + [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
-                                             for p in ("pmc_f64", "pmc_f32", "pmc_ps_f64", "pmc_step", "cal", "cal262k")] + \
-           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32", "ps")] + \
+EXPECTED = ["kt", "kt_s1", "kt_s1_ps", "kt_s1_mis", "kt_step", "kt_2m", "kt_2m_ps", "kt_2m_step", "instbench"] + \
+           [f"{p}_{c}" for c in ("FETCH_SIZE", "WRITE_SIZE")
+            for p in ("pmc_f64", "pmc_f32", "pmc_ps_f64", "pmc_mis_f64", "pmc_2m_f64", "pmc_2m_ps_f64", "pmc_2m_step", "pmc_step", "cal", "cal262k")] + \
+           [f"valu_{g}_{c}" for g in "abc" for c in ("f64", "f32", "ps", "mis")] + \
            ["kt_actor", "pmc_actor_a", "pmc_actor_b", "pmc_actor_FETCH_SIZE", "pmc_actor_WRITE_SIZE", "valu_a_mixed",
             "kt_actor_bf", "pmc_actor_bf_a", "kt_actor_b1", "pmc_actor_b1_a"]
 
@@ -20,14 +21,17 @@ def _tree(tmp_path, status_lines, sha_ok=True):
     (tmp_path / "mr_rl_amd" / "libmrsim.so").write_bytes(b"\x7fELF-not-really")
     src = tmp_path / "gpurun_out" / "prof_t9"
     src.mkdir(parents=True)
-    if status_lines is not None:
-        (src / "status.txt").write_text("\n".join(status_lines) + "\n")
+    if status_lines is not None:     # a round taken in two parts (profile_round.sh <tag> a|b): the collector unites them
+        half = len(status_lines) // 2
+        (src / "status_a.txt").write_text("\n".join(status_lines[:half]) + "\n")
+        (src / "status_b.txt").write_text("\n".join(status_lines[half:]) + "\n")
     h = lambda p: hashlib.sha256(p.read_bytes()).hexdigest()  # noqa: E731
     b, l = h(tmp_path / "bench.py"), h(tmp_path / "mr_rl_amd" / "libmrsim.so")
     if not sha_ok:
         b = "0" * 64
-    (src / "sha.txt").write_text(f"{b}  /x/bench.py\n{l}  /x/mr_rl_amd/libmrsim.so\n")
-    (src / "manifest.txt").write_text("status.txt\nsha.txt\n")
+    for part in "ab":
+        (src / f"sha_{part}.txt").write_text(f"{b}  /x/bench.py\n{l}  /x/mr_rl_amd/libmrsim.so\n")
+        (src / f"manifest_{part}.txt").write_text(f"status_{part}.txt\nsha_{part}.txt\n")
     return src
 
 
@@ -46,9 +50,10 @@ def test_refuses_when_a_pass_is_missing_or_no_status(tmp_path):
     _tree(tmp_path, [f"{k} 0" for k in EXPECTED if k != "valu_b_f64"])
     r = _run(tmp_path)
     assert r.returncode != 0 and "valu_b_f64=absent" in r.stderr and not (tmp_path / "profiles").exists()
-    (tmp_path / "gpurun_out" / "prof_t9" / "status.txt").unlink()
+    for part in "ab":
+        (tmp_path / "gpurun_out" / "prof_t9" / f"status_{part}.txt").unlink()
     r = _run(tmp_path)
-    assert r.returncode != 0 and "status.txt not found" in r.stderr
+    assert r.returncode != 0 and "status*.txt not found" in r.stderr
 
 
 def test_refuses_another_builds_round(tmp_path):
