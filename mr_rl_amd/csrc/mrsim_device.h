@@ -1421,6 +1421,19 @@ template <bool RK45, int NZ, bool MIS>
 __device__ __forceinline__ void step_prologue(const KParams& P, const Rng& R, bool random_policy,
                                               StepWords<RK45, NZ, MIS>& W, float& af, float& aa, bool policy_words = false) {
     using SW = StepWords<RK45, NZ, MIS>;
+#ifdef MRSIM_AB_SHARE   // MEASUREMENT build only (tools/ab_rollout.py): what the nominal collapsed kernel would gain if the policy's two
+    // words were shared by two consecutive steps (1.5 Philox calls per step instead of 2): odd steps pay ONE call, their second
+    // call's words are a scramble of the first's.  Wrong draws, right instruction mix.
+    if constexpr (nz_coll(NZ) && !MIS) {
+        if (R.step_lo & 1u) {
+            philox_call(R, c0_of(kStreamDyn, 0, 0), W.w[0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) W.w[1][j] = W.w[0][(j + 1) & 3] ^ 0x9E3779B9u;
+            if (random_policy) action_from_words(P, W.w[0], af, aa);
+            return;
+        }
+    }
+#endif
     if constexpr (SW::NDYN > 0) {
         uint32_t c0s[SW::N];
 #pragma unroll
