@@ -98,6 +98,8 @@ enum : uint32_t {
     kFActorBf16 = 1u << 25,   // the actor's 64 x 64 layer in bf16 x 3 arithmetic (mrsim_actor.h: kActBf16x3)
     kFActorBf16s = 1u << 26,  // ... in plain bf16 (kActBf16)
     kFOutAttempts = 1u << 27, // step kernel: rk_step attempts of the env step (MrsimStepIO.attempts; generic kernels only)
+    kFStatusPlain = 1u << 28, // step kernel, n == 1: the status word is OR-ed with a plain load / store (one lane writes; the word may
+                              // live in pinned host memory -- mr_rl_amd/env.py -- where a device atomic would need PCIe atomics)
 };
 __device__ __forceinline__ uint32_t live_flags(uint32_t f) {
     asm volatile("" : "+s"(f));

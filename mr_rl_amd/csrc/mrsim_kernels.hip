@@ -151,7 +151,10 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
                 if (fl & kFOutFinalRet) io.final_ret[i] = o.fret;
                 if (fl & kFOutFinalLen) io.final_len[i] = o.flen;
             }
-            if (fail && (fl & kFOutStatus)) atomicOr(io.status, fail);
+            if (fail && (fl & kFOutStatus)) {
+                if (FL == 0 && (fl & kFStatusPlain)) *io.status = *io.status | fail;
+                else atomicOr(io.status, fail);
+            }
             if constexpr (FL == 0) { if (fl & kFOutAttempts) io.attempts[i] = o.attempts; }
             if constexpr (!AOS) {
 #pragma unroll
@@ -1003,7 +1006,8 @@ static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
     K.flags |= (io->actions ? kFActions : 0u) | (io->goal_table ? kFGoalTable : 0u) |
                (io->actions_out ? kFOutActions : 0u) | (io->state_prime ? kFOutStatePrime : 0u) |
                (io->final_obs ? kFOutFinalObs : 0u) | (io->final_ret ? kFOutFinalRet : 0u) |
-               (io->final_len ? kFOutFinalLen : 0u) | (io->status ? kFOutStatus : 0u) | (io->attempts ? kFOutAttempts : 0u) | abits;
+               (io->final_len ? kFOutFinalLen : 0u) | (io->status ? kFOutStatus : 0u) | (io->attempts ? kFOutAttempts : 0u) |
+               ((io->status && n == 1) ? kFStatusPlain : 0u) | abits;
     LaunchCfg lc{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
     if (kernel_ms == nullptr) return launch_step(lc, p, K, S, IO, AC);
     // timed variant: events attached to this one dispatch (hipExtLaunchKernelGGL)

@@ -129,6 +129,45 @@ def test_facade_step_is_one_launch_on_the_host_record():
     assert not np.array_equal(pa, pb)             # sigma = 1: different env ids draw different noise
 
 
+def test_facade_drives_run_sim_and_the_ddpg_loop_shape_like_the_reference():
+    """The two callers a reference checkout has, written as THEY are written, on mr_rl_amd.MR_Env:
+    utils.run_sim (utils.py:43-61: reset, then step every row of the action table ignoring `done`, reading env.last_pos and
+    env.state_prime) against the golden tuple the reference's own run_sim produced, and the episode loop of RL/MR_ddpg.py:270-311
+    (reset(), render(), step(np.squeeze(action)) until done)."""
+    from mr_rl_amd import MR_Env
+    E = load_cases("ref_env.npz")
+    for name in ("g7_runsim_ramp", "g7_runsim_mis"):
+        G = E[name]
+        actions = G["actions"]
+        env = MR_Env()
+        state = env.reset(init=G["init"], noise_var=0.0, a0=float(G["a0"]), is_mismatched=bool(G["mismatched"]))   # utils.py:47
+        assert state.shape == (5,)
+        X, Y, states_prime = [], [], []
+        for i in range(len(actions)):                                                                                 # utils.py:51-54
+            env.step(actions[i, :2])
+            X.append(env.last_pos[0]); Y.append(env.last_pos[1]); states_prime.append(env.state_prime)
+        np.testing.assert_allclose(np.array(X), G["X"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(np.array(Y), G["Y"], rtol=0, atol=5e-5)
+        assert np.isfinite(np.array(states_prime)).all() and env.counter == len(actions)
+    # the DDPG loop's shape at the reference's defaults (sigma = 1): 51 steps, return 510, then the next episode
+    env = MR_Env(seed=11)
+    for ep in range(2):
+        s = env.reset()                                                          # RL/MR_ddpg.py:270
+        ep_reward, j = 0, 0
+        while True:
+            env.render()                                                         # :274
+            a = np.array([[3.0 + 0.1 * j, 0.05 * j]])
+            s2, r, terminal, info = env.step(np.squeeze(a))                      # :278
+            ep_reward += r; j += 1
+            if terminal:
+                break
+        assert j == 51 and ep_reward == 510 and info == {}
+    with pytest.raises(RuntimeError, match="mrsim device status"):              # a NaN action: SciPy's solver would fail (:42-43)
+        env.reset(); env.step([float("nan"), 0.0])
+    obs = env.reset()                                                            # the env is usable again after the failure
+    assert np.isfinite(obs).all() and np.isfinite(env.step([1.0, 1.0])[0]).all()
+
+
 def test_facade_equals_vec_env_of_one():
     """the facade and an MRVecEnv of one env (same seed, same env id) walk the same trajectory bit for bit at sigma = 1:
     same kernel, same arguments -- only where the buffers live differs."""
