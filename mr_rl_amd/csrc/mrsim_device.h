@@ -72,6 +72,7 @@ struct KParams {
     // level -1 test of the fused rollout's fast step (rk45_fast_step, Lm1): fp32 copies with their safety margins folded in
     float lm_a0, lm_sigma, lm_da, lm_dk, lm_dc, lm_es, lm_ed, lm_rt, lm_at, lm_kh, lm_mg;
     double lm_ccap;
+    double acc_lim_dt2;    // 1.96 / dt^2: the exact accept test of a whole-interval attempt with h = dt moved to the right-hand side
     int32_t substeps, reward_mode, max_timesteps, auto_reset, goal_K, goal_T;
     int32_t integrator;
     uint32_t flags;  // kF* bits: every wave-uniform yes/no of the launch in ONE scalar register
@@ -399,6 +400,14 @@ __device__ __forceinline__ void sincos_tab(const double2* __restrict__ tab, doub
 // scipy common.norm of a 2-vector
 __device__ __forceinline__ double rms2(double a, double b) { return sqrt(a * a + b * b) / 1.4142135623730951; }
 
+// fmax / fmin of two doubles (or of their magnitudes) as ONE instruction.  hipcc's fmax() / fmin() canonicalise each operand
+// first (v_max_f64 x, x, x: quieting signalling NaNs), three fp64-rate instructions where one does; v_max_f64 / v_min_f64
+// themselves return the non-NaN operand, which is all the first-level tests below rely on (a NaN fails a later comparison).
+__device__ __forceinline__ double max2(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double min2(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double max_abs2(double a, double b) { double r; asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double min_abs2(double a, double b) { double r; asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // ---------------------------------------------------------------------------
 // Simulator.simulate (MR_simulator.py:58-88) as  K = V + N:
 //   nominal:     V = (a0*f)*(cos a, sin a),            N = sigma*(z_x, z_y)                  :82-83
@@ -529,22 +538,27 @@ struct SubStep {
 // to the fp32 test of rk45_construct and from there to the exact formulas.
 template <bool MIS>
 __device__ __forceinline__ double construct_gd_bound(const KParams& P, const RhsCtx<MIS>& C) {
-    if constexpr (MIS) return __builtin_fma(fmax(__builtin_fabs(C.gx), __builtin_fabs(C.gy)), P.zmax2_dt, P.gmax_dt);
+    if constexpr (MIS) return __builtin_fma(max_abs2(C.gx, C.gy), P.zmax2_dt, P.gmax_dt);
     else return P.gmax_dt;
 }
 template <bool MIS>
 __device__ __forceinline__ bool construct_level0(const KParams& P, double x, double y, double sc0, double sc1, double f0x,
                                                  double f0y, double Gd) {
-    const double F = fmax(__builtin_fabs(f0x), __builtin_fabs(f0y));
-    const double c = 2e-5 * fmax(sc0, sc1);
-    const double u = P.h1_thresh_m * fmin(sc0, sc1);
+    const double F = max_abs2(f0x, f0y);
     if constexpr (MIS) {
-        const double K = fmax(0.01 * P.k_h0 * F, c);
-        return (__builtin_fabs(x) >= K) && (__builtin_fabs(y) >= K) && (F >= c) && (u >= fmax(F, Gd)) &&
-               (u * fmin(__builtin_fabs(x), __builtin_fabs(y)) >= P.k_h0 * (Gd * F));
-    } else {
+        // scale is increasing in |coordinate|: min / max of the two scales are the scales of min / max |coordinate| (same fma, same
+        // bits as sc0 / sc1, which this branch leaves unused)
+        const double m = min_abs2(x, y), M = max_abs2(x, y);
+        const double c = 2e-5 * __builtin_fma(M, P.rtol, P.atol);
+        const double u = P.h1_thresh_m * __builtin_fma(m, P.rtol, P.atol);
+        const double K = max2(0.01 * P.k_h0 * F, c);      // |x| >= K and |y| >= K  <=>  min(|x|, |y|) >= K
+        return (m >= K) && (F >= c) && (u >= max2(F, Gd)) && (u * m >= P.k_h0 * (Gd * F));
+    }
+    const double c = 2e-5 * max2(sc0, sc1);
+    const double u = P.h1_thresh_m * min2(sc0, sc1);
+    {
         const double kF = P.k_h0 * F;
-        return (__builtin_fabs(x) >= kF) && (__builtin_fabs(y) >= kF) && (F >= c) && (u >= fmax(F, Gd));
+        return (__builtin_fabs(x) >= kF) && (__builtin_fabs(y) >= kF) && (F >= c) && (u >= max2(F, Gd));
     }
 }
 
@@ -998,9 +1012,9 @@ __device__ __forceinline__ void finish_k6(const KParams& P, const RhsCtx<MIS>& C
 // and the extra g*z_a noise put error_norm near 0.5, where this test fails for half the waves and only adds work.
 __device__ __forceinline__ bool accept_level0(const KParams& P, const AttemptNoise& A, double dfx, double dfy, double h,
                                               double l0, double l1) {
-    const double dmax = fmax(__builtin_fabs(dfx), __builtin_fabs(dfy));
+    const double dmax = max_abs2(dfx, dfy);
     const double eb = __builtin_fma(P.sigma, (double)A.R32, -kE0 * dmax);
-    return h * eb <= 0.99 * fmin(l0, l1);
+    return h * eb <= 0.99 * min2(l0, l1);
 }
 // level 1 (rms norm with the exact stage sums ex32 / ey32 / ea32 and the worst-case K6): sqrt(2) less pessimistic
 template <bool MIS, int NZ>
@@ -1012,9 +1026,14 @@ __device__ __forceinline__ bool accept_level1(const KParams& P, const RhsCtx<MIS
         pex = __builtin_fma(C.gx, (double)A.ea32, pex);
         pey = __builtin_fma(C.gy, (double)A.ea32, pey);
     }
-    // (mismatched model under the collapsed law: f_new's term is part of the sums -- nothing is left to bound)
-    const double b6 = (MIS && nz_coll(NZ)) ? 0.0 : h * P.zmax_e6_sigma;
     const double l00 = l0 * l0, l11 = l1 * l1;
+    if constexpr (MIS && nz_coll(NZ)) {
+        // mismatched model under the collapsed law: f_new's term is part of the sums -- nothing is left to bound, and the squares
+        // need no magnitudes
+        const double ax = h * pex, ay = h * pey;
+        return __builtin_fma(ax * ax, l11, (ay * ay) * l00) < 1.96 * (l00 * l11);
+    }
+    const double b6 = h * P.zmax_e6_sigma;
     const double axw = __builtin_fabs(h * pex) + b6;
     const double ayw = __builtin_fabs(h * pey) + b6;
     return __builtin_fma(axw * axw, l11, (ayw * ayw) * l00) < 1.96 * (l00 * l11);
@@ -1235,6 +1254,13 @@ __device__ __forceinline__ bool rk45_fast_step(const KParams& P, const RhsCtx<MI
     bool acc;
     if constexpr (!MIS) {
         acc = accept_level0(P, A, dfx, dfy, h, l0, l1);
+    } else if constexpr (nz_coll(NZ)) {
+        // collapsed law: the error sums are complete (f_new folded in), the test is the exact one on scale_lo, and with h = dt the
+        // step size moves to the right-hand side as a host-folded constant:  pex^2 l1^2 + pey^2 l0^2 < (1.96 / dt^2) l0^2 l1^2
+        const double pex = __builtin_fma(C.gx, (double)A.ea32, __builtin_fma(P.sigma, (double)A.ex32, kE0 * dfx));
+        const double pey = __builtin_fma(C.gy, (double)A.ea32, __builtin_fma(P.sigma, (double)A.ey32, kE0 * dfy));
+        const double p = pex * l1, q = pey * l0, r = l0 * l1;
+        acc = __builtin_fma(p, p, q * q) < P.acc_lim_dt2 * (r * r);
     } else {
         acc = accept_level1<MIS, NZ>(P, C, A, dfx, dfy, h, l0, l1);  // the mismatched attempt forms its E sums eagerly
     }

@@ -802,6 +802,7 @@ static int make_kparams(const MrsimParams* p, int64_t n, uint32_t env_id0, uint6
         K.lm_mg = (float)(K.gmax_dt * 1.001 * q * 1.001);    // dropping - atol / rtol only raises the demand on mn
     }
     K.lm_ccap = 2e-5 * (p->atol + p->rtol * 16385.0) * 1.001;
+    K.acc_lim_dt2 = 1.96 / (p->time_span * p->time_span);
     K.dt2_f = (float)(p->time_span * p->time_span);
     K.substeps = p->substeps; K.reward_mode = p->reward_mode; K.max_timesteps = p->max_timesteps;
     K.auto_reset = p->auto_reset; K.goal_K = p->goal_K; K.goal_T = p->goal_T; K.integrator = p->integrator;
