@@ -429,7 +429,9 @@ __device__ __forceinline__ RhsCtx<MIS> make_ctx(const KParams& P, double f_t, do
                                                 const double2* __restrict__ tab = nullptr) {
     RhsCtx<MIS> C;
     if constexpr (MIS) {
-        const double a0b = P.a0 + (f_t / 4) * 0.8;
+        // a0 + (f/4)*0.8 (MR_simulator.py:55-56) as ONE multiply: the double 0.2 is the double 0.8 with its exponent lowered by two,
+        // so f * 0.2 and (f / 4) * 0.8 round the same real number -- equal bits (barring denormal f)
+        const double a0b = P.a0 + f_t * 0.2;      // (product rounded, then the sum: as the reference; -ffp-contract=off)
         // cos(al + 0.1) and sin(al - 0.15) from ONE sincos by the angle-addition formulas (<= 2 ulp from the
         // direct evaluation; an fp64 sincos costs about as much as a Philox call)
         constexpr double kC01 = 0.99500416527802577, kS01 = 0.099833416646828152;   // cos, sin of 0.1
