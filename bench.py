@@ -753,17 +753,20 @@ def measure_learner(args, n_local, dev, seed, streams):
     ep = cfg.max_timesteps + 1
     # learner_cus = 1: the learner's launches on 8 compute units of their own (one per XCC), the collection on the other 248
     # (mr_rl_amd.partition) -- reported beside the shared-device rows
-    rows = [("f32", 8, 60, 0), ("bf16", 8, 150, 0), ("bf16", 8, 150, 1), ("bf16", 0, 150, 0)]
+    # (actor arithmetic, updates per episode, episodes, learner compute units per XCC or 0 = shared, rows per update)
+    rows = [("f32", 8, 60, 0, 64), ("bf16", 8, 150, 0, 64), ("bf16", 8, 150, 1, 64), ("bf16", 0, 150, 0, 64),
+            ("bf16", 8, 150, 0, 4096)]      # the same loop learning from 4 096 rows per update (batch / 64 workgroups per update)
     if getattr(args, "no_partition_row", False):
         rows = [r for r in rows if r[3] == 0]
-    for math, U, episodes, cus in rows:
-        agent = DDPG(env, seed=seed, obs_scale=scale, fused=True)
+    for math, U, episodes, cus, batch in rows:
+        agent = DDPG(env, seed=seed, obs_scale=scale, fused=True, min_batch=batch)
         st = {}
         rets = agent.train_collected(episodes, updates_per_episode=U, sample=4096, streams=streams, math=math, stats=st, warm_episodes=10,
                                      learner_cus=cus)
         agent.close()    # the partition's streams go last, after everything that names them (DDPG.close; profiles/r05/partition_kt.txt)
         out["end_to_end"].append({
-            "actor_math": math, "updates_per_episode": U, "learner_compute_units": 8 * cus if cus else "shared",
+            "actor_math": math, "updates_per_episode": U, "rows_per_update": batch, "learner_compute_units": 8 * cus if cus else "shared",
+            "rows_learnt_from_per_transition_collected": U * batch / float(n_local * ep),
             "transitions_per_episode": n_local * ep,
             "update_to_transition_ratio": U / float(n_local * ep), "value": st["env_steps_timed"] / st["seconds"], "unit": "env-steps/s",
             "updates_per_s": st["updates_timed"] / st["seconds"], "episodes_timed": st["episodes_timed"],
@@ -1006,31 +1009,22 @@ def verify_ranks(args, cfg, world, rank, dev, seed, n_local, probe_envs=4096):
         env.check_status()
         return v
 
-    env_id0, _ = shard_of(n_local * world, rank, world)
-    mine = torch.cat([torch.tensor([float(rank), float(env_id0)], dtype=torch.float64, device=dev), probe(env_id0)])
+    from mr_rl_amd.dist import verify_shards
     pr = torch.cuda.get_device_properties(dev)
     ident = {"rank": rank, "host": socket.gethostname(), "device_index": dev.index, "name": pr.name,
              "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
              "uuid": str(getattr(pr, "uuid", "")), "pid": os.getpid()}
+    check = verify_shards(probe, n_local * world, rank, world, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
-        every = torch.zeros(world * 5, dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_gather_into_tensor(every, mine if args.dist_backend == "nccl" else mine.cpu())
-        every = every.view(world, 5)
         idents = [None] * world
         dist.all_gather_object(idents, ident)
     else:
-        every, idents = mine.unsqueeze(0), [ident]
+        idents = [ident]
     if rank != 0:
         return None
-    every = every.cpu()
-    ok, rows = True, []
-    for r in range(world):
-        e0, _ = shard_of(n_local * world, r, world)
-        want = probe(e0).cpu() if r != 0 else mine[2:].cpu()
-        same = bool(int(every[r, 0]) == r and int(every[r, 1]) == e0 and torch.equal(every[r, 2:], want))
-        ok = ok and same
-        rows.append({"rank": r, "env_id0": int(every[r, 1]), "probe_sum_x": float(every[r, 2]), "probe_sum_y": float(every[r, 3]),
-                     "probe_sum_returns": float(every[r, 4]), "equals_rank0_recomputation": same})
+    ok = check["all_equal"]
+    rows = [{"rank": r["rank"], "env_id0": r["env_id0"], "probe_sum_x": r["probe"][0], "probe_sum_y": r["probe"][1],
+             "probe_sum_returns": r["probe"][2], "equals_rank0_recomputation": r["equals_rank0_recomputation"]} for r in check["per_rank"]]
     distinct = len({(d["host"], d["pci"], d["uuid"]) for d in idents})
     return {"world_size_from_process_group": dist.get_world_size() if (world > 1 or dist.is_initialized()) else 1,
             "backend": (dist.get_backend() if (world > 1 or dist.is_initialized()) else "none"),

@@ -148,3 +148,36 @@ class ReturnGatherer:
     def last_mean(self):
         r = self.latest()
         return None if r is None else float(r.mean().item())
+
+
+def verify_shards(probe, total_envs, rank, world_size, device="cpu", group=None):
+    """Self-verification of a sharded run over the run's own backend.  probe(env_id0) -> 1-D float64 tensor: a deterministic
+    function of the GLOBAL env ids a shard starts at (e.g. sums of final positions and returns of one episode of its first envs --
+    the RNG is keyed by global env id, so any rank can recompute any shard's probe).  Every rank contributes {rank, env_id0,
+    probe(env_id0)} to ONE all_gather_into_tensor; rank 0 recomputes every shard's probe itself and compares bit for bit.
+    Returns on rank 0 a dict {"per_rank": [{rank, env_id0, probe, equals_rank0_recomputation}], "all_equal": bool}, None elsewhere.
+    device: where the gathered tensor lives ("cpu" for gloo, the rank's cuda device for nccl = RCCL)."""
+    import torch
+    import torch.distributed as dist
+    env_id0, _ = shard_of(total_envs, rank, world_size)
+    mine_probe = probe(env_id0).to(torch.float64).reshape(-1)
+    k = int(mine_probe.numel())
+    mine = torch.cat([torch.tensor([float(rank), float(env_id0)], dtype=torch.float64), mine_probe.cpu()]).to(device)
+    distributed = world_size > 1 and dist.is_available() and dist.is_initialized()
+    if distributed:
+        every = torch.zeros(world_size * (k + 2), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every, mine, group=group)
+        every = every.view(world_size, k + 2).cpu()
+    else:
+        every = mine.cpu().unsqueeze(0)
+    if rank != 0:
+        return None
+    rows, ok = [], True
+    for r in range(world_size):
+        e0, _ = shard_of(total_envs, r, world_size)
+        want = (mine_probe if r == 0 else probe(e0).to(torch.float64).reshape(-1)).cpu()
+        same = bool(int(every[r, 0]) == r and int(every[r, 1]) == e0 and torch.equal(every[r, 2:], want))
+        ok = ok and same
+        rows.append({"rank": r, "env_id0": int(every[r, 1]), "probe": [float(x) for x in every[r, 2:]],
+                     "equals_rank0_recomputation": same})
+    return {"per_rank": rows, "all_equal": ok}

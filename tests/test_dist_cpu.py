@@ -237,3 +237,63 @@ def test_block_return_gatherer_follows_the_collectors_launch_groups():
     col.episodes = 8                 # groups 5 and 6 never reported
     with pytest.raises(RuntimeError, match="skipped"):
         g.gather()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# verify_shards: the self-verification `bench.py --gpus N` writes into its record (rank_verification), over gloo with the oracle
+# standing in for the env compute
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_probe(env_id0, n=64, seed=11):
+    from oracle import oracle as O
+    p = O.default_params(sigma=1.0, auto_reset=1)
+    v = O.VecOracle(n, p, seed=seed, env_id0=env_id0)
+    v.reset(0)
+    lo, hi = [-20.0, -2 * np.pi], [20.0, 2 * np.pi]
+    for t in range(1, 52):
+        v.step(v.random_policy(t, lo, hi), t)
+    return torch.tensor([v.envs["y"][:, 0].sum(), v.envs["y"][:, 1].sum(), float(v.final_ret.sum())], dtype=torch.float64)
+
+
+def _verify_worker(rank, world, port, total, corrupt_rank, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mr_rl_amd.dist import verify_shards
+
+        def probe(env_id0):
+            # a rank that ran the WRONG shard (e.g. env ids offset by one): what the verification must catch
+            return _oracle_probe(env_id0 + (1 if (rank == corrupt_rank and rank != 0) else 0))
+        out = verify_shards(probe, total, rank, world, device="cpu")
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt_rank", [-1, 1])
+def test_verify_shards_over_gloo_detects_a_rank_on_the_wrong_shard(corrupt_rank):
+    world, total = 2, 256
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verify_worker, args=(r, world, port, total, corrupt_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] is None                                   # only rank 0 reports
+    rep = got[0]
+    assert [r["rank"] for r in rep["per_rank"]] == [0, 1] and [r["env_id0"] for r in rep["per_rank"]] == [0, 128]
+    assert rep["per_rank"][0]["equals_rank0_recomputation"] is True
+    assert rep["per_rank"][1]["equals_rank0_recomputation"] is (corrupt_rank != 1)
+    assert rep["all_equal"] is (corrupt_rank != 1)
+    assert len(rep["per_rank"][1]["probe"]) == 3 and rep["per_rank"][1]["probe"][2] == 64 * 510.0
+
+
+def test_verify_shards_single_process():
+    from mr_rl_amd.dist import verify_shards
+    rep = verify_shards(lambda e0: torch.tensor([float(e0), 2.0]), 100, 0, 1)
+    assert rep["all_equal"] and rep["per_rank"] == [{"rank": 0, "env_id0": 0, "probe": [0.0, 2.0], "equals_rank0_recomputation": True}]
