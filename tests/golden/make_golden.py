@@ -36,6 +36,10 @@ them is copied.  What is committed is data: inputs and the reference's outputs.
                 samples (per-stage and collapsed noise law, fast and spec Box-Muller) are tested against these (KS on the stored
                 ECDF points, |std ratio - 1| < 0.005, chi-square on the attempts), not only against the formula of SURVEY 3.3.
 
+  ref_main_runs.npz  main.py's own two noisy run_sim calls (idle set; first half circle of the learning set; noise_var 0.5, a0 1.5,
+                mismatched, from the origin: main.py:9-84) repeated 4000 times each with the imported Simulator: position quantiles,
+                moments and cumulative rk_step attempts at five checkpoints each.
+
 Usage:  python tests/golden/make_golden.py   (writes next to this file)
 """
 import os
@@ -581,9 +585,90 @@ def gen_increments(workers=None):
     print("ref_increments.npz written")
 
 
+# --------------------------------------------------------------------------
+# the reference's own experiment (main.py:9-84) repeated: distributions of where run_sim ends up
+# --------------------------------------------------------------------------
+MAIN_RUNS = {   # name -> (action table, checkpoints (1-based step counts), repetitions)
+    # main.py:15-17,57-60: 100 idle steps (zero action) from the origin: the drift (0.2, -0.1) of the mismatched model + noise,
+    # every step split into tens of attempts (|y| stays below 1)
+    "idle": (lambda: np.zeros((100, 2)), (1, 5, 20, 50, 100), 4000),
+    # main.py:21-33,67-70: the first half circle of the learning set (freq 4, alpha from -pi over 300 of its 600 steps): starts in the
+    # splitting regime and leaves it (a0' f = 9.2 units/s: 0.28 per step)
+    "learn": (lambda: np.stack([np.full(300, 4.0), np.linspace(-np.pi, np.pi, 600)[:300]], 1), (1, 10, 50, 150, 300), 4000),
+}
+MAIN_Q = 513
+
+
+def _main_chunk(task):
+    """`n` repetitions of the reference's Simulator over one of main.py's action tables at main.py's parameters (noise_var = 0.5,
+    a0 = 1.5, is_mismatched = True, start (0, 0): MR_env.reset's order -- mismatch set after the integrator is built); positions and
+    cumulative rk_step attempts at the checkpoints."""
+    name, n, seed = task
+    table_fn, cps, _ = MAIN_RUNS[name]
+    acts = f32(table_fn())
+    np.random.seed(seed % (2 ** 32))
+    pos = np.zeros((n, len(cps), 2))
+    att = np.zeros((n, len(cps)), dtype=np.int64)
+    for r in range(n):
+        s = MR_simulator.Simulator()
+        s.noise_var = 0.5
+        s.a0 = 1.5
+        s.reset_start_pos(np.array([0.0, 0.0]))
+        s.is_mismatched = True
+        total, ci = 0, 0
+        for k in range(len(acts)):
+            integ = s.integrator
+            n0 = integ.nfev
+            p1 = s.step(acts[k, 0], acts[k, 1])
+            total += (integ.nfev - n0) // 6
+            if k + 1 == cps[ci]:
+                pos[r, ci] = p1
+                att[r, ci] = total
+                ci += 1
+                if ci == len(cps):
+                    break
+    return pos, att
+
+
+def gen_main_runs(workers=None):
+    """ref_main_runs.npz: main.py's own two noisy run_sim calls (idle set, first half circle of the learning set; noise_var 0.5,
+    a0 1.5, mismatched, from the origin) repeated 4000 times each with the imported Simulator: per checkpoint the sorted-sample
+    quantiles of x and y, their moments and covariance, and the cumulative rk_step attempts -- what the batched run_sim of the build
+    (oracle and kernels, both noise laws) is compared with in distribution (tests/increments.py: compare_checkpoints)."""
+    import multiprocessing as mp
+    import time
+    workers = workers or min(8, os.cpu_count() or 1)
+    flat = {"schema": np.int64(1), "sigma": np.float64(0.5), "a0": np.float64(1.5), "mismatched": np.int64(1)}
+    with mp.Pool(workers) as pool:
+        for name, (table_fn, cps, reps) in MAIN_RUNS.items():
+            t0 = time.time()
+            chunk = 100
+            parts = pool.map(_main_chunk, [(name, chunk, 880000 + 1000 * list(MAIN_RUNS).index(name) + c) for c in range(reps // chunk)],
+                             chunksize=1)
+            pos = np.concatenate([p[0] for p in parts]); att = np.concatenate([p[1] for p in parts])
+            ranks = np.round(np.linspace(0.0, 1.0, MAIN_Q) * (len(pos) - 1)).astype(np.int64)
+            flat[f"{name}/actions"] = f32(table_fn())
+            flat[f"{name}/checkpoints"] = np.asarray(cps, dtype=np.int64)
+            flat[f"{name}/n"] = np.int64(len(pos))
+            flat[f"{name}/ranks"] = ranks
+            flat[f"{name}/q"] = np.stack([np.sort(pos[:, c, :], axis=0)[ranks].T for c in range(len(cps))]).astype(np.float64)  # [C, 2, Q]
+            flat[f"{name}/mean"] = pos.mean(axis=0)
+            flat[f"{name}/var"] = pos.var(axis=0)
+            flat[f"{name}/cov_xy"] = np.array([np.cov(pos[:, c, 0], pos[:, c, 1])[0, 1] for c in range(len(cps))])
+            flat[f"{name}/att_mean"] = att.mean(axis=0)
+            flat[f"{name}/att_var"] = att.var(axis=0)
+            print(f"  {name}: {len(pos)} runs x {cps[-1]} steps in {time.time() - t0:.0f} s; final mean {pos[:, -1].mean(axis=0)}, "
+                  f"std {pos[:, -1].std(axis=0)}, attempts per step {att[:, -1].mean() / cps[-1]:.2f}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "ref_main_runs.npz"), **flat)
+    print("ref_main_runs.npz written")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "increments":   # only the statistics fixture (the others are unchanged)
         gen_increments()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "main_runs":
+        gen_main_runs()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "circle_fm":
         gen_circle_fm()
@@ -601,3 +686,4 @@ if __name__ == "__main__":
     gen_reused()
     gen_increments()
     gen_circle_fm()
+    gen_main_runs()

@@ -163,3 +163,57 @@ def compare(regime, mis, resn, att, label=""):
           f"{len(out['p'])} tests, smallest p {out['p'][worst]:.3g} ({worst})")
     assert out["p"][worst] > P_MIN, (tag, worst, out["p"][worst])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# main.py's own noisy run_sim calls (tests/golden/ref_main_runs.npz): distributions of the position at checkpoints of the run
+# ---------------------------------------------------------------------------------------------------------------------
+def main_runs(name):
+    """{actions [T,2] float32-valued, checkpoints [C], n, ranks, q [C,2,Q], mean [C,2], var [C,2], cov_xy [C], att_mean [C], att_var [C]}
+    of one of main.py's runs ("idle", "learn") as the imported reference produced it 4000 times (make_golden.py: gen_main_runs)"""
+    if "main" not in _cache:
+        _cache["main"] = np.load(os.path.join(GOLDEN, "ref_main_runs.npz"))
+        assert int(_cache["main"]["schema"]) == 1
+    g = _cache["main"]
+    return {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "/")}
+
+
+def run_main(stepper, ref, n_envs):
+    """drive `stepper` (all envs at the origin, main.py's parameters) through the run's action table, the same action for every env;
+    -> pos [n, C, 2], cumulative attempts [n, C] at the checkpoints"""
+    acts, cps = ref["actions"].astype(np.float32), [int(c) for c in ref["checkpoints"]]
+    pos = np.zeros((n_envs, len(cps), 2))
+    att = np.zeros((n_envs, len(cps)))
+    total, ci = np.zeros(n_envs), 0
+    for k in range(cps[-1]):
+        stepper.step(np.tile(acts[k][None, :], (n_envs, 1)))
+        total += stepper.attempts()
+        if k + 1 == cps[ci]:
+            pos[:, ci], att[:, ci] = stepper.pos(), total
+            ci += 1
+    return pos, att
+
+
+def compare_checkpoints(ref, pos, att, label=""):
+    """the run's position law at every checkpoint against the reference's 4000 runs: KS on the stored ECDF points per component,
+    std ratio within 5 % (the reference sample's own standard error: 1.1 %), means within 5 standard errors, x-y correlation within
+    0.06, mean cumulative attempts within 5 standard errors"""
+    n_ref, C = int(ref["n"]), len(ref["checkpoints"])
+    ps, worst_ratio = {}, 0.0
+    for c in range(C):
+        for j in range(2):
+            x = pos[:, c, j]
+            ps[f"ks_cp{c}_{j}"] = ks_vs_quantiles(x, ref["q"][c, j], ref["ranks"], n_ref)[1]
+            sd_ref = float(np.sqrt(ref["var"][c, j]))
+            ratio = x.std() / sd_ref
+            worst_ratio = max(worst_ratio, abs(ratio - 1.0))
+            assert abs(ratio - 1.0) < 0.05, (label, "std ratio", c, j, ratio)
+            assert abs(x.mean() - float(ref["mean"][c, j])) < 5.0 * sd_ref * np.sqrt(1.0 / n_ref + 1.0 / len(x)), (label, "mean", c, j)
+        rho_ref = float(ref["cov_xy"][c]) / np.sqrt(float(ref["var"][c, 0]) * float(ref["var"][c, 1]))
+        assert abs(np.corrcoef(pos[:, c, 0], pos[:, c, 1])[0, 1] - rho_ref) < 0.06, (label, "correlation", c)
+        se = np.sqrt(float(ref["att_var"][c]) / n_ref + att[:, c].var() / len(att))
+        assert abs(att[:, c].mean() - float(ref["att_mean"][c])) < 5.0 * se + 1e-9, (label, "attempts", c, att[:, c].mean(), float(ref["att_mean"][c]))
+    worst = min(ps, key=ps.get)
+    print(f"{label}: {len(ps)} KS tests, smallest p {ps[worst]:.3g} ({worst}); worst |std ratio - 1| {worst_ratio:.4f}; attempts per step at the end "
+          f"{att[:, -1].mean() / int(ref['checkpoints'][-1]):.2f} vs reference {float(ref['att_mean'][-1]) / int(ref['checkpoints'][-1]):.2f}")
+    assert ps[worst] > 0.01 / (4 * len(ps)), (label, worst, ps[worst])       # family-wise 1 % over runs x laws

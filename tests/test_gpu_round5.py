@@ -313,3 +313,35 @@ def test_in_kernel_sampler_never_repeats_a_row_on_a_nearly_empty_ring(ring, B):
     if ring > B:                # every row gets its turn (uniform over the ring: 40 x B / ring expected visits)
         assert int((seen == 0).sum()) == 0
         assert float(seen.max()) <= 40 and float(seen.float().std()) < 0.45 * 40 * B / ring + 3
+
+
+# ---------------------------------------------------------------------------
+# main.py's own noisy runs (noise_var 0.5, a0 1.5, mismatched, from the origin) in distribution, kernels vs the reference's 4000 runs
+# ---------------------------------------------------------------------------
+class _KernelMain:
+    def __init__(self, n, law, math, seed):
+        from mr_rl_amd import MRConfig, MRVecEnv
+        self.env = MRVecEnv(n, cfg=MRConfig(noise_var=0.5, a0=1.5, is_mismatched=True, noise_law=law, noise_math=math), seed=seed,
+                            track_attempts=True)
+        self.env.reset(init=np.zeros((n, 2)), noise_var=0.5, a0=1.5, is_mismatched=True)     # fresh env: nominal-law constructor
+
+    def pos(self):
+        return self.env.pos.cpu().numpy()
+
+    def attempts(self):
+        return self.env.attempts.cpu().numpy()
+
+    def step(self, a):
+        self.env.step(a)
+
+
+@pytest.mark.parametrize("law", ["collapsed", "per_stage"])
+@pytest.mark.parametrize("math", ["fast", "spec"])
+@pytest.mark.parametrize("run", ["idle", "learn"])
+def test_kernel_reproduces_the_law_of_main_py_runs(run, law, math):
+    ref = INC.main_runs(run)
+    n = 32768
+    st = _KernelMain(n, law, math, seed=5)
+    pos, att = INC.run_main(st, ref, n)
+    st.env.check_status()
+    INC.compare_checkpoints(ref, pos, att, label=f"kernel {law}/{math} main.py {run}")

@@ -159,3 +159,34 @@ def test_oracle_increments_and_attempts_match_the_reference_sample(regime, law, 
     resn, att = INC.draw(st, n, steps, mis, seed=5 + law)
     out = INC.compare(regime, mis, resn, att, label=f"oracle law={law}")
     assert out["tol"] <= 0.02
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# main.py's own noisy run_sim calls (main.py:9-84: noise_var 0.5, a0 1.5, mismatched, from the origin), repeated 4000 times by the
+# imported reference (tests/golden/ref_main_runs.npz): where the robot is, in distribution, at five checkpoints of each run
+# ---------------------------------------------------------------------------------------------------------------------
+class _OracleMain:
+    def __init__(self, n, law, seed):
+        p = O.default_params(sigma=0.5, a0=1.5, mismatched=1, noise_law=law)
+        self.orc = O.VecOracle(n, p, seed=seed, threads=8)
+        self.orc.reset(0, init_xy=np.zeros((n, 2)))      # a fresh env, as run_sim builds one (utils.py:46): nominal-law constructor
+        self.t = 0
+
+    def pos(self):
+        return self.orc.envs["y"]
+
+    def attempts(self):
+        return self.orc.envs["n_attempts"]
+
+    def step(self, a):
+        self.t += 1
+        self.orc.step(a, step_idx=self.t)
+
+
+@pytest.mark.parametrize("law", [O.LAW_PER_STAGE, O.LAW_COLLAPSED], ids=["per_stage", "collapsed"])
+@pytest.mark.parametrize("run", ["idle", "learn"])
+def test_oracle_reproduces_the_law_of_main_py_runs(run, law):
+    ref = INC.main_runs(run)
+    n = 12000
+    pos, att = INC.run_main(_OracleMain(n, law, seed=3 + law), ref, n)
+    INC.compare_checkpoints(ref, pos, att, label=f"oracle law={law} main.py {run}")
