@@ -208,7 +208,9 @@ typedef struct MrsimStepIO {
     float* final_ret;        /* optional [n]: episode return where done                       */
     int32_t* final_len;      /* optional [n]: episode length where done                       */
     int32_t* status;         /* optional [1]: OR-ed per-env flags; bit0 = RK45 attempt guard  */
-                             /*   tripped (the reference would raise "failed solver")         */
+                             /*   tripped (the reference would raise "failed solver").  With  */
+                             /*   n == 1 the word is updated by a plain load / store (it may  */
+                             /*   live in mrsim_host_alloc memory), otherwise by an atomic    */
     const MrsimActor* actor; /* optional (HOST pointer; ABI 3): the policy source is the      */
                              /*   in-kernel actor on the env's current observation; actions   */
                              /*   must then be NULL and the integrator RK45                   */
