@@ -136,6 +136,7 @@ def parse(argv=None):
     ap.add_argument("--no-actor-leg", action="store_true", help="skip the actor-in-the-loop collection measurement")
     ap.add_argument("--no-learner-leg", action="store_true", help="skip the DDPG learner measurement (updates/s, end-to-end training rate)")
     ap.add_argument("--no-facade-leg", action="store_true", help="skip the single-env MR_Env.step() drop-in measurement")
+    ap.add_argument("--no-consumers-leg", action="store_true", help="skip the run_sim + velocity post-processing / recorder export measurement")
     ap.add_argument("--no-streaming-point", action="store_true", help="skip the N = 2 097 152 single-GPU streaming point (SURVEY H4)")
     ap.add_argument("--no-partition-row", action="store_true",
                     help="learner leg without its compute-unit-partition row (round 4 needed this under rocprofv3 --kernel-trace: "
@@ -1035,6 +1036,61 @@ def verify_ranks(args, cfg, world, rank, dev, seed, n_local, probe_envs=4096):
 
 
 
+def measure_consumers(dev, seed, n=65536, T=600):
+    """The two data-format rows either side of the path, measured: the batched run_sim + velocity post-processing
+    every consumer of run_sim applies (Learning_module.py:46-59: box filter -> gradient -> box filter -> drift; one fused launch over
+    trajectories x time chunks: 32 algorithmic bytes per (t, env) of [T][n][2] fp64), and the batched MRExperiment export (recorder.export_all: the episodes of
+    all envs of one resident rollout cut on the device).  Workload: one circle of main.py's learning set (600 steps at freq 4,
+    main.py:21-33) for 65 536 envs at main.py's parameters."""
+    import numpy as np
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv, recorder
+    from mr_rl_amd.rollout import estimate_velocity
+    acts = np.stack([np.full(T, 4.0), np.linspace(-np.pi, np.pi, T)], 1)
+    env = MRVecEnv(n, cfg=MRConfig(noise_var=0.5, a0=1.5, is_mismatched=True), device=dev, seed=seed)
+    env.reset(init=np.zeros((n, 2)), is_mismatched=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    traj = env.rollout(T, actions=acts, shared_actions=True, want=("traj",))["traj"]
+    ev[1].record()
+    time_axis = np.linspace(0, (T - 1) / 30.0, T)
+    estimate_velocity(traj, time_axis)            # warm
+    ms = []
+    for _ in range(5):
+        ev[2].record()
+        v, drift = estimate_velocity(traj, time_axis)
+        ev[3].record()
+        torch.cuda.synchronize(dev)
+        ms.append(ev[2].elapsed_time(ev[3]))
+    env.check_status()
+    vel_ms = sorted(ms)[len(ms) // 2]
+    # algorithmic bytes of the post-processing: every position read once, every velocity written once (fp64 pairs): 32 B per point
+    # (the three-pass form of rounds 2-4 moved 96-128)
+    gbs = 32.0 * n * T / (vel_ms * 1e-3) / 1e9
+    out = {"what": "batched run_sim + velocity post-processing (8f-1, 8f-4) and batched MRExperiment export (8f-3)",
+           "run_sim": {"envs": n, "steps": T, "ms": round(ev[0].elapsed_time(ev[1]), 3),
+                       "env_steps_per_s": n * T / (ev[0].elapsed_time(ev[1]) * 1e-3),
+                       "note": "one fused launch, shared fp64 action table, fp64 positions of every step written (16 B per env-step)"},
+           "velocity": {"ms": round(vel_ms, 3), "points_per_s": n * T / (vel_ms * 1e-3),
+                        "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_point": 32},
+                        "mean_drift_estimate": [float(x) for x in drift.mean(dim=0).tolist()]}}
+    del traj, v, drift, env
+    torch.cuda.empty_cache()
+    n2, T2 = 16384, 204
+    env2 = MRVecEnv(n2, cfg=MRConfig(noise_var=1.0, auto_reset=True), device=dev, seed=seed)
+    env2.reset()
+    recorder.export_all(env2, T2)                 # warm
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    be = recorder.export_all(env2, T2)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    out["recorder_export"] = {"envs": n2, "steps": T2, "ms": round(el * 1e3, 3), "episodes_cut": int(be.ep_count.sum().item()),
+                              "transitions_per_s": n2 * T2 / el}
+    return out
+
+
 def stats_us(ms):
     ms = sorted(ms)
     return sum(ms) / len(ms) * 1e3, ms[len(ms) // 2] * 1e3
@@ -1341,6 +1397,11 @@ def main():
         streaming = measure_streaming_point(args, cfg, dev, seed)
         trace("streaming point done")
 
+    consumers = None
+    if rank == 0 and world == 1 and args.mode == "rollout" and args.workload == "ddpg" and not args.no_consumers_leg and not pmc:
+        consumers = measure_consumers(dev, seed)
+        trace("consumers leg done")
+
     rank_check = None
     if world > 1 or os.environ.get("MRSIM_BENCH_FORCE_DIST"):
         rank_check = verify_ranks(args, cfg, world, rank, dev, seed, n_local)
@@ -1405,6 +1466,8 @@ def main():
             out["facade"] = facade
         if streaming is not None:
             out["streaming_point"] = streaming
+        if consumers is not None:
+            out["consumers"] = consumers
         if rank_check is not None:
             out["rank_verification"] = rank_check
         if pmc:

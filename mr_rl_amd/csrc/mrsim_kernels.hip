@@ -705,6 +705,111 @@ __global__ __launch_bounds__(kBlock) void mr_gradient_kernel(long long n, int T,
     }
 }
 
+// The three passes above fused and cut into time chunks (round 5).  One lane per (trajectory, chunk of `chunk` output steps): the
+// lane streams the positions of its chunk (+ the stencil's reach on either side) ONCE, carries the first filter's running sum, the
+// last three filtered positions (the gradient's stencil) and a ring of the last RING gradients (the second filter's window) and
+// writes the velocity once: 16 B read + 16 B written per point (+ the overlap of neighbouring chunks, which hits L2) instead of six
+// array passes -- and chunks x as many waves in flight as one lane per trajectory gave (65 536 trajectories were ONE wave per SIMD,
+// each waiting for a load per time step).  Same window / edge rules as the three kernels: uniform_filter1d "nearest" clamps the
+// INDEX of every window element, np.gradient is one-sided at the two ends; a chunk starts its running sums from a direct window sum
+// (the additions happen in another order than in one pass over the whole trajectory: differences at the 1e-16 level).
+// part[chunk][n]: the chunk's contribution to the drift sum (mean of v[lo:hi)), reduced by mr_velocity_drift_kernel in chunk order.
+constexpr int kVelRing = 16;   // second filter windows up to 15 steps (n_filter <= 31); longer ones take the three-pass form
+constexpr int kVelCoef = 160;  // gradient coefficients a block keeps: chunk + window <= this (3.8 KB of LDS beside the 32 KB ring)
+template <int RING>            // 8 (windows up to 7 steps: the reference's n_filter = 14; 32 KB of LDS per block) or kVelRing
+__global__ __launch_bounds__(kBlock) void mr_velocity_fused_kernel(long long n, int T, int N1, int N2, int chunk,
+                                                                   const double2* __restrict__ in, const double* __restrict__ x,
+                                                                   double2* __restrict__ out, double2* __restrict__ part,
+                                                                   int mean_lo, int mean_hi) {
+    __shared__ double2 ring[RING][kBlock];
+    // np.gradient's three coefficients depend on the time axis alone: formed once per block for the gradients of its chunk (three fp64
+    // divisions per entry -- per lane and point they were most of the kernel), read back as LDS broadcasts
+    __shared__ double cA[kVelCoef], cB[kVelCoef], cC[kVelCoef];
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int t0 = (int)blockIdx.y * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
+    if (t0 >= T) return;                                                     // (block-uniform)
+    const int left1 = N1 / 2, right1 = N1 - left1 - 1, left2 = N2 / 2, right2 = N2 - left2 - 1;
+    const double inv1 = 1.0 / N1, inv2 = 1.0 / N2;
+    auto clampi = [&](int k) { return k < 0 ? 0 : (k >= T ? T - 1 : k); };
+    const int gb = clampi(t0 - left2), ge = clampi(t1 - 1 + right2);       // the gradients of this chunk (ge - gb < kVelCoef: host)
+    for (int k = tid; k <= ge - gb; k += kBlock) {
+        const int gg = gb + k;
+        if (gg > 0 && gg < T - 1) {
+            const double hs = x[gg] - x[gg - 1], hd = x[gg + 1] - x[gg];
+            cA[k] = -hd / (hs * (hd + hs)); cB[k] = (hd - hs) / (hd * hs); cC[k] = hs / (hd * (hd + hs));
+        }
+    }
+    __syncthreads();
+    if (i >= n) return;
+    auto p_at = [&](int k) { return in[(long long)clampi(k) * n + i]; };
+    // ---- stage A as a stream: P1[j1] = (running window sum) / N1, then advance the window
+    const int g_lo = clampi(t0 - left2);                                     // the first gradient this chunk needs
+    int j1 = g_lo > 0 ? g_lo - 1 : 0;
+    double s1x = 0.0, s1y = 0.0;
+    for (int k = -left1; k <= right1; ++k) { const double2 v = p_at(j1 + k); s1x += v.x; s1y += v.y; }
+    auto next_p1 = [&]() {
+        const double2 r = make_double2(s1x * inv1, s1y * inv1);
+        const double2 a = p_at(j1 + right1 + 1), b = p_at(j1 - left1);
+        s1x += a.x - b.x; s1y += a.y - b.y;
+        ++j1;
+        return r;
+    };
+    // ---- stage B as a stream: G[g] from P1[g-1], P1[g], P1[g+1]
+    double2 pm = make_double2(0.0, 0.0), p0, pp = make_double2(0.0, 0.0);
+    int g = g_lo;                    // the NEXT gradient to produce
+    if (g_lo > 0) pm = next_p1();
+    p0 = next_p1();
+    if (g + 1 <= T - 1) pp = next_p1();
+    auto next_g = [&]() {
+        double2 o;
+        if (T == 1) {
+            o = make_double2(0.0, 0.0);
+        } else if (g == 0) {
+            const double h = x[1] - x[0];
+            o = make_double2((pp.x - p0.x) / h, (pp.y - p0.y) / h);
+        } else if (g == T - 1) {
+            const double h = x[T - 1] - x[T - 2];
+            o = make_double2((p0.x - pm.x) / h, (p0.y - pm.y) / h);
+        } else {
+            const double a = cA[g - gb], b = cB[g - gb], c = cC[g - gb];
+            o = make_double2(a * pm.x + b * p0.x + c * pp.x, a * pm.y + b * p0.y + c * pp.y);
+        }
+        ring[g % RING][tid] = o;
+        pm = p0; p0 = pp;
+        if (g + 2 <= T - 1) pp = next_p1();
+        ++g;
+        return o;
+    };
+    auto g_at = [&](int k) {         // G[clamp(k)], producing the stream up to it first (indices only ever grow by one past `g`)
+        const int idx = clampi(k);
+        while (g <= idx) next_g();
+        return ring[idx % RING][tid];
+    };
+    // ---- stage C: running window sum of G, started from a direct sum of the first window of the chunk
+    double s2x = 0.0, s2y = 0.0;
+    for (int k = -left2; k <= right2; ++k) { const double2 v = g_at(t0 + k); s2x += v.x; s2y += v.y; }
+    double mx = 0.0, my = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        const double ox = s2x * inv2, oy = s2y * inv2;
+        out[(long long)t * n + i] = make_double2(ox, oy);
+        if (t >= mean_lo && t < mean_hi) { mx += ox; my += oy; }
+        if (t + 1 < t1) {
+            const double2 a = g_at(t + right2 + 1), b = g_at(t - left2);   // (the trailing one is at most N2 behind: still in the ring)
+            s2x += a.x - b.x; s2y += a.y - b.y;
+        }
+    }
+    if (part != nullptr) part[(long long)blockIdx.y * n + i] = make_double2(mx, my);
+}
+__global__ __launch_bounds__(kBlock) void mr_velocity_drift_kernel(long long n, int chunks, const double2* __restrict__ part,
+                                                                   double2* __restrict__ drift, int cnt) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double mx = 0.0, my = 0.0;
+    for (int c = 0; c < chunks; ++c) { const double2 v = part[(long long)c * n + i]; mx += v.x; my += v.y; }
+    drift[i] = cnt > 0 ? make_double2(mx / cnt, my / cnt) : make_double2(0.0, 0.0);
+}
+
 __global__ void mr_advance_kernel(unsigned long long* step_base, unsigned long long delta) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *step_base += delta;
 }
@@ -1493,6 +1598,31 @@ int mrsim_velocity(int64_t n, int32_t T, int32_t n_filter, const double* traj_xy
     const int lo = n_filter, hi = T - n_filter;  // v[N:-N]
     auto P2 = [](const double* p) { return reinterpret_cast<const double2*>(p); };
     auto Q2 = [](double* p) { return reinterpret_cast<double2*>(p); };
+    if (n2 + 1 <= kVelRing) {
+        // fused form: one launch over (trajectories, time chunks) + the drift's chunk reduction.  Chunks: enough of them for ~8 waves
+        // per SIMD in flight, none shorter than 32 steps (a chunk re-reads the stencil's reach, ~25 steps, around its own)
+        const long long blocks_x = (n + kBlock - 1) / kBlock;
+        int chunks = (int)((8192 + blocks_x - 1) / blocks_x);
+        if (chunks > T / 32) chunks = T / 32;
+        if (chunks < 1) chunks = 1;
+        if (chunks > 65535) chunks = 65535;
+        int chunk = (T + chunks - 1) / chunks;
+        if (chunk > kVelCoef - kVelRing - 2) chunk = kVelCoef - kVelRing - 2;     // the block's gradient coefficients fit its LDS table
+        chunks = (T + chunk - 1) / chunk;
+        if (chunks > 65535) return MRSIM_EINVAL;                                   // T beyond 32 million steps
+        const int mlo = lo, mhi = hi > lo ? hi : lo;
+        double2* part = drift_xy ? Q2(scratch_xy) : (double2*)nullptr;
+        if (n2 + 1 <= 8)
+            hipLaunchKernelGGL(mr_velocity_fused_kernel<8>, dim3((unsigned)blocks_x, (unsigned)chunks), dim3(kBlock), 0, lc.stream,
+                               (long long)n, (int)T, (int)n_filter, n2, chunk, P2(traj_xy), time, Q2(v_xy), part, mlo, mhi);
+        else
+            hipLaunchKernelGGL(mr_velocity_fused_kernel<kVelRing>, dim3((unsigned)blocks_x, (unsigned)chunks), dim3(kBlock), 0, lc.stream,
+                               (long long)n, (int)T, (int)n_filter, n2, chunk, P2(traj_xy), time, Q2(v_xy), part, mlo, mhi);
+        if (hipGetLastError() != hipSuccess) return MRSIM_ELAUNCH;
+        if (drift_xy != nullptr)
+            return launch(lc, mr_velocity_drift_kernel, (long long)n, (long long)n, chunks, P2(scratch_xy), Q2(drift_xy), mhi - mlo);
+        return MRSIM_OK;
+    }
     if ((rc = launch(lc, mr_boxfilter_kernel, (long long)n, (long long)n, (int)T, (int)n_filter, P2(traj_xy), Q2(v_xy),
                      (double2*)nullptr, 0, 0)))
         return rc;

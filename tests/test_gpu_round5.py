@@ -345,3 +345,32 @@ def test_kernel_reproduces_the_law_of_main_py_runs(run, law, math):
     pos, att = INC.run_main(st, ref, n)
     st.env.check_status()
     INC.compare_checkpoints(ref, pos, att, label=f"kernel {law}/{math} main.py {run}")
+
+
+# ---------------------------------------------------------------------------
+# velocity post-processing, fused and cut into time chunks (Learning_module.py:46-59,72-93)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("T,n,N", [(1800, 300, 14), (600, 1000, 14), (33, 7, 14), (64, 257, 14), (95, 3, 30), (2000, 64, 31),
+                                   (400, 37, 40), (1, 4, 14), (2, 4, 14), (3, 5, 2)])
+def test_fused_velocity_matches_scipy_numpy_over_chunk_boundaries(T, n, N):
+    """mrsim_velocity (one fused launch over trajectories x time chunks; the three-pass form for windows beyond 15 steps: N = 40)
+    against uniform_filter1d -> np.gradient -> uniform_filter1d and the drift mean(v[N:-N]) computed with scipy / numpy as the
+    reference does: long runs (many chunks), lengths around the chunk and window sizes, T = 1 .. 3, non-uniform time axis"""
+    import torch
+    from scipy.ndimage import uniform_filter1d
+    from mr_rl_amd.rollout import estimate_velocity
+    rng = np.random.default_rng(T * 7 + n)
+    traj = np.cumsum(rng.normal(0.1, 0.05, (T, n, 2)), axis=0)
+    time_axis = np.linspace(0, (T - 1) / 30.0, T) + rng.uniform(0, 1e-3, T).cumsum() * (T > 100)
+    v, D = estimate_velocity(torch.as_tensor(traj, device="cuda"), time_axis, n_filter=N)
+    want = np.zeros_like(traj)
+    for e in range(n):
+        for d in range(2):
+            p = uniform_filter1d(traj[:, e, d], N, mode="nearest")
+            g = np.gradient(p, time_axis) if T > 1 else np.zeros(1)
+            want[:, e, d] = uniform_filter1d(g, max(int(N / 2), 1), mode="nearest")
+    np.testing.assert_allclose(v.cpu().numpy(), want, rtol=1e-9, atol=1e-9)
+    if T > 2 * N:
+        np.testing.assert_allclose(D.cpu().numpy(), want[N:-N].mean(0), rtol=1e-9, atol=1e-12)
+    else:
+        assert float(D.abs().max()) == 0.0

@@ -33,13 +33,13 @@ pass() {  # pass <name> <cmd...>: run (if the pass belongs to this invocation's 
     esac
   done
 }
-PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --no-actor-leg --no-learner-leg --no-other-law --no-facade-leg --no-streaming-point --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
-S1ARGS="--no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg --no-facade-leg --no-streaming-point"
+PMCARGS="--no-cpu-baseline --no-step-path --no-mixed-set --no-power --no-actor-leg --no-learner-leg --no-other-law --no-facade-leg --no-streaming-point --no-consumers-leg --steps 102 --warmup 102 --settle-episodes 20 --sustained-steps 0"
+S1ARGS="--no-cpu-baseline --no-power --streams 1 --no-step-path --no-mixed-set --no-other-law --no-actor-leg --no-learner-leg --no-facade-leg --no-streaming-point --no-consumers-leg"
 pass kt rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-power
 pass kt_s1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1 -- python3 $R/bench.py $S1ARGS
 pass kt_s1_ps rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1_ps -- python3 $R/bench.py $S1ARGS --noise-law per_stage
 pass kt_s1_mis rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_s1_mis -- python3 $R/bench.py $S1ARGS --mismatched
-pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --no-power --mode step --no-facade-leg
+pass kt_step rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_step -- python3 $R/bench.py --no-cpu-baseline --no-power --mode step --no-facade-leg --no-consumers-leg
 # ---- SURVEY H4's streaming point: N = 2 097 152 envs on this one GPU (rollout both laws, step kernel)
 BIG="--envs-per-gpu 2097152 --settle-episodes 40 --warmup 510 --steps 2040 --sustained-steps 2040"
 pass kt_2m rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_2m -- python3 $R/bench.py $S1ARGS $BIG
