@@ -284,6 +284,17 @@ int mrsim_replay_push(int64_t n_envs, int32_t T, const float* obs_T, const float
                       const uint8_t* done_T, const float* prev_obs, const float* obs_scale5_host, int32_t n, float* ring_s,
                       float* ring_a, float* ring_r, float* ring_done, float* ring_s2, int32_t capacity, int32_t head,
                       uint64_t seed, uint64_t draw_counter, void* stream);
+/* The per-step bookkeeping of the reference's loop as ONE launch (ABI 5) -- RL/MR_ddpg.py:278-282 `replay_buffer.add(state, action,
+ * reward, terminal, next_state)` for the n transitions of one lockstep env step, :307 `state = next_state`, :309-311 the return of
+ * the episodes that ended: ring rows head .. head + n - 1 (mod capacity; the last `capacity` envs when n > capacity) receive
+ * s = obs_prev x obs_scale, a = actions, r = rew, done, s2 = (done and final_obs given ? final_obs : obs_next) x obs_scale -- with
+ * MrsimParams.auto_reset the env's own observation of a finished env is already the next episode's reset row, the transition's s2
+ * is MrsimStepIO.final_obs; obs_prev_out[n][5] := obs_next (may be obs_prev itself); ended2[2] += {sum of final_ret over the envs
+ * that are done, their number} (optional).  [n][5] observation rows.  All DEVICE except obs_scale5_host. */
+int mrsim_replay_add_step(int64_t n, const float* obs_prev, const float* actions, const float* rew, const uint8_t* done,
+                          const float* obs_next, const float* final_obs, const float* final_ret, const float* obs_scale5_host,
+                          float* ring_s, float* ring_a, float* ring_r, float* ring_done, float* ring_s2, int32_t capacity, int32_t head,
+                          float* obs_prev_out, float* ended2, void* stream);
 /* The learner's online actor (MrsimDdpgLearner.online) -> the packed block of MrsimActor.blob, on the device: batch norm folded
  * with the given moving statistics (bn_stats: the learner's, its online actor's two layers), weights permuted and split exactly
  * as mrsim_actor_fold_bn_host + mrsim_actor_pack_host do (bit-identical block).  One launch on `stream`; order it before the

@@ -29,7 +29,7 @@ PRODUCT_SYMBOLS = (
     "mrsim_stream_create_cu_mask", "mrsim_stream_destroy", "mrsim_velocity",
     "mrsim_device_count", "mrsim_device_name",
     "mrsim_actor_fold_bn_host", "mrsim_actor_pack_host", "mrsim_actor_forward", "mrsim_ddpg_update",
-    "mrsim_replay_push", "mrsim_actor_pack_device",
+    "mrsim_replay_push", "mrsim_replay_add_step", "mrsim_actor_pack_device",
     "mrsim_host_alloc", "mrsim_host_free", "mrsim_stream_synchronize",
 )
 # include/mrsim_bench.h: measurement and test aids (bench.py, tools/, tests/); nothing in mr_rl_amd's product path calls them
@@ -148,6 +148,7 @@ def load(path):
     L.mrsim_ddpg_update.argtypes = [C.POINTER(MrsimDdpgLearner), i32, i32, vp, vp, vp, vp, vp, vp, i32, u64, u64, vp, vp, vp]
     L.mrsim_replay_push.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, u64, u64, vp]
     L.mrsim_actor_pack_device.argtypes = [vp, vp, C.c_float, vp, vp, vp, vp]
+    L.mrsim_replay_add_step.argtypes = [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     L.mrsim_host_alloc.argtypes = [i64, C.POINTER(vp), C.POINTER(vp)]
     L.mrsim_host_free.argtypes = [vp]
     L.mrsim_stream_synchronize.argtypes = [vp]

@@ -1569,6 +1569,25 @@ int mrsim_replay_push(int64_t n_envs, int32_t T, const float* obs_T, const float
     return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
 
+int mrsim_replay_add_step(int64_t n, const float* obs_prev, const float* actions, const float* rew, const uint8_t* done,
+                          const float* obs_next, const float* final_obs, const float* final_ret, const float* obs_scale, float* ring_s,
+                          float* ring_a, float* ring_r, float* ring_done, float* ring_s2, int32_t capacity, int32_t head,
+                          float* obs_prev_out, float* ended2, void* stream) {
+    if (n < 0 || capacity < 1 || head < 0 || head >= capacity || obs_prev == nullptr || actions == nullptr || rew == nullptr ||
+        done == nullptr || obs_next == nullptr || obs_scale == nullptr || ring_s == nullptr || ring_a == nullptr || ring_r == nullptr ||
+        ring_done == nullptr || ring_s2 == nullptr || obs_prev_out == nullptr)
+        return MRSIM_EINVAL;
+    if (n > 0xFFFFFFFFll) return MRSIM_ERANGE;
+    if (n == 0) return MRSIM_OK;
+    int rc = check_device();
+    if (rc) return rc;
+    learner::AddStepArgs A{obs_prev, actions, rew, done, obs_next, final_obs, final_ret, ring_s, ring_a, ring_r, ring_done, ring_s2,
+                           obs_prev_out, ended2, (long long)n, capacity, head, n > capacity ? (int32_t)(n - capacity) : 0,
+                           {obs_scale[0], obs_scale[1], obs_scale[2], obs_scale[3], obs_scale[4]}};
+    hipLaunchKernelGGL(learner::mr_replay_add_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+    return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+}
+
 int mrsim_actor_pack_device(const float* learner_online, const float* bn_stats, float bn_eps, const float* obs_scale,
                             const float* action_bound, float* blob, void* stream) {
     if (learner_online == nullptr || bn_stats == nullptr || obs_scale == nullptr || action_bound == nullptr || blob == nullptr ||

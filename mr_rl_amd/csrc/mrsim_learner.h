@@ -855,6 +855,49 @@ __global__ __launch_bounds__(kPushThreads) void mr_replay_push_kernel(const Push
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The per-step bookkeeping of the reference-shaped loop (RL/MR_ddpg.py:278-282,307-311) as ONE launch: replay_buffer.add of the
+// step's n transitions (s = the observation the action was computed from, s2 = the terminal observation where the episode ended --
+// with auto-reset the env's own observation is already the next episode's reset row), `state = next_state`, and the sum / count of
+// the returns of the episodes that ended at this step.  mr_rl_amd/ddpg.py did this with ~20 small PyTorch kernels per step.
+// ---------------------------------------------------------------------------------------------------------------------
+struct AddStepArgs {
+    const float* obs_prev; const float* act; const float* rew; const uint8_t* done; const float* obs_next; const float* final_obs;
+    const float* final_ret;
+    float* s; float* a; float* r; float* d; float* s2;     // the ring
+    float* obs_prev_out;                                    // [n][5]: receives obs_next (may be obs_prev itself)
+    float* ended;                                           // [2] += {sum of final_ret over done envs, their number}, or null
+    long long n; int32_t capacity, head, skip;              // the first `skip` envs are not stored (n > capacity: the last ones stay)
+    float scale[5];
+};
+__global__ __launch_bounds__(256) void mr_replay_add_step_kernel(const AddStepArgs A) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float ret = 0.f, cnt = 0.f;
+    if (i < A.n) {
+        const bool dn = A.done[i] != 0;
+        float so[5], s2o[5], nx[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { so[j] = A.obs_prev[i * 5 + j]; nx[j] = A.obs_next[i * 5 + j]; }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) s2o[j] = (dn && A.final_obs != nullptr) ? A.final_obs[i * 5 + j] : nx[j];
+        if (i >= A.skip) {
+            const long long row = (long long)((A.head + (i - A.skip)) % A.capacity);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { A.s[row * 5 + j] = so[j] * A.scale[j]; A.s2[row * 5 + j] = s2o[j] * A.scale[j]; }
+            A.a[row * 2] = A.act[i * 2]; A.a[row * 2 + 1] = A.act[i * 2 + 1];
+            A.r[row] = A.rew[i];
+            A.d[row] = dn ? 1.0f : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) A.obs_prev_out[i * 5 + j] = nx[j];
+        if (dn && A.final_ret != nullptr) { ret = A.final_ret[i]; cnt = 1.f; }
+    }
+    if (A.ended != nullptr) {       // (every lane of the wave is here: full-wave reduction, one atomic pair per wave that saw an end)
+        ret = wave_sum(ret); cnt = wave_sum(cnt);
+        if ((threadIdx.x & 63) == 0 && cnt > 0.f) { atomicAdd(A.ended, ret); atomicAdd(A.ended + 1, cnt); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Behaviour-policy upload on the device: the learner's online actor (parameter vector above, offsets A_*) -> the packed block the
 // env kernels read (mrsim_actor.h layout).  Same arithmetic as the host pair mrsim_actor_fold_bn_host + mrsim_actor_pack_host
 // (batch norm folded in double and rounded once; bf16 terms by round-to-nearest-even): the block is bit-identical (tested).

@@ -92,6 +92,25 @@ class ReplayBuffer:
         self.head = (self.head + n) % self.buffer_size
         self.count = min(self.count + n, self.buffer_size)
 
+    def add_step(self, obs_prev, actions, rew, done_u8, obs_next, final_obs, final_ret, obs_scale, ended=None):
+        """One lockstep env step's bookkeeping as ONE launch of libmrsim's mrsim_replay_add_step: add() of the n transitions
+        (s = obs_prev, s2 = final_obs where done else obs_next, both x obs_scale), obs_prev := obs_next in place, and
+        ended[2] += {sum of final_ret over the finished envs, their number}.  [n][5] rows; final_obs / final_ret may be None
+        (no auto-reset)."""
+        import ctypes as C
+        from . import _lib
+        n = int(obs_prev.shape[0])
+        sc = (C.c_float * 5)(*([1.0] * 5 if obs_scale is None else [float(x) for x in obs_scale]))
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        strm = C.c_void_p(torch.cuda.current_stream(self.s.device).cuda_stream)
+        _lib.check(_lib.lib().mrsim_replay_add_step(n, p(obs_prev), p(actions), p(rew), p(done_u8), p(obs_next), p(final_obs),
+                                                    p(final_ret), sc, p(self.s), p(self.a), p(self.r), p(self.t), p(self.s2),
+                                                    self.buffer_size, self.head, p(obs_prev), p(ended), strm),
+                   "mrsim_replay_add_step")
+        B = min(n, self.buffer_size)
+        self.head = (self.head + B) % self.buffer_size
+        self.count = min(self.count + B, self.buffer_size)
+
     def sample_batch(self, batch_size):
         n = min(batch_size, self.count)
         idx = torch.randperm(self.count, device=self.s.device, generator=self.gen)[:n]
@@ -535,12 +554,22 @@ class DDPG:
         self.collector, self.device_actor = col, pol
         return [float(x) for x in torch.cat(means).cpu()] if means else []
 
-    def train(self, total_steps, updates_per_step=1, log_every=0, warmup_quirk=False, observe=None):
+    def train(self, total_steps, updates_per_step=1, log_every=0, warmup_quirk=False, observe=None, fused_bookkeeping="auto"):
         """Runs `total_steps` lockstep env steps (N transitions each); returns per-episode returns seen.
         warmup_quirk=True reproduces RL/MR_ddpg.py:283-286,307: while the ring holds fewer than min_batch transitions
         after a step, `state = next_state` is skipped -- the policy keeps seeing (and the ring keeps storing as `state`)
-        the observation the episode was reset to.  observe: optional callback(step, obs_fed_to_the_policy) (tests)."""
+        the observation the episode was reset to.  observe: optional callback(step, obs_fed_to_the_policy) (tests).
+        fused_bookkeeping: with the in-kernel actor on a HIP device, the step's replay add / state hand-over / finished-episode
+        sums are ONE launch (ReplayBuffer.add_step) instead of ~20 PyTorch kernels; "auto" uses it when it applies, False keeps
+        the PyTorch statements (the two are compared in tests/test_gpu_round5.py), True demands it."""
         env = self.env
+        can_fuse = (self.device_actor is not None and env.device.type == "cuda" and env.cfg.auto_reset and not warmup_quirk
+                    and env._actions_out is not None and not getattr(env, "_soa", False))
+        if fused_bookkeeping is True and not can_fuse:
+            raise ValueError("fused_bookkeeping=True needs DDPG(device_actor=True), auto_reset, [N][5] observation rows, "
+                             "MRVecEnv(track_actions=True), a HIP device and warmup_quirk=False")
+        if fused_bookkeeping and can_fuse:
+            return self._train_fused_bookkeeping(total_steps, updates_per_step, log_every, observe)
         obs = env.reset().clone()
         # per-step (sum of the returns of the episodes that ended, their number) stay on the device: the loop never waits for the
         # host (the reference reads every reward on the host, RL/MR_ddpg.py:278-311); read back once per log line and at the end
@@ -581,3 +610,25 @@ class DDPG:
             return []
         rows = torch.stack(ended).cpu().tolist()
         return [sm / cnt for sm, cnt in rows if cnt > 0]          # mean return of the episodes that ended at each such step
+
+    def _train_fused_bookkeeping(self, total_steps, updates_per_step, log_every, observe):
+        """train() with two launches per env step besides the learner's: the step kernel (policy + noise + MR_Env.step) and
+        mrsim_replay_add_step (replay_buffer.add, `state = next_state`, the finished episodes' returns)."""
+        env = self.env
+        obs = env.reset().reshape(env.num_envs, 5).clone()
+        ended = torch.zeros((max(1, total_steps), 2), dtype=torch.float32, device=env.device)
+        scale = None if self.obs_scale is None else [float(x) for x in self.obs_scale.cpu()]
+        for k in range(total_steps):
+            if observe is not None:
+                observe(k, obs)
+            env.step(actor=self.device_actor)
+            self.buffer.add_step(obs, env._actions_out, env.rew, env._done_u8, env._obs, env._final_obs, env.final_ret, scale,
+                                 ended=ended[k])
+            for _ in range(updates_per_step):
+                self.update()
+            if log_every and (k + 1) % log_every == 0:
+                tail = ended[max(0, k + 1 - log_every):k + 1].sum(0).tolist()
+                if tail[1] > 0:
+                    print(f"step {k + 1}: mean return of the episodes finished in the last {log_every} steps {tail[0] / tail[1]:.2f}")
+        rows = ended[:total_steps].cpu().tolist()
+        return [sm / cnt for sm, cnt in rows if cnt > 0]

@@ -374,3 +374,64 @@ def test_fused_velocity_matches_scipy_numpy_over_chunk_boundaries(T, n, N):
         np.testing.assert_allclose(D.cpu().numpy(), want[N:-N].mean(0), rtol=1e-9, atol=1e-12)
     else:
         assert float(D.abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference-shaped loop's per-step bookkeeping as one launch (mrsim_replay_add_step)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused_learner", [False, True])
+@pytest.mark.parametrize("n_envs,ring", [(256, 10000), (192, 1000), (3000, 2048)])
+def test_fused_step_bookkeeping_equals_the_pytorch_statements(n_envs, ring, fused_learner):
+    """DDPG.train with fused_bookkeeping (replay add + `state = next_state` + finished-episode sums in ONE launch) against the
+    same loop written as PyTorch statements: the ring (all five arrays, head, fill), every network parameter after the updates
+    and the device policy's block are BIT-identical; the per-step mean returns agree to float32 summation order.  Rings that
+    wrap (192 envs into 1000 slots) and rings smaller than one step (3000 envs into 2048 slots: the last 2048 stay)."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.ddpg import DDPG
+    scale = (0.01, 0.01, 0.01, 0.01, 1.0)
+    cfg = MRConfig(noise_var=0.1, reward_mode="goal", auto_reset=True, init_low=(20.0, 20.0), init_high=(30.0, 30.0),
+                   min_dist2goal=25.0)
+    out = []
+    for fb in (False, True):
+        env = MRVecEnv(n_envs, cfg=cfg, seed=3, track_actions=True)
+        agent = DDPG(env, seed=5, obs_scale=scale, device_actor=True, buffer_size=ring, fused=fused_learner)
+        seen = []
+        rets = agent.train(70, fused_bookkeeping=fb, observe=lambda k, o: seen.append(o.clone()))
+        env.check_status()
+        b = agent.buffer
+        out.append({"rets": rets, "ring": [t.clone() for t in (b.s, b.a, b.r, b.t, b.s2)], "head": b.head, "count": b.count,
+                    "params": [p.detach().clone() for m in (agent.actor, agent.critic, agent.actor_t, agent.critic_t)
+                               for p in m.parameters()] if not fused_learner else [agent.fused.online.clone(), agent.fused.target.clone()],
+                    "blob": agent.device_actor.blob.clone(), "seen": seen, "obs": env.obs.clone()})
+    a, b = out
+    assert a["head"] == b["head"] and a["count"] == b["count"] == min(ring, 70 * n_envs)
+    for x, y in zip(a["ring"], b["ring"]):
+        assert torch.equal(x, y)
+    for x, y in zip(a["seen"], b["seen"]):
+        assert torch.equal(x, y)                       # the observation handed to the policy at every step
+    for x, y in zip(a["params"], b["params"]):
+        assert torch.equal(x, y)
+    assert torch.equal(a["blob"], b["blob"]) and torch.equal(a["obs"], b["obs"])
+    assert len(a["rets"]) == len(b["rets"]) > 0
+    np.testing.assert_allclose(a["rets"], b["rets"], rtol=2e-6, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_replay_add_step_rejects_bad_arguments_and_demands_its_conditions():
+    import ctypes as C
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv, _lib
+    from mr_rl_amd.ddpg import DDPG
+    L = _lib.lib()
+    t = torch.zeros(64, device="cuda")
+    p = C.c_void_p(t.data_ptr())
+    sc = (C.c_float * 5)(1, 1, 1, 1, 1)
+    assert L.mrsim_replay_add_step(1, p, p, p, p, p, None, None, sc, p, p, p, p, p, 8, 8, p, None, None) == _lib.EINVAL  # head
+    assert L.mrsim_replay_add_step(1, None, p, p, p, p, None, None, sc, p, p, p, p, p, 8, 0, p, None, None) == _lib.EINVAL
+    assert L.mrsim_replay_add_step(0, p, p, p, p, p, None, None, sc, p, p, p, p, p, 8, 0, p, None, None) == _lib.OK
+    env = MRVecEnv(64, cfg=MRConfig(auto_reset=False), seed=0, track_actions=True)
+    agent = DDPG(env, seed=0, device_actor=True)
+    with pytest.raises(ValueError, match="fused_bookkeeping=True needs"):
+        agent.train(2, fused_bookkeeping=True)
