@@ -1227,9 +1227,8 @@ def main():
     # the timed region would idle the GPU for milliseconds and the region would start on a dropped clock
     one_stream = args.mode == "rollout" and streams == 1
     ks = max(args.sustained_steps // ep, 1) * ep if (args.mode == "rollout" and args.sustained_steps > 0) else 0
-    ev_pool = [EventPair() for _ in range(min(K // ep + 1, 4096))] if (rank == 0 and one_stream) else None
     sus_pool = [EventPair() for _ in range(ks // ep + 1)] if (rank == 0 and ks) else None
-    ev_used, sus_used = [], []
+    sus_used = []
 
     # clock settle (tools/clock_ramp_probe.py: ~35 ms of load after idle), independent of the W the caller asks for
     trace("env ready; settle phase: %d episodes" % args.settle_episodes)
@@ -1248,7 +1247,7 @@ def main():
     # ---- the contract's timed region: EXACTLY K steps between barrier + synchronize, max over ranks
     region_phases = None
     if args.mode == "rollout":
-        el, launches = reg.timed(K, ev_pool, ev_used)
+        el, launches = reg.timed(K)
         region_phases = reg.last_phases_us
         per_rank_s = reg.last_per_rank_s
     else:
@@ -1285,33 +1284,42 @@ def main():
             return {"value": total * ks / els, "unit": "env-steps/s", "steps": ks, "launches": ls, "streams": region.col.S,
                     "preroll_episodes": PREROLL_EPISODES, "ms_per_step": els / ks * 1e3}, els
 
-        sustained, els_main = leg(reg, sus_pool if one_stream else None, sus_used)
+        sustained, els_main = leg(reg, None, None)        # plain launches: the throughput
         sustained["what"] = "the headline workload over its own region, independent of --steps"
-        els_one = els_main
-        if not one_stream:
-            reg1 = make_region(args, cfg, n_local, env_id0, world, dev, seed, 1, goal_table=goal_table, T=T)
-            one, _ = leg(reg1, None, None)                # its own buffers and state; plain launches: the throughput
-            ev_leg, els_one = leg(reg1, sus_pool, sus_used)  # again with a HIP event pair on every dispatch: the durations
-            reg1.col.check_status()
-            one["what"] = ("the same on ONE stream, one launch per episode (plain launches); `with_events` = that region "
-                           "again with a HIP event pair attached to every dispatch, the kernel durations behind `roofline`")
-            one["with_events"] = {"value": ev_leg["value"], "ms_per_step": ev_leg["ms_per_step"]}
-            sustained["one_stream"] = one
+        # the same on ONE stream, one launch per episode: plain, then again with a HIP event pair on every dispatch (the durations)
+        if one_stream:
+            reg1, one = reg, {k: v for k, v in sustained.items() if k != "what"}
+        else:
+            reg1 = make_region(args, cfg, n_local, env_id0, world, dev, seed, 1, goal_table=goal_table, T=T)  # its own buffers and state
+            one, _ = leg(reg1, None, None)
+        ev_leg, els_one = leg(reg1, sus_pool, sus_used)
+        reg1.col.check_status()
+        one["what"] = ("the same on ONE stream, one launch per episode (plain launches); `with_events` = that region "
+                       "again with a HIP event pair attached to every dispatch, the kernel durations behind `roofline`")
+        one["with_events"] = {"value": ev_leg["value"], "ms_per_step": ev_leg["ms_per_step"]}
+        sustained["one_stream"] = one
+        if one_stream:      # and the two-sub-shard form (mr_rl_amd.collector: two launch chains fill each other's tails), for the record
+            reg2 = make_region(args, cfg, n_local, env_id0, world, dev, seed, 2, goal_table=goal_table, T=T)
+            two, _ = leg(reg2, None, None)
+            reg2.col.check_status()
+            two["what"] = "the same as two sub-shard launches per episode on two HIP streams (--streams 2)"
+            sustained["two_streams"] = two
+            del reg2
+        else:
             del reg1
         trace("sustained legs done")
 
     (reg.col if args.mode == "rollout" else env).check_status()
     mean_ret = gatherer.last_mean()
     # events are read only now, after every timed region
-    region_ms = [e.elapsed_ms() for e in ev_used]
+    region_ms = []      # (the contract's timed region carries no events: they cost ~5 % of a one-stream region)
     sus_ms = [e.elapsed_ms() for e in sus_used]
-    for pool in (ev_pool, sus_pool):
-        if pool is not None:
-            for e in pool:
-                e.close()
+    if sus_pool is not None:
+        for e in sus_pool:
+            e.close()
     if sustained is not None and sus_ms:
         avg_us, med_us = stats_us(sus_ms)
-        tgt = sustained if one_stream else sustained["one_stream"]["with_events"]
+        tgt = sustained["one_stream"]["with_events"]
         tgt.update({"avg_kernel_us": round(avg_us, 3), "median_kernel_us": round(med_us, 3),
                     "kernel_time_over_wall": round(sum(sus_ms) * 1e-3 / els_one, 4),
                     "in_kernel_value": n_local * args.rollout_len / (avg_us * 1e-6)})
