@@ -751,6 +751,29 @@ def measure_learner(args, n_local, dev, seed, streams):
                    "(collection with the actor in the kernel + learner) at a stated update : transition ratio",
            "batch": 64, "updates_per_s": {k: round(v, 1) for k, v in ups.items()},
            "us_per_update": {k: round(1e6 / v, 1) for k, v in ups.items()}, "by_batch": big, "end_to_end": []}
+    # the reference's own loop shape (RL/MR_ddpg.py:262-311: act, env.step, replay add, ONE update -- per env step), DDPG.train:
+    # step kernel with the actor inside + mrsim_replay_add_step + mrsim_ddpg_update (+ the policy upload), N envs in lockstep
+    loop = {"what": "DDPG.train: one env step, one replay add, one learner update (64 rows) per iteration, as RL/MR_ddpg.py:262-311 does "
+                    "for one env; per-step bookkeeping as PyTorch statements (rounds 2-4) and as ONE launch (mrsim_replay_add_step)",
+            "rows": []}
+    for n_loop in (1, 256, 4096):
+        for fb in (False, True):
+            envl = MRVecEnv(n_loop, cfg=MRConfig(noise_var=0.1, reward_mode="goal", auto_reset=True, init_low=(20.0, 20.0),
+                                                 init_high=(30.0, 30.0), min_dist2goal=25.0, seed=seed), device=dev, seed=seed,
+                            track_actions=True)
+            agl = DDPG(envl, seed=seed, obs_scale=[0.01, 0.01, 0.01, 0.01, 1.0], device_actor=True, fused=True,
+                       buffer_size=max(10000, 4 * n_loop))
+            agl.train(200, fused_bookkeeping=fb)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            agl.train(1500, fused_bookkeeping=fb)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            agl.close()
+            loop["rows"].append({"envs": n_loop, "bookkeeping": "one launch" if fb else "pytorch statements",
+                                 "us_per_iteration": round(dt / 1500 * 1e6, 1), "iterations_per_s": round(1500 / dt, 1),
+                                 "env_steps_per_s": round(1500 * n_loop / dt, 1)})
+    out["reference_shaped_loop"] = loop
     ep = cfg.max_timesteps + 1
     # learner_cus = 1: the learner's launches on 8 compute units of their own (one per XCC), the collection on the other 248
     # (mr_rl_amd.partition) -- reported beside the shared-device rows
