@@ -129,7 +129,10 @@ d1 = json.loads(line1[-1])
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt1))
        if "mr_rollout_kernel<true, 4, false, 7" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == N]
 seq = [("settle", 400), ("warm-up", d1["warmup"] // T), ("timed (the contract's region)", d1["steps"] // T),
-       ("pre-roll of the sustained leg", d1["sustained"].get("preroll_episodes", 0)), ("sustained", d1["sustained"]["steps"] // T)]
+       ("pre-roll of the sustained leg", d1["sustained"].get("preroll_episodes", 0)), ("sustained", d1["sustained"]["steps"] // T),
+       # (--streams 1: the same region again with a HIP event pair on every dispatch -- the durations bench.py's roofline uses)
+       ("pre-roll of the with-events leg", d1["sustained"].get("preroll_episodes", 0)),
+       ("sustained, a HIP event pair on every dispatch", d1["sustained"]["steps"] // T)]
 if sum(n for _, n in seq) != len(dur):
     die(f"{kt1}: {len(dur)} full-size rollout dispatches, expected {sum(n for _, n in seq)} from the bench line of that run")
 by_region, k0 = [], 0
@@ -145,7 +148,7 @@ files["rollout_kernel_by_region.json"] = json.dumps({
             "that same run",
     **stamp, "source": prov(kt1), "by_region": by_region,
     "blocks_of_100_us": [round(sum(dur[i:i + 100]) / len(dur[i:i + 100]), 1) for i in range(0, len(dur), 100)],
-    "bench_events": {"sustained_avg_kernel_us": d1["sustained"].get("avg_kernel_us"),
+    "bench_events": {"sustained_avg_kernel_us": d1["sustained"]["one_stream"]["with_events"].get("avg_kernel_us"),
                      "roofline_avg_kernel_us": d1["roofline"]["avg_kernel_us"]}}, indent=1) + "\n"
 files["instbench.json"] = json.dumps({"what": "tools/instbench --json: ns per wave-instruction per SIMD, 8 independent chains per wave",
                                       **stamp, "rows": inst}, indent=1) + "\n"
