@@ -754,10 +754,11 @@ def measure_learner(args, n_local, dev, seed, streams):
     # the reference's own loop shape (RL/MR_ddpg.py:262-311: act, env.step, replay add, ONE update -- per env step), DDPG.train:
     # step kernel with the actor inside + mrsim_replay_add_step + mrsim_ddpg_update (+ the policy upload), N envs in lockstep
     loop = {"what": "DDPG.train: one env step, one replay add, one learner update (64 rows) per iteration, as RL/MR_ddpg.py:262-311 does "
-                    "for one env; per-step bookkeeping as PyTorch statements (rounds 2-4) and as ONE launch (mrsim_replay_add_step)",
+                    "for one env; per-step bookkeeping as PyTorch statements (rounds 2-4), as ONE launch (mrsim_replay_add_step), and inside "
+                    "the step kernel (MrsimStepIO.replay: no launch of its own)",
             "rows": []}
     for n_loop in (1, 256, 4096):
-        for fb in (False, True):
+        for fb in (False, "add_step", True):
             envl = MRVecEnv(n_loop, cfg=MRConfig(noise_var=0.1, reward_mode="goal", auto_reset=True, init_low=(20.0, 20.0),
                                                  init_high=(30.0, 30.0), min_dist2goal=25.0, seed=seed), device=dev, seed=seed,
                             track_actions=True)
@@ -770,7 +771,7 @@ def measure_learner(args, n_local, dev, seed, streams):
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t0
             agl.close()
-            loop["rows"].append({"envs": n_loop, "bookkeeping": "one launch" if fb else "pytorch statements",
+            loop["rows"].append({"envs": n_loop, "bookkeeping": {False: "pytorch statements", "add_step": "one launch", True: "in the step kernel"}[fb],
                                  "us_per_iteration": round(dt / 1500 * 1e6, 1), "iterations_per_s": round(1500 / dt, 1),
                                  "env_steps_per_s": round(1500 * n_loop / dt, 1)})
     out["reference_shaped_loop"] = loop

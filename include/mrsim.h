@@ -194,6 +194,25 @@ typedef struct MrsimActor {
     int32_t reserved0;        /* 0                                                                            */
 } MrsimActor;
 
+/* Optional sink of a step launch whose policy is the in-kernel actor (ABI 5): the step writes its n transitions straight into a
+ * replay ring -- RL/MR_ddpg.py:278-282 `replay_buffer.add(state, action, reward, terminal, next_state)` without a launch of its
+ * own.  Env i of the launch goes to row (head + i - skip) mod capacity, skip = max(0, n - capacity) (the last `capacity` envs stay);
+ * s = the observation the actor was evaluated on x obs_scale, a = the applied action, r, done, s2 = the observation after the step
+ * (the TERMINAL one where the episode ended, also under auto_reset) x obs_scale -- the rows mrsim_replay_add_step writes from the
+ * step's outputs, bit for bit.  ended2 (optional) [2] += {sum of the returns of the episodes that ended (auto_reset), their number}. */
+typedef struct MrsimReplaySink {
+    float* s;            /* DEVICE [capacity][5] */
+    float* a;            /* DEVICE [capacity][2] */
+    float* r;            /* DEVICE [capacity]    */
+    float* done;         /* DEVICE [capacity]: 1.0 / 0.0 */
+    float* s2;           /* DEVICE [capacity][5] */
+    float* ended2;       /* DEVICE [2], optional */
+    int32_t capacity;
+    int32_t head;
+    float obs_scale[5];
+    int32_t reserved0;   /* 0 */
+} MrsimReplaySink;
+
 /* Inputs / outputs of one step.  Optional pointers may be NULL. */
 typedef struct MrsimStepIO {
     const float* actions;    /* [n][2] {f_t, alpha_t}  (MR_env.py:81-82).  NULL: draw the     */
@@ -218,6 +237,7 @@ typedef struct MrsimStepIO {
                              /*   (integrator.nfev after - before) / 6 of the RK45 object     */
                              /*   that integrates it (MR_simulator.py:42-43); fixed-step      */
                              /*   modes: substeps                                             */
+    const MrsimReplaySink* replay; /* optional (HOST pointer; ABI 5): needs `actor`             */
 } MrsimStepIO;
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -259,6 +279,12 @@ typedef struct MrsimDdpgLearner {
                              /*   the whole batch's gradient, the actor's gradient the updated critic) instead of one workgroup  */
                              /*   looping over the tiles; partial gradients are summed in tile order: bit-identical to that loop */
     int64_t batch_scratch_floats; /* its size in floats: >= MRSIM_DDPG_BATCH_SCRATCH_FLOATS(batch)                                 */
+    float* actor_blob;       /* DEVICE [MRSIM_ACTOR_BLOB_FLOATS], 16-byte aligned, or NULL (ABI 5): after the LAST update of the call the */
+                             /*   online actor is folded and packed into this block exactly as mrsim_actor_pack_device does (same bits)   */
+                             /*   -- the behaviour policy follows the learner (RL/MR_ddpg.py:277 actor.predict uses the weights of :302)  */
+                             /*   without a launch of its own: the tail of the update kernel (a launch after the multi-workgroup form)    */
+    float actor_obs_scale[5];/* the input scaling folded into that block's first layer                                                    */
+    int32_t reserved0;       /* 0                                                                                                          */
 } MrsimDdpgLearner;
 #define MRSIM_DDPG_BATCH_SCRATCH_FLOATS(batch) ((int64_t)((batch) / 64) * (MRSIM_DDPG_PARAMS + 4) + (batch) + 64)
 /* One update on `batch` transitions (a multiple of 64, <= MRSIM_DDPG_MAX_BATCH; the reference uses 64; batches above 64 spread over

@@ -74,7 +74,14 @@ class MrsimDdpgLearner(C.Structure):
                 ("grad_scratch", C.c_void_p), ("steps", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_eps", C.c_float),
                 ("gamma", C.c_float), ("tau", C.c_float), ("actor_lr", C.c_float), ("critic_lr", C.c_float), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("adam_eps", C.c_float), ("action_bound", C.c_float * 2),
-                ("batch_scratch", C.c_void_p), ("batch_scratch_floats", C.c_int64)]
+                ("batch_scratch", C.c_void_p), ("batch_scratch_floats", C.c_int64),
+                ("actor_blob", C.c_void_p), ("actor_obs_scale", C.c_float * 5), ("reserved0", C.c_int32)]
+
+
+class MrsimReplaySink(C.Structure):
+    _fields_ = [("s", C.c_void_p), ("a", C.c_void_p), ("r", C.c_void_p), ("done", C.c_void_p), ("s2", C.c_void_p),
+                ("ended2", C.c_void_p), ("capacity", C.c_int32), ("head", C.c_int32), ("obs_scale", C.c_float * 5),
+                ("reserved0", C.c_int32)]
 
 
 class MrsimStepIO(C.Structure):
@@ -83,6 +90,7 @@ class MrsimStepIO(C.Structure):
         ("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("state_prime", C.c_void_p),
         ("final_obs", C.c_void_p), ("final_ret", C.c_void_p), ("final_len", C.c_void_p),
         ("status", C.c_void_p), ("actor", C.POINTER(MrsimActor)), ("attempts", C.c_void_p),
+        ("replay", C.POINTER(MrsimReplaySink)),
     ]
 
 
@@ -161,7 +169,8 @@ def load(path):
         raise ImportError(f"{path}: ABI {L.mrsim_abi_version()} != binding ABI {ABI_VERSION}")
     assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 12 + 8
     assert C.sizeof(MrsimRolloutIO) == 8 + 8 * 11 + 8 + 4 + 4 + 8
-    assert C.sizeof(MrsimStepIO) == 8 * 13
+    assert C.sizeof(MrsimStepIO) == 8 * 14 and C.sizeof(MrsimReplaySink) == 8 * 6 + 4 * 8
+    assert C.sizeof(MrsimDdpgLearner) == 144
     assert C.sizeof(MrsimActor) == 40 and C.sizeof(MrsimActorWeights) == 48 + 28 + 4
     return L
 

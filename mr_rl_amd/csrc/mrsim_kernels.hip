@@ -68,6 +68,12 @@ struct StateArgs {
     float* ep_ret;
 };
 
+struct ReplaySinkArgs {      // MrsimReplaySink by value; s == nullptr: none
+    float* s; float* a; float* r; float* d; float* s2; float* ended;
+    int32_t capacity, head, skip;
+    float scale[5];
+};
+
 struct IOArgs {
     const float* actions;
     float* actions_out;
@@ -81,6 +87,7 @@ struct IOArgs {
     int32_t* final_len;
     int32_t* status;
     int32_t* attempts;
+    ReplaySinkArgs rp;
 };
 
 // ---------------------------------------------------------------------------
@@ -118,8 +125,8 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
         }
         step_prologue<RK45, NZ, MIS>(P, R, !HAS_ACT && !(fl & kFActions), W, af, aa, HAS_ACT && (fl & kFActorOU));
         float ou0 = 0.f, ou1 = 0.f;
+        float obs_cur[HAS_ACT ? 5 : 1];
         if constexpr (HAS_ACT) {
-            float obs_cur[5];
             obs_from_state(P, fl, io.goal_table, R.env, e, obs_cur);
             if (fl & kFActorOU) {
                 const float2 u = reinterpret_cast<const float2*>(ac.ou_state)[il];
@@ -159,6 +166,28 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
             if constexpr (!AOS) {
 #pragma unroll
                 for (int j = 0; j < 5; ++j) io.obs[(long long)j * P.n + i] = o.obs[j];
+            }
+            if constexpr (HAS_ACT && FL == 0) {
+                // replay_buffer.add (RL/MR_ddpg.py:278-282) from the registers: what the actor saw, what it did, what came of it
+                if (io.rp.s != nullptr && i >= io.rp.skip) {
+                    const long long row = (long long)(((long long)io.rp.head + (i - io.rp.skip)) % io.rp.capacity);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        io.rp.s[row * 5 + j] = obs_cur[j] * io.rp.scale[j];
+                        io.rp.s2[row * 5 + j] = (o.has_final ? o.fobs[j] : o.obs[j]) * io.rp.scale[j];
+                    }
+                    io.rp.a[row * 2] = af; io.rp.a[row * 2 + 1] = aa;
+                    io.rp.r[row] = o.rew;
+                    io.rp.d[row] = o.done ? 1.0f : 0.0f;
+                }
+            }
+        }
+        if constexpr (HAS_ACT && FL == 0) {
+            if (io.rp.ended != nullptr) {     // (every lane of the wave is here: ACT runs the whole body wave-wide)
+                float ret = (active && o.has_final) ? o.fret : 0.f, cnt = (active && o.has_final) ? 1.f : 0.f;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) { ret += __shfl_xor(ret, m, 64); cnt += __shfl_xor(cnt, m, 64); }
+                if ((threadIdx.x & 63) == 0 && cnt > 0.f) { atomicAdd(io.rp.ended, ret); atomicAdd(io.rp.ended + 1, cnt); }
             }
         }
     }
@@ -1107,8 +1136,18 @@ static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
     if ((rc = actor_args(p, io->actor, io->actions != nullptr, AC, abits, actor_on))) return rc;
     if ((rc = check_device())) return rc;
     const StateArgs S{st->pos, st->aux, st->ep_ret};
+    ReplaySinkArgs RP{};
+    if (io->replay != nullptr) {
+        const MrsimReplaySink* q = io->replay;
+        if (!actor_on || q->s == nullptr || q->a == nullptr || q->r == nullptr || q->done == nullptr || q->s2 == nullptr ||
+            q->capacity < 1 || q->head < 0 || q->head >= q->capacity)
+            return MRSIM_EINVAL;
+        RP = ReplaySinkArgs{q->s, q->a, q->r, q->done, q->s2, q->ended2, q->capacity, q->head,
+                            n > q->capacity ? (int32_t)(n - q->capacity) : 0,
+                            {q->obs_scale[0], q->obs_scale[1], q->obs_scale[2], q->obs_scale[3], q->obs_scale[4]}};
+    }
     const IOArgs IO{io->actions, io->actions_out, io->goal_table, io->obs, io->rew, io->done, io->state_prime,
-                    io->final_obs, io->final_ret, io->final_len, io->status, io->attempts};
+                    io->final_obs, io->final_ret, io->final_len, io->status, io->attempts, RP};
     K.flags |= (io->actions ? kFActions : 0u) | (io->goal_table ? kFGoalTable : 0u) |
                (io->actions_out ? kFOutActions : 0u) | (io->state_prime ? kFOutStatePrime : 0u) |
                (io->final_obs ? kFOutFinalObs : 0u) | (io->final_ret ? kFOutFinalRet : 0u) |
@@ -1486,13 +1525,14 @@ int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, int32_t n_updat
                       const float* s2, const int32_t* idx, int32_t ring_count, uint64_t seed, uint64_t draw_counter,
                       int32_t* idx_out, float* losses_out, void* stream) {
     static_assert(MRSIM_DDPG_PARAMS == learner::kParams && MRSIM_DDPG_MAX_BATCH == learner::kMaxBatch, "mrsim.h / mrsim_learner.h");
+    static_assert(sizeof(MrsimDdpgLearner) == 144 && sizeof(MrsimReplaySink) == 80 && sizeof(MrsimStepIO) == 112, "mrsim.h / mr_rl_amd/_lib.py");
     if (Lr == nullptr || Lr->online == nullptr || Lr->target == nullptr || Lr->adam_m == nullptr || Lr->adam_v == nullptr ||
         Lr->grad_scratch == nullptr || Lr->steps == nullptr || Lr->bn_stats == nullptr || s == nullptr || a == nullptr ||
         r == nullptr || done == nullptr || s2 == nullptr)
         return MRSIM_EINVAL;
     if (batch < learner::kTile || batch > learner::kMaxBatch || batch % learner::kTile != 0) return MRSIM_EINVAL;
     if (ring_count < 0 || n_updates < 1 || n_updates > 65536) return MRSIM_EINVAL;
-    if (!aligned16(Lr->online) || !aligned16(Lr->target)) return MRSIM_EALIGN;
+    if (!aligned16(Lr->online) || !aligned16(Lr->target) || (Lr->actor_blob != nullptr && !aligned16(Lr->actor_blob))) return MRSIM_EALIGN;
     if (!(Lr->bn_eps > 0.0f) || !(Lr->beta1 >= 0.0f && Lr->beta1 < 1.0f) || !(Lr->beta2 >= 0.0f && Lr->beta2 < 1.0f)) return MRSIM_EINVAL;
     int rc = check_device();
     if (rc) return rc;
@@ -1514,7 +1554,8 @@ int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, int32_t n_updat
     learner::Args A{Lr->online, Lr->target, Lr->adam_m, Lr->adam_v, Lr->grad_scratch, Lr->steps, Lr->bn_stats, s, a, r, done, s2, idx,
                     idx_out, ring_count, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)draw_counter, (uint32_t)(draw_counter >> 32),
                     losses_out, batch, n_updates, Lr->bn_eps, Lr->gamma, Lr->tau, Lr->actor_lr, Lr->critic_lr, Lr->beta1, Lr->beta2, Lr->adam_eps,
-                    Lr->action_bound[0], Lr->action_bound[1], nullptr, nullptr, nullptr, nullptr, 1};
+                    Lr->action_bound[0], Lr->action_bound[1], nullptr, nullptr, nullptr, nullptr, 1, Lr->actor_blob,
+                    {Lr->actor_obs_scale[0], Lr->actor_obs_scale[1], Lr->actor_obs_scale[2], Lr->actor_obs_scale[3], Lr->actor_obs_scale[4]}};
     if (!multi) {
         hipLaunchKernelGGL(learner::mr_ddpg_update_kernel, dim3(1), dim3(learner::kThreads), sizeof(learner::Lds),
                            static_cast<hipStream_t>(stream), A);
@@ -1545,6 +1586,11 @@ int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, int32_t n_updat
             hipLaunchKernelGGL(learner::mr_ddpg_mw_step_kernel<1>, dim3(kActorBlocks), dim3(learner::kThreads), 0, st_, A, tiles);
             hipLaunchKernelGGL(learner::mr_ddpg_mw_count_kernel, dim3(1), dim3(64), 0, st_, Lr->steps);
         }
+    }
+    if (Lr->actor_blob != nullptr) {   // (no single workgroup ends this form: the policy upload is a launch of its own)
+        const learner::PackArgs K{Lr->online, Lr->bn_stats, Lr->bn_stats + 64, 128, Lr->actor_blob, Lr->bn_eps, Lr->action_bound[0], Lr->action_bound[1],
+                                  {A.pack_scale[0], A.pack_scale[1], A.pack_scale[2], A.pack_scale[3], A.pack_scale[4]}};
+        hipLaunchKernelGGL(learner::mr_actor_pack_kernel, dim3(1), dim3(256), 0, st_, K);
     }
     return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
 }
@@ -1596,7 +1642,7 @@ int mrsim_actor_pack_device(const float* learner_online, const float* bn_stats, 
     if (!aligned16(blob)) return MRSIM_EALIGN;
     int rc = check_device();
     if (rc) return rc;
-    learner::PackArgs A{learner_online, bn_stats, blob, bn_eps, action_bound[0], action_bound[1],
+    learner::PackArgs A{learner_online, bn_stats, bn_stats + 64, 128, blob, bn_eps, action_bound[0], action_bound[1],
                         {obs_scale[0], obs_scale[1], obs_scale[2], obs_scale[3], obs_scale[4]}};
     hipLaunchKernelGGL(learner::mr_actor_pack_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), A);
     return hipGetLastError() == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;

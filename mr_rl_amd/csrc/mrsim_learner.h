@@ -56,6 +56,8 @@ struct Args {
     float* loss_partial;            // [tiles][2]
     unsigned int* counter;          // [2]: arrival tickets of the two halves (zero between launches)
     int32_t reduce_in_kernel;       // 1: the last workgroup to arrive reduces and steps (few tiles); 0: mr_ddpg_mw_step_kernel does
+    float* pack_blob;               // optional: the online actor folded / packed into this block after the last update of the launch
+    float pack_scale[5];            //   (single-workgroup kernel: its tail; multi-workgroup form: mr_actor_pack_kernel follows)
 };
 
 // C[m0 .. m0+TM)[n0 .. n0+TN) = sum_k A(m, k) B(k, n).  B is k-major ([K][ldb], n contiguous).  A is k-major ([K][lda], m
@@ -143,7 +145,7 @@ __device__ __forceinline__ double ipow(double b, int t) {
 
 struct Lds {
     float P[kParams];          // the staged network pair (target, then online)
-    float rstd[3][64], mean[3][64];
+    float rstd[3][64], mean[3][64], var[3][64];   // (var: the raw moving variances, for the policy upload's double-precision fold)
     float s[kTile * 5], s2[kTile * 5], a[kTile * 2], ap[kTile * 2], th[kTile * 2], dz3[kTile * 2], r[kTile], d[kTile], dq[kTile];
     float y[kMaxBatch];
     float X[5][kTile * 64];
@@ -167,7 +169,9 @@ __device__ __forceinline__ void stage_params(Lds& L, const float* __restrict__ s
     for (int q = tid; q < 3 * 64; q += kThreads) {
         const int l = q >> 6, k = q & 63;
         L.mean[l][k] = bn[(l * 2 + 0) * 64 + k];
-        L.rstd[l][k] = 1.0f / sqrtf(bn[(l * 2 + 1) * 64 + k] + eps);
+        const float vr = bn[(l * 2 + 1) * 64 + k];
+        L.var[l][k] = vr;
+        L.rstd[l][k] = 1.0f / sqrtf(vr + eps);
     }
 }
 
@@ -235,7 +239,7 @@ __device__ __forceinline__ void layer1_backward(Lds& L, const float* __restrict_
 // Adam (torch.optim.Adam's formula: theta -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)) + soft update of the target,
 // four parameters per thread and pass (16-byte accesses; [p0, p1) is 16-byte aligned -- the padding floats carry zero gradients)
 template <int P0, int P1>
-__device__ __forceinline__ void adam_soft(const Args& A, float lr, float bc1, float bc2s, int tid) {
+__device__ __forceinline__ void adam_soft(const Args& A, float lr, float bc1, float bc2s, int tid, float* __restrict__ lds_online = nullptr) {
     const float c1 = 1.0f - A.beta1, c2 = 1.0f - A.beta2, step = lr / bc1, omt = 1.0f - A.tau;
     // every load of the thread's parameters in flight before the first store (the pointers may alias as far as the compiler knows:
     // written as one loop it waits for a round trip to L2 per pass)
@@ -269,6 +273,8 @@ __device__ __forceinline__ void adam_soft(const Args& A, float lr, float bc1, fl
         *reinterpret_cast<float4*>(A.adam_v + p) = make_float4(vo[0], vo[1], vo[2], vo[3]);
         *reinterpret_cast<float4*>(A.online + p) = make_float4(th[0], th[1], th[2], th[3]);
         *reinterpret_cast<float4*>(A.target + p) = make_float4(tg[0], tg[1], tg[2], tg[3]);
+        // (the policy upload that ends the launch reads the new actor from the staged image instead of waiting for L2)
+        if (lds_online != nullptr) *reinterpret_cast<float4*>(lds_online + p) = make_float4(th[0], th[1], th[2], th[3]);
     }
 }
 
@@ -746,7 +752,7 @@ __device__ __forceinline__ void ddpg_update_body(const Args& A, Lds& L) {
         mw_reduce<A_W1, C_W1>(A, L, 1, tid);
         if (tid == 0) A.counter[1] = 0u;
     }
-    adam_soft<A_W1, C_W1>(A, A.actor_lr, L.bc[2], L.bc[3], tid);
+    adam_soft<A_W1, C_W1>(A, A.actor_lr, L.bc[2], L.bc[3], tid, (MODE == kModeAll && A.pack_blob != nullptr) ? L.P : nullptr);
     if (tid < 2) A.steps[tid] += 1;
     if constexpr (MODE == kModeActorHalf) { if (A.losses != nullptr && tid == 0) A.losses[1] = L.loss[1]; }
     else { if (A.losses != nullptr && tid < 2) A.losses[tid] = L.loss[tid]; }
@@ -806,9 +812,122 @@ __global__ void mr_ddpg_mw_count_kernel(int32_t* steps) {
     if (blockIdx.x == 0 && threadIdx.x < 2) steps[threadIdx.x] += 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Behaviour-policy upload on the device: the learner's online actor (parameter vector above, offsets A_*) -> the packed block the
+// env kernels read (mrsim_actor.h layout).  Same arithmetic as the host pair mrsim_actor_fold_bn_host + mrsim_actor_pack_host
+// (batch norm folded in double and rounded once; bf16 terms by round-to-nearest-even): the block is bit-identical (tested).
+// One workgroup of 256 lanes; runs as a kernel of its own (mrsim_actor_pack_device) or as the tail of the update kernel
+// (MrsimDdpgLearner.actor_blob: the policy upload of RL/MR_ddpg.py's loop without a launch -- 9.3 us as a launch, profiles/r05).
+// ---------------------------------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* params;      // learner layout (actor part); global, or the update kernel's staged image in LDS
+    const float* mean;        // moving means of the actor's two batch-norm layers, [l * bn_stride + f]
+    const float* var;         // moving variances, likewise
+    int bn_stride;
+    float* blob;              // [kActBlobFloats]
+    float eps, bound0, bound1;
+    float scale[5];
+};
+__device__ __forceinline__ uint16_t bf16_rne_bits(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+constexpr int kPackW2Stride = 65;   // rows of the folded W2 in LDS: lanes read one COLUMN element of 32 different rows at a time -- a
+                                    // stride of 64 floats puts all of them in one bank (6 us of the 9.3 us this kernel took)
+struct PackLds {
+    float w1f[64 * 5], b1f[64], w2f[64 * kPackW2Stride], b2f[64];
+    double g2s[64];
+};
+static_assert(sizeof(PackLds) <= sizeof(Lds), "the pack tail reuses the update kernel's LDS image");
+__device__ __forceinline__ void actor_pack_body(const PackArgs& A, PackLds& S, int tid) {
+    constexpr int H = 64;
+    // fold: y = gamma (W x + b - mean) / sqrt(var + eps) + beta == W' x + b'   (double, rounded once; the per-feature gains are
+    // formed once -- a double divide and square root per ELEMENT of W2 made this kernel 14 us long)
+    if (tid < H) {
+        const int f = tid;
+        const double g1 = (double)A.params[A_G1 + f] / sqrt((double)A.var[f] + (double)A.eps);
+        for (int k = 0; k < 5; ++k) S.w1f[f * 5 + k] = (float)((double)A.params[A_W1 + f * 5 + k] * g1);
+        S.b1f[f] = (float)(((double)A.params[A_B1 + f] - (double)A.mean[f]) * g1 + (double)A.params[A_BE1 + f]);
+        const double g2 = (double)A.params[A_G2 + f] / sqrt((double)A.var[A.bn_stride + f] + (double)A.eps);
+        S.b2f[f] = (float)(((double)A.params[A_B2 + f] - (double)A.mean[A.bn_stride + f]) * g2 + (double)A.params[A_BE2 + f]);
+        S.g2s[f] = g2;
+    }
+    __syncthreads();
+    for (int o = tid * 4; o < H * H; o += 256 * 4) {        // (one row of W2 per 16 lanes: the gain is per row)
+        const float4 w = *reinterpret_cast<const float4*>(A.params + A_W2 + o);
+        const double g = S.g2s[o >> 6];
+        float* dst = &S.w2f[(o >> 6) * kPackW2Stride + (o & 63)];
+        dst[0] = (float)((double)w.x * g); dst[1] = (float)((double)w.y * g); dst[2] = (float)((double)w.z * g); dst[3] = (float)((double)w.w * g);
+    }
+    __syncthreads();
+    // every float of the block is written below (the host packer zero-fills first: the only bytes it leaves zero are the layer-1
+    // slots past the fifth input and the four pad floats of the tail)
+    {   // layer-2 A operands, f32: [rt 2][q4 8][lane 64][4] -- one 16-byte store per (rt, q4, lane): 1024 stores, four per lane
+        for (int it = tid; it < 2 * 8 * 64; it += 256) {
+            const int lane = it & 63, q4 = (it >> 6) & 7, rt = it >> 9, f = 32 * rt + (lane & 31), h = lane >> 5;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = S.w2f[f * kPackW2Stride + act_kperm(4 * q4 + j, h)];
+            *reinterpret_cast<float4*>(A.blob + kActA2 + (size_t)it * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    {   // layer-2 A operands as three bf16 terms: [rt 2][s 4][part 3][lane 64][8] -- three 16-byte stores per (rt, s, lane)
+        uint16_t* bf = reinterpret_cast<uint16_t*>(A.blob + kActA2bf);
+        for (int it = tid; it < 2 * 4 * 64; it += 256) {
+            const int lane = it & 63, sx = (it >> 6) & 3, rt = it >> 8, f = 32 * rt + (lane & 31), h = lane >> 5;
+            uint32_t pk[3][4];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                float r = S.w2f[f * kPackW2Stride + act_kperm(8 * sx + jj, h)];
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    const uint16_t t = bf16_rne_bits(r);
+                    if (jj & 1) pk[part][jj >> 1] |= (uint32_t)t << 16; else pk[part][jj >> 1] = (uint32_t)t;
+                    r -= __uint_as_float((uint32_t)t << 16);
+                }
+            }
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+                *reinterpret_cast<uint4*>(bf + ((((size_t)(rt * 4 + sx) * 3 + part) * 64 + lane) * 8)) =
+                    make_uint4(pk[part][0], pk[part][1], pk[part][2], pk[part][3]);
+        }
+    }
+    if (tid < 128) {
+        const int rt = tid >> 6, lane = tid & 63, f = 32 * rt + (lane & 31), h = lane >> 5;
+        for (int sx = 0; sx < 3; ++sx) {
+            const int k = 2 * sx + h;
+            A.blob[kActA1 + (rt * 3 + sx) * 64 + lane] = k < 5 ? S.w1f[f * 5 + k] * A.scale[k] : 0.0f;
+        }
+    } else if (tid < 192) {
+        const int o = tid - 128, h = o >> 5, q = o & 31;
+        A.blob[kActC1 + h * 32 + q] = S.b1f[act_kperm(q, h)];
+        A.blob[kActC2 + h * 32 + q] = S.b2f[act_kperm(q, h)];
+        for (int oo = 0; oo < 2; ++oo) A.blob[kActW3 + (h * 2 + oo) * 32 + q] = A.params[A_W3 + oo * H + act_kperm(q, h)];
+    } else if (tid == 192) {
+        A.blob[kActTail + 0] = A.params[A_B3 + 0]; A.blob[kActTail + 1] = A.params[A_B3 + 1];
+        A.blob[kActTail + 2] = A.bound0; A.blob[kActTail + 3] = A.bound1;
+#pragma unroll
+        for (int j = 4; j < 8; ++j) A.blob[kActTail + j] = 0.0f;
+    }
+}
+__global__ __launch_bounds__(256) void mr_actor_pack_kernel(const PackArgs A) {
+    __shared__ PackLds S;
+    actor_pack_body(A, S, threadIdx.x);
+}
+
 __global__ __launch_bounds__(kThreads) void mr_ddpg_update_kernel(const Args A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     ddpg_update_body<kModeAll>(A, *reinterpret_cast<Lds*>(lds_raw));
+    if (A.pack_blob != nullptr) {   // the behaviour policy's block from the parameters the last update just wrote: read from the
+        // staged image (the actor's Adam step left its new values there too; the online network's batch-norm constants are the
+        // ones staged last) -- no trip to L2; the fold's scratch lives in the activation buffers, which are free now
+        Lds& L = *reinterpret_cast<Lds*>(lds_raw);
+        static_assert(sizeof(PackLds) <= sizeof(L.X), "pack scratch inside the activation buffers");
+        const PackArgs K{L.P, &L.mean[0][0], &L.var[0][0], 64, A.pack_blob, A.bn_eps, A.bound0, A.bound1,
+                         {A.pack_scale[0], A.pack_scale[1], A.pack_scale[2], A.pack_scale[3], A.pack_scale[4]}};
+        actor_pack_body(K, *reinterpret_cast<PackLds*>(&L.X[0][0]), threadIdx.x);
+    }
 }
 // the multi-workgroup form: grid = batch / 64 workgroups, the two halves of ONE update (see ddpg_update_body)
 __global__ __launch_bounds__(kThreads) void mr_ddpg_mw_critic_kernel(const Args A) {
@@ -894,70 +1013,6 @@ __global__ __launch_bounds__(256) void mr_replay_add_step_kernel(const AddStepAr
     if (A.ended != nullptr) {       // (every lane of the wave is here: full-wave reduction, one atomic pair per wave that saw an end)
         ret = wave_sum(ret); cnt = wave_sum(cnt);
         if ((threadIdx.x & 63) == 0 && cnt > 0.f) { atomicAdd(A.ended, ret); atomicAdd(A.ended + 1, cnt); }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Behaviour-policy upload on the device: the learner's online actor (parameter vector above, offsets A_*) -> the packed block the
-// env kernels read (mrsim_actor.h layout).  Same arithmetic as the host pair mrsim_actor_fold_bn_host + mrsim_actor_pack_host
-// (batch norm folded in double and rounded once; bf16 terms by round-to-nearest-even): the block is bit-identical (tested).
-// ---------------------------------------------------------------------------------------------------------------------
-struct PackArgs {
-    const float* params;      // learner layout (actor part)
-    const float* bn;          // [2 layers][2 mean/var][64] of the actor
-    float* blob;              // [kActBlobFloats]
-    float eps, bound0, bound1;
-    float scale[5];
-};
-__device__ __forceinline__ uint16_t bf16_rne_bits(float x) {
-    const uint32_t u = __float_as_uint(x);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__global__ __launch_bounds__(256) void mr_actor_pack_kernel(const PackArgs A) {
-    __shared__ float w1f[64 * 5], b1f[64], w2f[64 * 64], b2f[64];
-    __shared__ double g2s[64];
-    const int tid = threadIdx.x;
-    constexpr int H = 64;
-    // fold: y = gamma (W x + b - mean) / sqrt(var + eps) + beta == W' x + b'   (double, rounded once; the per-feature gains are
-    // formed once -- a double divide and square root per ELEMENT of W2 made this kernel 14 us long)
-    for (int f = tid; f < H; f += 256) {
-        const double g1 = (double)A.params[A_G1 + f] / sqrt((double)A.bn[(0 * 2 + 1) * 64 + f] + (double)A.eps);
-        for (int k = 0; k < 5; ++k) w1f[f * 5 + k] = (float)((double)A.params[A_W1 + f * 5 + k] * g1);
-        b1f[f] = (float)(((double)A.params[A_B1 + f] - (double)A.bn[(0 * 2 + 0) * 64 + f]) * g1 + (double)A.params[A_BE1 + f]);
-        const double g2 = (double)A.params[A_G2 + f] / sqrt((double)A.bn[(1 * 2 + 1) * 64 + f] + (double)A.eps);
-        b2f[f] = (float)(((double)A.params[A_B2 + f] - (double)A.bn[(1 * 2 + 0) * 64 + f]) * g2 + (double)A.params[A_BE2 + f]);
-        g2s[f] = g2;
-    }
-    __syncthreads();
-    for (int o = tid; o < H * H; o += 256) w2f[o] = (float)((double)A.params[A_W2 + o] * g2s[o >> 6]);
-    for (int o = tid; o < kActBlobFloats; o += 256) A.blob[o] = 0.0f;
-    __syncthreads();
-    if (tid < 128) {
-        const int rt = tid >> 6, lane = tid & 63, f = 32 * rt + (lane & 31), h = lane >> 5;
-        for (int s = 0; s < 3; ++s) {
-            const int k = 2 * s + h;
-            A.blob[kActA1 + (rt * 3 + s) * 64 + lane] = k < 5 ? w1f[f * 5 + k] * A.scale[k] : 0.0f;
-        }
-        for (int q = 0; q < 32; ++q) A.blob[kActA2 + ((rt * 8 + q / 4) * 64 + lane) * 4 + (q % 4)] = w2f[f * H + act_kperm(q, h)];
-        uint16_t* bf = reinterpret_cast<uint16_t*>(A.blob + kActA2bf);
-        for (int s = 0; s < 4; ++s)
-            for (int jj = 0; jj < 8; ++jj) {
-                float r = w2f[f * H + act_kperm(8 * s + jj, h)];
-                for (int part = 0; part < 3; ++part) {
-                    const uint16_t t = bf16_rne_bits(r);
-                    bf[((((rt * 4 + s) * 3 + part) * 64 + lane) * 8) + jj] = t;
-                    r -= __uint_as_float((uint32_t)t << 16);
-                }
-            }
-    } else if (tid < 192) {
-        const int o = tid - 128, h = o >> 5, q = o & 31;
-        A.blob[kActC1 + h * 32 + q] = b1f[act_kperm(q, h)];
-        A.blob[kActC2 + h * 32 + q] = b2f[act_kperm(q, h)];
-        for (int oo = 0; oo < 2; ++oo) A.blob[kActW3 + (h * 2 + oo) * 32 + q] = A.params[A_W3 + oo * H + act_kperm(q, h)];
-    } else if (tid == 192) {
-        A.blob[kActTail + 0] = A.params[A_B3 + 0]; A.blob[kActTail + 1] = A.params[A_B3 + 1];
-        A.blob[kActTail + 2] = A.bound0; A.blob[kActTail + 3] = A.bound1;
     }
 }
 

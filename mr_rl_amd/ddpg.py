@@ -111,6 +111,28 @@ class ReplayBuffer:
         self.head = (self.head + B) % self.buffer_size
         self.count = min(self.count + B, self.buffer_size)
 
+    def sink(self, obs_scale=None, ended=None):
+        """The ring as a _lib.MrsimReplaySink for MRVecEnv.step(actor=..., replay=...): the step kernel stores its transitions
+        at the CURRENT head; call advance(n) after the launch.  ended: optional [2] device tensor (+= finished episodes' return
+        sum, count)."""
+        from . import _lib
+        sk = getattr(self, "_sink", None)
+        if sk is None:
+            sk = self._sink = _lib.MrsimReplaySink(self.s.data_ptr(), self.a.data_ptr(), self.r.data_ptr(), self.t.data_ptr(),
+                                                   self.s2.data_ptr(), None, self.buffer_size, 0)
+        sc = [1.0] * 5 if obs_scale is None else [float(x) for x in obs_scale]
+        for j in range(5):
+            sk.obs_scale[j] = sc[j]
+        sk.head = self.head
+        sk.ended2 = None if ended is None else ended.data_ptr()
+        return sk
+
+    def advance(self, n):
+        """n transitions were appended at the head by a kernel (sink())."""
+        B = min(int(n), self.buffer_size)
+        self.head = (self.head + B) % self.buffer_size
+        self.count = min(self.count + B, self.buffer_size)
+
     def sample_batch(self, batch_size):
         n = min(batch_size, self.count)
         idx = torch.randperm(self.count, device=self.s.device, generator=self.gen)[:n]
@@ -282,6 +304,7 @@ class DDPG:
         self._count_t = torch.zeros((), dtype=torch.float32, device=dev)    # ring fill, as the captured sampler reads it
         self.last_losses = None
         self.fused = None
+        self.fused_upload = True    # update(): the policy upload rides in the update's launch (False: a launch of its own; tests)
         if fused:
             if bn_mode != "reference":
                 raise ValueError("fused=True needs bn_mode='reference'")
@@ -349,17 +372,23 @@ class DDPG:
         (s, a, r, done, s2) instead of a ring sample (tests)."""
         if batch is None and self.buffer.size() < self.min_batch:
             return None
+        uploaded = False
         if self.fused is not None:
-            self.last_losses = self.fused.update(batch)     # one launch: the rows are drawn in the kernel
+            # one launch: the rows are drawn in the kernel, and when the behaviour policy is due for its refresh the same launch
+            # folds and packs the new actor into the policy's block (no mrsim_actor_pack_device launch: 9 us of a 62 us iteration)
+            pol = self.device_actor
+            uploaded = (self.fused_upload and pol is not None and len(pol.blobs) == 1
+                        and (self._updates + 1) % self.refresh_every == 0)
+            self.last_losses = self.fused.update(batch, pack_into=pol if uploaded else None)
         else:
             self._count_t.fill_(float(self.buffer.size()))
             self.last_losses = self._update_body(batch)
-        self._after_update()
+        self._after_update(uploaded)
         return self.last_losses
 
-    def _after_update(self):
+    def _after_update(self, uploaded=False):
         self._updates += 1
-        if self.device_actor is not None and self._updates % self.refresh_every == 0:
+        if self.device_actor is not None and self._updates % self.refresh_every == 0 and not uploaded:
             self.sync_policy()
 
     def sync_policy(self, policy=None, slot=None):
@@ -560,8 +589,9 @@ class DDPG:
         after a step, `state = next_state` is skipped -- the policy keeps seeing (and the ring keeps storing as `state`)
         the observation the episode was reset to.  observe: optional callback(step, obs_fed_to_the_policy) (tests).
         fused_bookkeeping: with the in-kernel actor on a HIP device, the step's replay add / state hand-over / finished-episode
-        sums are ONE launch (ReplayBuffer.add_step) instead of ~20 PyTorch kernels; "auto" uses it when it applies, False keeps
-        the PyTorch statements (the two are compared in tests/test_gpu_round5.py), True demands it."""
+        sums need no PyTorch kernels (~20 per step before): "auto" / True = the step kernel writes the transitions into the ring
+        itself (MrsimStepIO.replay), "add_step" = one launch of mrsim_replay_add_step after the step, False = the PyTorch
+        statements (the three are compared bit for bit in tests/test_gpu_round5.py); True demands the conditions."""
         env = self.env
         can_fuse = (self.device_actor is not None and env.device.type == "cuda" and env.cfg.auto_reset and not warmup_quirk
                     and env._actions_out is not None and not getattr(env, "_soa", False))
@@ -569,7 +599,8 @@ class DDPG:
             raise ValueError("fused_bookkeeping=True needs DDPG(device_actor=True), auto_reset, [N][5] observation rows, "
                              "MRVecEnv(track_actions=True), a HIP device and warmup_quirk=False")
         if fused_bookkeeping and can_fuse:
-            return self._train_fused_bookkeeping(total_steps, updates_per_step, log_every, observe)
+            return self._train_fused_bookkeeping(total_steps, updates_per_step, log_every, observe,
+                                                 in_step_kernel=fused_bookkeeping != "add_step")
         obs = env.reset().clone()
         # per-step (sum of the returns of the episodes that ended, their number) stay on the device: the loop never waits for the
         # host (the reference reads every reward on the host, RL/MR_ddpg.py:278-311); read back once per log line and at the end
@@ -611,19 +642,26 @@ class DDPG:
         rows = torch.stack(ended).cpu().tolist()
         return [sm / cnt for sm, cnt in rows if cnt > 0]          # mean return of the episodes that ended at each such step
 
-    def _train_fused_bookkeeping(self, total_steps, updates_per_step, log_every, observe):
-        """train() with two launches per env step besides the learner's: the step kernel (policy + noise + MR_Env.step) and
-        mrsim_replay_add_step (replay_buffer.add, `state = next_state`, the finished episodes' returns)."""
+    def _train_fused_bookkeeping(self, total_steps, updates_per_step, log_every, observe, in_step_kernel=True):
+        """train() without PyTorch kernels between the launches: the step kernel (policy + noise + MR_Env.step) stores the
+        transitions in the ring itself and sums the finished episodes' returns (in_step_kernel), or mrsim_replay_add_step does
+        after it (replay_buffer.add, `state = next_state`, the returns)."""
         env = self.env
-        obs = env.reset().reshape(env.num_envs, 5).clone()
+        obs = env.reset().reshape(env.num_envs, 5)
+        if not in_step_kernel:
+            obs = obs.clone()
         ended = torch.zeros((max(1, total_steps), 2), dtype=torch.float32, device=env.device)
         scale = None if self.obs_scale is None else [float(x) for x in self.obs_scale.cpu()]
         for k in range(total_steps):
             if observe is not None:
-                observe(k, obs)
-            env.step(actor=self.device_actor)
-            self.buffer.add_step(obs, env._actions_out, env.rew, env._done_u8, env._obs, env._final_obs, env.final_ret, scale,
-                                 ended=ended[k])
+                observe(k, obs)     # (in_step_kernel: the env's own observation buffer -- what the kernel's policy is evaluated on)
+            if in_step_kernel:
+                env.step(actor=self.device_actor, replay=self.buffer.sink(scale, ended[k]))
+                self.buffer.advance(env.num_envs)
+            else:
+                env.step(actor=self.device_actor)
+                self.buffer.add_step(obs, env._actions_out, env.rew, env._done_u8, env._obs, env._final_obs, env.final_ret, scale,
+                                     ended=ended[k])
             for _ in range(updates_per_step):
                 self.update()
             if log_every and (k + 1) % log_every == 0:

@@ -84,8 +84,22 @@ class FusedLearner:
     def export_to_modules(self):
         """nothing to do: the modules alias the learner's vectors"""
 
-    def update(self, batch=None, n=1):
-        """n consecutive updates in ONE launch (each draws its own rows when batch is None)"""
+    def update(self, batch=None, n=1, pack_into=None):
+        """n consecutive updates in ONE launch (each draws its own rows when batch is None).  pack_into: a DeviceActor of one
+        parameter block -- after the last update the online actor is folded and packed into that block by the same launch
+        (MrsimDdpgLearner.actor_blob; the bits of DeviceActor.load_from_learner)."""
+        if pack_into is None:
+            return self._update(batch, n)
+        st = self.struct
+        st.actor_blob = pack_into.blobs[0].data_ptr()
+        for j, x in enumerate(pack_into.weights["obs_scale"]):
+            st.actor_obs_scale[j] = float(x)
+        try:
+            return self._update(batch, n)
+        finally:
+            st.actor_blob = None
+
+    def _update(self, batch=None, n=1):
         import torch
         ag = self.agent
         buf = ag.buffer

@@ -205,7 +205,7 @@ class MRVecEnv:
         self.step_idx += 1
         return self.obs
 
-    def _step_io(self, act_t, actor=None):
+    def _step_io(self, act_t, actor=None, replay=None):
         io = _lib.MrsimStepIO(
             self._p(act_t), self._p(self._actions_out), self._p(self.goal_table), self._p(self._obs),
             self._p(self.rew), self._p(self._done_u8), self._p(self._state_prime), self._p(self._final_obs),
@@ -213,17 +213,22 @@ class MRVecEnv:
         if actor is not None:
             self._actor_struct = actor.struct(self.num_envs)   # keeps the ctypes block alive through the call
             io.actor = C.pointer(self._actor_struct)
+        if replay is not None:
+            io.replay = C.pointer(replay)     # (the caller keeps the struct alive: ReplayBuffer.sink)
         return io
 
-    def step(self, actions=None, actor=None):
+    def step(self, actions=None, actor=None, replay=None):
         """MR_Env.step for all envs.  actions: [N,2] float32 device tensor {f_t, alpha_t}; or actor=DeviceActor: the action
         is actor.predict(obs) + actor_noise() evaluated inside the step kernel on the env's current observation
         (RL/MR_ddpg.py:277-278 in one launch); or neither, to draw the uniform random policy in-kernel
-        (cfg.policy_low/high)."""
+        (cfg.policy_low/high).  replay (with actor): a _lib.MrsimReplaySink (ddpg.ReplayBuffer.sink) -- the step kernel writes
+        the transitions into that ring itself (RL/MR_ddpg.py:278-282 without a launch of its own)."""
         torch = _torch()
         act_t = None
         if actions is not None and actor is not None:
             raise ValueError("step: pass actions or actor, not both")
+        if replay is not None and actor is None:
+            raise ValueError("step: replay needs actor (the kernel stores the observation its own policy saw)")
         if actions is not None:
             act_t = actions if (torch.is_tensor(actions) and actions.dtype == torch.float32 and
                                 actions.device == self.device and actions.is_contiguous()) else \
@@ -233,7 +238,7 @@ class MRVecEnv:
             self.last_action = act_t
         elif self._actions_out is not None:
             self.last_action = self._actions_out
-        io = self._step_io(act_t, actor)
+        io = self._step_io(act_t, actor, replay)
         rc = self._L.mrsim_step(C.byref(self._params), self.num_envs, self.env_id0, C.byref(self._st), C.byref(io),
                                 self.seed_value, self.step_idx, self._stream())
         _lib.check(rc, "mrsim_step")

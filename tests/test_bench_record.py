@@ -75,7 +75,8 @@ def test_committed_bench_line_carries_this_rounds_legs():
     assert b["4096"]["multi_workgroup"]["transitions_per_s"] > 10 * b["64"]["single_workgroup"]["transitions_per_s"]
     rows = {(r["envs"], r["bookkeeping"]): r for r in d["learner"]["reference_shaped_loop"]["rows"]}   # DDPG.train's iteration
     assert rows[(256, "one launch")]["us_per_iteration"] < 0.8 * rows[(256, "pytorch statements")]["us_per_iteration"]
-    assert rows[(1, "one launch")]["iterations_per_s"] > 7200          # one env, learner included, against the reference's env alone
+    assert rows[(1, "in the step kernel")]["iterations_per_s"] > 7200   # one env, learner included, against the reference's env alone
+    assert rows[(256, "in the step kernel")]["us_per_iteration"] <= 1.05 * rows[(256, "one launch")]["us_per_iteration"]
 
 
 def test_committed_mismatched_line_has_its_own_roofline_and_counters():

@@ -383,7 +383,8 @@ def test_fused_velocity_matches_scipy_numpy_over_chunk_boundaries(T, n, N):
 @pytest.mark.parametrize("fused_learner", [False, True])
 @pytest.mark.parametrize("n_envs,ring", [(256, 10000), (192, 1000), (3000, 2048)])
 def test_fused_step_bookkeeping_equals_the_pytorch_statements(n_envs, ring, fused_learner):
-    """DDPG.train with fused_bookkeeping (replay add + `state = next_state` + finished-episode sums in ONE launch) against the
+    """DDPG.train with fused_bookkeeping -- the step kernel stores the transitions in the ring itself (MrsimStepIO.replay), or ONE
+    launch of mrsim_replay_add_step does after the step (replay add + `state = next_state` + finished-episode sums) -- against the
     same loop written as PyTorch statements: the ring (all five arrays, head, fill), every network parameter after the updates
     and the device policy's block are BIT-identical; the per-step mean returns agree to float32 summation order.  Rings that
     wrap (192 envs into 1000 slots) and rings smaller than one step (3000 envs into 2048 slots: the last 2048 stay)."""
@@ -394,7 +395,7 @@ def test_fused_step_bookkeeping_equals_the_pytorch_statements(n_envs, ring, fuse
     cfg = MRConfig(noise_var=0.1, reward_mode="goal", auto_reset=True, init_low=(20.0, 20.0), init_high=(30.0, 30.0),
                    min_dist2goal=25.0)
     out = []
-    for fb in (False, True):
+    for fb in (False, "add_step", True):
         env = MRVecEnv(n_envs, cfg=cfg, seed=3, track_actions=True)
         agent = DDPG(env, seed=5, obs_scale=scale, device_actor=True, buffer_size=ring, fused=fused_learner)
         seen = []
@@ -405,17 +406,18 @@ def test_fused_step_bookkeeping_equals_the_pytorch_statements(n_envs, ring, fuse
                     "params": [p.detach().clone() for m in (agent.actor, agent.critic, agent.actor_t, agent.critic_t)
                                for p in m.parameters()] if not fused_learner else [agent.fused.online.clone(), agent.fused.target.clone()],
                     "blob": agent.device_actor.blob.clone(), "seen": seen, "obs": env.obs.clone()})
-    a, b = out
-    assert a["head"] == b["head"] and a["count"] == b["count"] == min(ring, 70 * n_envs)
-    for x, y in zip(a["ring"], b["ring"]):
-        assert torch.equal(x, y)
-    for x, y in zip(a["seen"], b["seen"]):
-        assert torch.equal(x, y)                       # the observation handed to the policy at every step
-    for x, y in zip(a["params"], b["params"]):
-        assert torch.equal(x, y)
-    assert torch.equal(a["blob"], b["blob"]) and torch.equal(a["obs"], b["obs"])
-    assert len(a["rets"]) == len(b["rets"]) > 0
-    np.testing.assert_allclose(a["rets"], b["rets"], rtol=2e-6, atol=1e-4)
+    a = out[0]
+    for b in out[1:]:
+        assert a["head"] == b["head"] and a["count"] == b["count"] == min(ring, 70 * n_envs)
+        for x, y in zip(a["ring"], b["ring"]):
+            assert torch.equal(x, y)
+        for x, y in zip(a["seen"], b["seen"]):
+            assert torch.equal(x, y)                       # the observation handed to the policy at every step
+        for x, y in zip(a["params"], b["params"]):
+            assert torch.equal(x, y)
+        assert torch.equal(a["blob"], b["blob"]) and torch.equal(a["obs"], b["obs"])
+        assert len(a["rets"]) == len(b["rets"]) > 0
+        np.testing.assert_allclose(a["rets"], b["rets"], rtol=2e-6, atol=1e-4)
 
 
 @pytest.mark.gpu
@@ -435,3 +437,50 @@ def test_replay_add_step_rejects_bad_arguments_and_demands_its_conditions():
     agent = DDPG(env, seed=0, device_actor=True)
     with pytest.raises(ValueError, match="fused_bookkeeping=True needs"):
         agent.train(2, fused_bookkeeping=True)
+    # the step's own sink: needs the in-kernel actor, a valid head, all five arrays
+    env2 = MRVecEnv(64, cfg=MRConfig(auto_reset=True), seed=0, track_actions=True)
+    env2.reset()
+    sk = agent.buffer.sink()
+    with pytest.raises(ValueError, match="replay needs actor"):
+        env2.step(replay=sk)
+    sk.head = agent.buffer.buffer_size
+    with pytest.raises(_lib.MrsimError):
+        env2.step(actor=agent.device_actor, replay=sk)
+    sk.head, sk.s2 = 0, None
+    with pytest.raises(_lib.MrsimError):
+        env2.step(actor=agent.device_actor, replay=sk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [64, 256, 1024])
+def test_policy_upload_in_the_update_launch_equals_the_separate_launch(batch):
+    """MrsimDdpgLearner.actor_blob: the update's launch folds and packs the new online actor into the behaviour policy's block (the
+    tail of the single-workgroup kernel; a launch behind the multi-workgroup form) -- against mrsim_actor_pack_device as a launch of
+    its own after every update, and against the library's HOST packer on the final network: the block, the ring and every
+    parameter bit-identical after 60 steps of DDPG.train."""
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv
+    from mr_rl_amd.actor import DeviceActor
+    from mr_rl_amd.ddpg import DDPG
+    scale = (0.01, 0.01, 0.01, 0.01, 1.0)
+    cfg = MRConfig(noise_var=0.1, reward_mode="goal", auto_reset=True, init_low=(20.0, 20.0), init_high=(30.0, 30.0),
+                   min_dist2goal=25.0)
+    out = []
+    for upload in (True, False):
+        env = MRVecEnv(512, cfg=cfg, seed=3, track_actions=True)
+        agent = DDPG(env, seed=5, obs_scale=scale, device_actor=True, buffer_size=8192, fused=True, min_batch=batch)
+        agent.fused_upload = upload
+        w0 = agent.device_actor.blob.clone()
+        agent.train(60)
+        env.check_status()
+        assert not torch.equal(w0, agent.device_actor.blob)
+        b = agent.buffer
+        out.append({"blob": agent.device_actor.blob.clone(), "online": agent.fused.online.clone(), "target": agent.fused.target.clone(),
+                    "ring": [t.clone() for t in (b.s, b.a, b.r, b.t, b.s2)]})
+        agent.actor.eval()
+        host = DeviceActor.from_module(agent.actor, obs_scale=scale, device="cuda", ou=False)     # mrsim_actor_pack_host
+        assert torch.equal(host.blob, agent.device_actor.blob)
+    a, b = out
+    assert torch.equal(a["blob"], b["blob"]) and torch.equal(a["online"], b["online"]) and torch.equal(a["target"], b["target"])
+    for x, y in zip(a["ring"], b["ring"]):
+        assert torch.equal(x, y)

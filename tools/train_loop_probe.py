@@ -17,12 +17,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, nargs="+", default=[1, 256, 4096])
     ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--forms", nargs="+", default=["pytorch", "add_step", "step"], help="bookkeeping forms to run")
+    ap.add_argument("--learners", nargs="+", default=["eager", "fused"])
     a = ap.parse_args()
     cfg = MRConfig(noise_var=0.1, reward_mode="goal", auto_reset=True, init_low=(20.0, 20.0), init_high=(30.0, 30.0), min_dist2goal=25.0)
     rows = []
     for n in a.envs:
-        for fused_learner in (False, True):
-            for fb in (False, True):
+        for fused_learner in [x == "fused" for x in a.learners]:
+            for fb in [{"pytorch": False, "add_step": "add_step", "step": True}[x] for x in a.forms]:
                 env = MRVecEnv(n, cfg=cfg, seed=0, track_actions=True)
                 agent = DDPG(env, seed=0, obs_scale=(0.01, 0.01, 0.01, 0.01, 1.0), device_actor=True, fused=fused_learner,
                              buffer_size=max(10000, 4 * n))
@@ -33,7 +35,7 @@ def main():
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 rows.append({"envs": n, "learner": "one kernel" if fused_learner else "eager PyTorch",
-                             "bookkeeping": "one launch" if fb else "PyTorch statements", "us_per_iteration": round(dt / a.steps * 1e6, 1),
+                             "bookkeeping": {False: "PyTorch statements", "add_step": "one launch (mrsim_replay_add_step)", True: "in the step kernel"}[fb], "us_per_iteration": round(dt / a.steps * 1e6, 1),
                              "iterations_per_s": round(a.steps / dt), "env_steps_per_s": round(a.steps * n / dt)})
                 print(json.dumps(rows[-1]), flush=True)
                 agent.close()
