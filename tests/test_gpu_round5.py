@@ -96,7 +96,7 @@ def test_library_default_law_is_collapsed_everywhere():
     assert p.noise_law == _lib.LAW_COLLAPSED
     assert MRConfig().noise_law == "collapsed" and MRConfig().to_params().noise_law == _lib.LAW_COLLAPSED
     assert orc_params_from_cfg(MRConfig()).noise_law == O.LAW_COLLAPSED
-    assert C.sizeof(_lib.MrsimStepIO) == 104
+    assert C.sizeof(_lib.MrsimStepIO) == 112
 
 
 # ---------------------------------------------------------------------------
