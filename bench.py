@@ -719,12 +719,15 @@ def measure_learner(args, n_local, dev, seed, streams):
                       (torch.rand(n, device=dev, generator=g) < 0.02).float(), s + 0.01 * torch.randn(n, 5, device=dev, generator=g))
         return ag
 
-    def rate(f, n):
+    def rate(f, n, chunk=256):
+        # (bounded launch queue, as everywhere in this script: thousands of launches enqueued without a wait leave the runtime a
+        # backlog whose retirement the later launch calls pay for -- the same leg read 14 k and 23 k updates/s on two boxes)
         f(10)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        f(n)
-        torch.cuda.synchronize(dev)
+        for c0 in range(0, n, chunk):
+            f(min(chunk, n - c0))
+            torch.cuda.synchronize(dev)
         return n / (time.perf_counter() - t0)
     ag = filled()
     ups = {"eager_pytorch": rate(lambda n: [ag.update() for _ in range(n)], 100)}
