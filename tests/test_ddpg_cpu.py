@@ -25,6 +25,23 @@ def test_replay_ring_semantics():
     assert rb.size() == 0
 
 
+def test_replay_sink_bookkeeping_follows_add():
+    """ReplayBuffer.sink() / advance(): the struct a step kernel writes through names the ring's arrays and its CURRENT head, and
+    advance(n) moves head / fill exactly as add() of n rows does (host logic only: nothing is launched)."""
+    a, b = ReplayBuffer(10, device="cpu"), ReplayBuffer(10, device="cpu")
+    for n in (3, 3, 7, 12, 1):
+        sk = a.sink(obs_scale=(0.5, 1, 1, 1, 2))
+        assert (sk.s, sk.a, sk.r, sk.done, sk.s2) == tuple(t.data_ptr() for t in (a.s, a.a, a.r, a.t, a.s2))
+        assert sk.capacity == 10 and sk.head == a.head == b.head and not sk.ended2
+        assert list(sk.obs_scale) == [0.5, 1.0, 1.0, 1.0, 2.0]
+        a.advance(n)
+        z = torch.zeros(n, 5)
+        b.add(z, torch.zeros(n, 2), torch.zeros(n), torch.zeros(n), z)
+        assert (a.head, a.count) == (b.head, b.count)
+    ended = torch.zeros(2)
+    assert a.sink(ended=ended).ended2 == ended.data_ptr() and list(a.sink().obs_scale) == [1.0] * 5
+
+
 def test_ou_noise_statistics():
     """x' = x + theta(0 - x)dt + sigma sqrt(dt) N: stationary std = sigma sqrt(dt / (2 theta dt - theta^2 dt^2))."""
     ou = OUNoise((20000, 2), device="cpu", seed=1)
