@@ -484,3 +484,23 @@ def test_policy_upload_in_the_update_launch_equals_the_separate_launch(batch):
     assert torch.equal(a["blob"], b["blob"]) and torch.equal(a["online"], b["online"]) and torch.equal(a["target"], b["target"])
     for x, y in zip(a["ring"], b["ring"]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_the_reference_shaped_loop_learns_the_one_step_goal_task():
+    """DDPG.train as the script runs it (RL/MR_ddpg.py:262-311: one env step, one replay add, ONE 64-row update per iteration; the
+    policy inside the step kernel is the network that update has just produced) on task "C" of tools/learning_check.py with 64 envs in
+    lockstep: returns start at the untrained policy's level and reach >= 60 (of +100) on EVERY one of four seeds within 4 000
+    iterations (profiles/r05/train_loop_learning.txt: 72-91 by the second to fourth tenth; DDPG drifts afterwards on some seeds, so the
+    criterion is the best tenth, and that it comes after the first)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_loop_learning", os.path.join(root, "tools", "train_loop_learning.py"))
+    tl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tl)
+    for seed in range(4):
+        agent, rets = tl.run(64, 4000, seed, fused=True)
+        assert agent._updates == 4000 and len(rets) > 3000 and np.isfinite(rets).all()
+        k = len(rets) // 10
+        tenths = [float(np.mean(rets[i:i + k])) for i in range(0, 10 * k, k)]
+        assert tenths[0] < 45.0 and max(tenths[1:]) >= 60.0 and max(tenths[1:]) > tenths[0] + 30.0, (seed, tenths)
