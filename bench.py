@@ -484,15 +484,16 @@ class RolloutRegion:
         self.g.finish()  # outstanding async all-gathers belong to the timed region
         torch.cuda.synchronize(self.dev)
         t2 = time.perf_counter()
+        el = t2 - t0         # this rank's clock stops when ITS K steps (and its collectives) are complete on its device ...
         if self.world > 1:
-            self.barrier()   # one rank: the synchronize above IS the closing barrier + synchronize (a second device-wide
-        el = time.perf_counter() - t0   # synchronize on the idle GPU costs ~10 us: a fifth of a 20-step region's GPU work)
-        if gc_was_on:
+            self.barrier()   # ... the closing barrier + synchronize follows; the job's time is the MAX of the ranks' clocks (below),
+        t3 = time.perf_counter()   # all started together by the opening barrier.  (A NCCL barrier is itself a collective of tens of
+        if gc_was_on:              # microseconds: inside the clock it would be most of a 20-step region at N = 8.)
             gc.enable()
         # where this rank's wall time went: host enqueue (launch argument blocks, event records, collectives), waiting for
         # the GPU, closing barrier -- a region of one short launch group is mostly the first and the last
         self.last_phases_us = {"enqueue": round((t1 - t0) * 1e6, 1), "wait_gpu": round((t2 - t1) * 1e6, 1),
-                               "closing_barrier": round((t0 + el - t2) * 1e6, 1)}
+                               "closing_barrier_untimed": round((t3 - t2) * 1e6, 1)}
         self.last_per_rank_s = [el]
         if self.world > 1:
             cdev = self.dev if self.backend == "nccl" else "cpu"
@@ -1284,9 +1285,9 @@ def main():
         run(K)
         gatherer.finish()
         torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0    # this rank's clock; the job's time is the MAX over ranks (below)
         if world > 1:
-            barrier()    # (one rank: the synchronize above closes the region)
-        el = time.perf_counter() - t0
+            barrier()    # closing barrier + synchronize, outside the ranks' clocks (see RolloutRegion.timed)
         gc.enable()
         launches = n_launches[0] - l0
         per_rank_s = [el]
