@@ -910,7 +910,8 @@ def measure_other_law(args, cfg, n_local, env_id0, world, dev, seed, streams, go
 def measure_facade(seed, episodes=40):
     """The literal drop-in call: mr_rl_amd.MR_Env.step() for ONE env, once per Python loop iteration, as utils.run_sim
     (utils.py:51-54) and the DDPG loop (RL/MR_ddpg.py:270-278) call the reference's MR_env.MR_Env.step (MR_env.py:70-98).
-    One launch + one stream wait per step on a pinned host record (mr_rl_amd/env.py).  `value` includes the reset of every
+    One launch + one wait per step on a pinned host record (mr_rl_amd/env.py; the wait polls a word of the record the kernel stores
+    after its last output).  `value` includes the reset of every
     51-step episode (the DDPG loop's shape); `phases_us` splits a step into the launch call, the wait and the Python around
     them; the reference's own rate is quoted from the committed measurement (the reference never travels to the GPU box)."""
     import ctypes as C
@@ -936,23 +937,33 @@ def measure_facade(seed, episodes=40):
     el_rs = time.perf_counter() - t0
     # where a step goes: the same two C calls the facade makes, timed apart
     L = env._L
-    t_launch = t_wait = 0.0
+    t_launch = t_wait = t_sync = 0.0
     for k in range(500):
+        env._io.done_value = word = 1000 + k
         t1 = time.perf_counter()
         L.mrsim_step(env._pp, 1, env.env_id, C.byref(env._st), C.byref(env._io), env.seed_value, env.step_idx + k, None)
         t2 = time.perf_counter()
-        L.mrsim_stream_synchronize(None)
+        L.mrsim_host_wait_word(env._word_host, word, 2000000)      # what the facade waits on: the record's own step word
         t3 = time.perf_counter()
         t_launch += t2 - t1; t_wait += t3 - t2
     env.step_idx += 500
+    for k in range(500):       # the same with a stream wait instead (round 5's first form): what the kernel's completion signal costs
+        env._io.done_value = 2000 + k
+        L.mrsim_step(env._pp, 1, env.env_id, C.byref(env._st), C.byref(env._io), env.seed_value, env.step_idx + k, None)
+        t2 = time.perf_counter()
+        L.mrsim_stream_synchronize(None)
+        t_sync += time.perf_counter() - t2
+    env.step_idx += 500
+    env._word = 2499
     out = {"what": "mr_rl_amd.MR_Env.step(action) for one env, one call per Python iteration (the drop-in for MR_env.py:70-98): one "
                    "launch + one wait per step on a pinned host record, no copy calls",
            "value": n / el, "unit": "MR_Env.step calls/s (one env; the reset of every 51-step episode included)",
            "us_per_step": round(el / n * 1e6, 2), "steps": n,
            "run_sim_shape": {"value": 1000 / el_rs, "us_per_step": round(el_rs / 1000 * 1e6, 2),
                              "what": "1000 consecutive steps without resets (utils.run_sim ignores done)"},
-           "phases_us": {"mrsim_step_call": round(t_launch / 500 * 1e6, 2), "mrsim_stream_synchronize": round(t_wait / 500 * 1e6, 2),
-                         "python_around_them": round(el_rs / 1000 * 1e6 - (t_launch + t_wait) / 500 * 1e6, 2)}}
+           "phases_us": {"mrsim_step_call": round(t_launch / 500 * 1e6, 2), "mrsim_host_wait_word": round(t_wait / 500 * 1e6, 2),
+                         "python_around_them": round(el_rs / 1000 * 1e6 - (t_launch + t_wait) / 500 * 1e6, 2)},
+           "wait_with_mrsim_stream_synchronize_us": round(t_sync / 500 * 1e6, 2)}
     env.close()
     f = newest_profile("ref_python_baseline.json")
     if f is not None:

@@ -49,7 +49,8 @@ enum {
     MRSIM_ENODEVICE = -2, /* no HIP device / wrong architecture                           */
     MRSIM_ELAUNCH = -3,   /* hipLaunchKernel / HIP runtime error                          */
     MRSIM_EALIGN = -4,    /* a buffer is not 16-byte aligned                              */
-    MRSIM_ERANGE = -5     /* n or env ids exceed 2^32                                     */
+    MRSIM_ERANGE = -5,    /* n or env ids exceed 2^32                                     */
+    MRSIM_ETIMEOUT = -6   /* mrsim_host_wait_word: the word did not take the value in time */
 };
 
 enum { MRSIM_INT_RK45 = 0, MRSIM_INT_EULER = 1, MRSIM_INT_RK4 = 2 };
@@ -238,6 +239,13 @@ typedef struct MrsimStepIO {
                              /*   that integrates it (MR_simulator.py:42-43); fixed-step      */
                              /*   modes: substeps                                             */
     const MrsimReplaySink* replay; /* optional (HOST pointer; ABI 5): needs `actor`             */
+    int32_t* done_word;      /* optional (ABI 5; launches of ONE workgroup only, n <= 256):    */
+    int32_t done_value;      /*   after every output of the launch has been written and made   */
+    int32_t reserved0;       /*   visible at system scope, done_value is stored there (release) */
+                             /*   -- a word of mrsim_host_alloc memory the host polls with     */
+                             /*   mrsim_host_wait_word instead of waiting for the stream: a    */
+                             /*   kernel's completion signal arrives microseconds after its    */
+                             /*   last store (the one-env facade's step is that wait)           */
 } MrsimStepIO;
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -450,6 +458,11 @@ int mrsim_host_alloc(int64_t bytes, void** host_ptr_out, void** dev_ptr_out);
 int mrsim_host_free(void* host_ptr);
 /* hipStreamSynchronize(stream) for callers that bind no HIP runtime of their own (ctypes). */
 int mrsim_stream_synchronize(void* stream);
+/* Spin (on the calling host thread, no HIP call) until *host_word == value: the host side of MrsimStepIO.done_word.  host_word is
+ * the HOST address of a word in mrsim_host_alloc memory.  Returns MRSIM_OK, or MRSIM_ETIMEOUT after timeout_us microseconds (the
+ * launch is then still in flight or has failed: mrsim_stream_synchronize tells which).  Everything the launch wrote before the
+ * word is visible to the caller on return (acquire). */
+int mrsim_host_wait_word(const int32_t* host_word, int32_t value, int64_t timeout_us);
 
 /* Number of HIP devices visible (0 without a GPU); fills name_host (may be NULL). */
 int mrsim_device_count(void);

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmrsim.so")
 
-OK, EINVAL, ENODEVICE, ELAUNCH, EALIGN, ERANGE = 0, -1, -2, -3, -4, -5
+OK, EINVAL, ENODEVICE, ELAUNCH, EALIGN, ERANGE, ETIMEOUT = 0, -1, -2, -3, -4, -5, -6
 INT_RK45, INT_EULER, INT_RK4 = 0, 1, 2
 REW_CONSTANT10, REW_GOAL = 0, 1
 OBS_AOS, OBS_SOA = 0, 1
@@ -30,7 +30,7 @@ PRODUCT_SYMBOLS = (
     "mrsim_device_count", "mrsim_device_name",
     "mrsim_actor_fold_bn_host", "mrsim_actor_pack_host", "mrsim_actor_forward", "mrsim_ddpg_update",
     "mrsim_replay_push", "mrsim_replay_add_step", "mrsim_actor_pack_device",
-    "mrsim_host_alloc", "mrsim_host_free", "mrsim_stream_synchronize",
+    "mrsim_host_alloc", "mrsim_host_wait_word", "mrsim_host_free", "mrsim_stream_synchronize",
 )
 # include/mrsim_bench.h: measurement and test aids (bench.py, tools/, tests/); nothing in mr_rl_amd's product path calls them
 BENCH_SYMBOLS = (
@@ -90,7 +90,7 @@ class MrsimStepIO(C.Structure):
         ("obs", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("state_prime", C.c_void_p),
         ("final_obs", C.c_void_p), ("final_ret", C.c_void_p), ("final_len", C.c_void_p),
         ("status", C.c_void_p), ("actor", C.POINTER(MrsimActor)), ("attempts", C.c_void_p),
-        ("replay", C.POINTER(MrsimReplaySink)),
+        ("replay", C.POINTER(MrsimReplaySink)), ("done_word", C.c_void_p), ("done_value", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -160,6 +160,7 @@ def load(path):
     L.mrsim_host_alloc.argtypes = [i64, C.POINTER(vp), C.POINTER(vp)]
     L.mrsim_host_free.argtypes = [vp]
     L.mrsim_stream_synchronize.argtypes = [vp]
+    L.mrsim_host_wait_word.argtypes = [vp, i32, i64]
     L.mrsim_device_count.restype = C.c_int
     L.mrsim_device_name.argtypes = [C.c_int, C.c_char_p, i32]
     for name in SYMBOLS:
@@ -169,7 +170,7 @@ def load(path):
         raise ImportError(f"{path}: ABI {L.mrsim_abi_version()} != binding ABI {ABI_VERSION}")
     assert C.sizeof(MrsimParams) == 8 * 6 + 8 * 18 + 4 * 12 + 8
     assert C.sizeof(MrsimRolloutIO) == 8 + 8 * 11 + 8 + 4 + 4 + 8
-    assert C.sizeof(MrsimStepIO) == 8 * 14 and C.sizeof(MrsimReplaySink) == 8 * 6 + 4 * 8
+    assert C.sizeof(MrsimStepIO) == 8 * 16 and C.sizeof(MrsimReplaySink) == 8 * 6 + 4 * 8
     assert C.sizeof(MrsimDdpgLearner) == 144
     assert C.sizeof(MrsimActor) == 40 and C.sizeof(MrsimActorWeights) == 48 + 28 + 4
     return L

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -88,6 +89,8 @@ struct IOArgs {
     int32_t* status;
     int32_t* attempts;
     ReplaySinkArgs rp;
+    int32_t* done_word;      // one-workgroup launches: done_value is stored here after every output (system-scope release)
+    int32_t done_value;
 };
 
 // ---------------------------------------------------------------------------
@@ -209,6 +212,11 @@ __global__ __launch_bounds__(kBlock) void mr_step_kernel(const KParams P, const 
                 for (int r = q; r < nvalid; ++r) dst[r] = s_obs[r];
             }
         }
+    }
+    if (io.done_word != nullptr) {    // (uniform; the launcher admits it for one-workgroup grids only)
+        __threadfence_system();       // this lane's stores, visible to the host ...
+        __syncthreads();              // ... every lane's ...
+        if (threadIdx.x == 0) __hip_atomic_store(io.done_word, io.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1146,8 +1154,9 @@ static int step_impl(const MrsimParams* p, int64_t n, uint32_t env_id0, const Mr
                             n > q->capacity ? (int32_t)(n - q->capacity) : 0,
                             {q->obs_scale[0], q->obs_scale[1], q->obs_scale[2], q->obs_scale[3], q->obs_scale[4]}};
     }
+    if (io->done_word != nullptr && n > kBlock) return MRSIM_EINVAL;   // (one workgroup: its last barrier orders every output)
     const IOArgs IO{io->actions, io->actions_out, io->goal_table, io->obs, io->rew, io->done, io->state_prime,
-                    io->final_obs, io->final_ret, io->final_len, io->status, io->attempts, RP};
+                    io->final_obs, io->final_ret, io->final_len, io->status, io->attempts, RP, io->done_word, io->done_value};
     K.flags |= (io->actions ? kFActions : 0u) | (io->goal_table ? kFGoalTable : 0u) |
                (io->actions_out ? kFOutActions : 0u) | (io->state_prime ? kFOutStatePrime : 0u) |
                (io->final_obs ? kFOutFinalObs : 0u) | (io->final_ret ? kFOutFinalRet : 0u) |
@@ -1183,6 +1192,7 @@ const char* mrsim_strerror(int code) {
         case MRSIM_ELAUNCH: return "HIP launch/runtime error";
         case MRSIM_EALIGN: return "buffer not 16-byte aligned";
         case MRSIM_ERANGE: return "n / env ids exceed 2^32";
+        case MRSIM_ETIMEOUT: return "timed out waiting for a host word";
         default: return "unknown error";
     }
 }
@@ -1525,7 +1535,7 @@ int mrsim_ddpg_update(const MrsimDdpgLearner* Lr, int32_t batch, int32_t n_updat
                       const float* s2, const int32_t* idx, int32_t ring_count, uint64_t seed, uint64_t draw_counter,
                       int32_t* idx_out, float* losses_out, void* stream) {
     static_assert(MRSIM_DDPG_PARAMS == learner::kParams && MRSIM_DDPG_MAX_BATCH == learner::kMaxBatch, "mrsim.h / mrsim_learner.h");
-    static_assert(sizeof(MrsimDdpgLearner) == 144 && sizeof(MrsimReplaySink) == 80 && sizeof(MrsimStepIO) == 112, "mrsim.h / mr_rl_amd/_lib.py");
+    static_assert(sizeof(MrsimDdpgLearner) == 144 && sizeof(MrsimReplaySink) == 80 && sizeof(MrsimStepIO) == 128, "mrsim.h / mr_rl_amd/_lib.py");
     if (Lr == nullptr || Lr->online == nullptr || Lr->target == nullptr || Lr->adam_m == nullptr || Lr->adam_v == nullptr ||
         Lr->grad_scratch == nullptr || Lr->steps == nullptr || Lr->bn_stats == nullptr || s == nullptr || a == nullptr ||
         r == nullptr || done == nullptr || s2 == nullptr)
@@ -1776,6 +1786,19 @@ int mrsim_host_alloc(int64_t bytes, void** host_ptr_out, void** dev_ptr_out) {
 int mrsim_host_free(void* host_ptr) {
     if (host_ptr == nullptr) return MRSIM_EINVAL;
     return hipHostFree(host_ptr) == hipSuccess ? MRSIM_OK : MRSIM_ELAUNCH;
+}
+
+int mrsim_host_wait_word(const int32_t* host_word, int32_t value, int64_t timeout_us) {
+    if (host_word == nullptr || timeout_us < 0) return MRSIM_EINVAL;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int k = 0; k < 256; ++k) {
+            if (__atomic_load_n(host_word, __ATOMIC_ACQUIRE) == value) return MRSIM_OK;
+            __builtin_ia32_pause();
+        }
+        if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_us)
+            return __atomic_load_n(host_word, __ATOMIC_ACQUIRE) == value ? MRSIM_OK : MRSIM_ETIMEOUT;
+    }
 }
 
 int mrsim_stream_synchronize(void* stream) {

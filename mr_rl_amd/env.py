@@ -49,7 +49,7 @@ class _HostRecord:
     mrsim_reset and the reset's start position.  Every array starts at a 16-byte boundary (include/mrsim.h: alignment)."""
     FIELDS = (("pos", 0, np.float64, 2), ("aux", 16, np.float32, 4), ("ep_ret", 32, np.float32, 1), ("action", 48, np.float32, 2),
               ("obs", 64, np.float32, 5), ("rew", 96, np.float32, 1), ("done", 100, np.uint8, 1), ("state_prime", 112, np.float32, 2),
-              ("status", 128, np.int32, 1), ("init_xy", 144, np.float64, 2))
+              ("status", 128, np.int32, 1), ("init_xy", 144, np.float64, 2), ("step_word", 160, np.int32, 1))
     SIZE = 192
 
     def __init__(self, L):
@@ -106,6 +106,9 @@ class MR_Env:
         self._st = _lib.MrsimState(r.ptr("pos"), r.ptr("aux"), r.ptr("ep_ret"))
         self._io = _lib.MrsimStepIO(r.ptr("action"), None, None, r.ptr("obs"), r.ptr("rew"), r.ptr("done"), r.ptr("state_prime"),
                                     None, None, None, r.ptr("status"))
+        self._io.done_word = r.ptr("step_word").value
+        self._word_host = C.c_void_p(r.host + 160)
+        self._word = 0
         self._prev_mismatched = False   # what Simulator.is_mismatched was before the latest reset (MR_env.py:181-183)
         self._params = None
         self._refresh_params()
@@ -141,8 +144,14 @@ class MR_Env:
         t = self._torch
         return t.cuda.device(self._dev_index) if t.cuda.current_device() != self._dev_index else _NULL_CTX
 
-    def _wait(self, what):
-        _lib.check(self._L.mrsim_stream_synchronize(None), what)
+    def _wait(self, what, word=None):
+        """word: the value the step kernel stores into the record's step_word after its last output (MrsimStepIO.done_word) -- the
+        host polls the record itself (mrsim_host_wait_word: the kernel's completion signal arrives microseconds after its last
+        store); after a generous timeout, and for every launch without a word, wait for the stream."""
+        if word is None or self._L.mrsim_host_wait_word(self._word_host, word, 2_000_000) != _lib.OK:
+            _lib.check(self._L.mrsim_stream_synchronize(None), what)
+            if word is not None and int(self._rec.step_word[0]) != word:
+                raise RuntimeError(f"{what}: the launch completed without storing its step word")
         if self._rec.status[0]:
             # SciPy raises from RK45.step() once the solver has failed (step size below the spacing of floats / NaN input):
             # "Attempt to step on a failed or finished solver."
@@ -194,10 +203,12 @@ class MR_Env:
         r = self._rec
         r.action[0] = f_t
         r.action[1] = alpha_t
+        self._word = word = (self._word % 0x7FFFFFFF) + 1      # never 0, never the previous step's
+        self._io.done_value = word
         with self._on_device():
             _lib.check(self._L.mrsim_step(self._pp, 1, self.env_id, C.byref(self._st), C.byref(self._io), self.seed_value,
                                           self.step_idx, None), "mrsim_step")
-            self._wait("mrsim_step")
+            self._wait("mrsim_step", word)
         self.step_idx += 1
         self.counter += 1
         self.last_pos = [float(r.pos[0]), float(r.pos[1])]

@@ -237,3 +237,23 @@ def test_partition_masks_keep_a_unit_of_every_xcc_on_both_sides():
         partition_masks(256, 8, 0)
     with pytest.raises(ValueError):
         partition_masks(256, 8, 17)
+
+
+def test_host_wait_word_polls_a_host_word_without_a_device():
+    """mrsim_host_wait_word is plain host code (the host side of MrsimStepIO.done_word): returns at once when the word holds the
+    value, MRSIM_ETIMEOUT after the stated time when it does not, and sees a store made by another thread."""
+    import ctypes as C
+    import threading
+    import time
+    from mr_rl_amd import _lib
+    L = _lib.lib()
+    w = np.zeros(4, dtype=np.int32)
+    p = C.c_void_p(w.ctypes.data)
+    w[0] = 7
+    assert L.mrsim_host_wait_word(p, 7, 0) == _lib.OK
+    t0 = time.perf_counter()
+    assert L.mrsim_host_wait_word(p, 8, 20000) == _lib.ETIMEOUT
+    assert 0.015 < time.perf_counter() - t0 < 1.0
+    assert L.mrsim_host_wait_word(None, 1, 10) == _lib.EINVAL and L.mrsim_host_wait_word(p, 1, -1) == _lib.EINVAL
+    threading.Timer(0.05, lambda: w.__setitem__(0, 9)).start()
+    assert L.mrsim_host_wait_word(p, 9, 5000000) == _lib.OK      # (ctypes releases the GIL during the call)

@@ -96,7 +96,7 @@ def test_library_default_law_is_collapsed_everywhere():
     assert p.noise_law == _lib.LAW_COLLAPSED
     assert MRConfig().noise_law == "collapsed" and MRConfig().to_params().noise_law == _lib.LAW_COLLAPSED
     assert orc_params_from_cfg(MRConfig()).noise_law == O.LAW_COLLAPSED
-    assert C.sizeof(_lib.MrsimStepIO) == 112
+    assert C.sizeof(_lib.MrsimStepIO) == 128
 
 
 # ---------------------------------------------------------------------------
@@ -504,3 +504,46 @@ def test_the_reference_shaped_loop_learns_the_one_step_goal_task():
         k = len(rets) // 10
         tenths = [float(np.mean(rets[i:i + k])) for i in range(0, 10 * k, k)]
         assert tenths[0] < 45.0 and max(tenths[1:]) >= 60.0 and max(tenths[1:]) > tenths[0] + 30.0, (seed, tenths)
+
+
+@pytest.mark.gpu
+def test_step_word_is_stored_after_the_outputs_of_a_one_workgroup_launch():
+    """MrsimStepIO.done_word: a launch of one workgroup stores done_value into a word of mrsim_host_alloc memory after its outputs
+    (the one-env facade polls it instead of waiting for the stream: tests of the facade above run through it); launches of more
+    than one workgroup refuse it.  Here: 200 envs whose outputs live in the SAME pinned block as the word -- when the host sees the
+    word, rewards and done flags of all 200 envs are there, and they equal a twin env's stepped the ordinary way."""
+    import ctypes as C
+    import torch
+    from mr_rl_amd import MRConfig, MRVecEnv, _lib
+    L = _lib.lib()
+    n = 200
+    cfg = MRConfig(noise_var=1.0, auto_reset=True)
+    env, twin = MRVecEnv(n, cfg=cfg, seed=4), MRVecEnv(n, cfg=cfg, seed=4)
+    env.reset(); twin.reset()
+    h, d = C.c_void_p(), C.c_void_p()
+    _lib.check(L.mrsim_host_alloc(4096, C.byref(h), C.byref(d)), "mrsim_host_alloc")
+    try:
+        host = np.frombuffer((C.c_uint8 * 4096).from_address(h.value), dtype=np.uint8)
+        word = host[:4].view(np.int32); rew = host[16:16 + 4 * n].view(np.float32); done = host[2048:2048 + n]
+        for k in range(60):
+            io = env._step_io(None)
+            io.rew, io.done = d.value + 16, d.value + 2048
+            io.done_word, io.done_value = d.value, 100 + k
+            rew[:] = -1.0
+            _lib.check(L.mrsim_step(C.byref(env._params), n, env.env_id0, C.byref(env._st), C.byref(io), env.seed_value, env.step_idx,
+                                    env._stream()), "mrsim_step")
+            env.step_idx += 1
+            assert L.mrsim_host_wait_word(h, 100 + k, 5_000_000) == _lib.OK and int(word[0]) == 100 + k
+            got_rew, got_done = rew.copy(), done.copy()            # no stream wait has happened since the launch
+            twin.step(None)
+            assert np.array_equal(got_rew, twin.rew.cpu().numpy()) and np.array_equal(got_done, twin._done_u8.cpu().numpy())
+        torch.cuda.synchronize()
+        assert torch.equal(env.obs, twin.obs)
+        big = MRVecEnv(300, cfg=cfg, seed=4)
+        big.reset()
+        io = big._step_io(None)
+        io.done_word, io.done_value = d.value, 5
+        assert L.mrsim_step(C.byref(big._params), 300, 0, C.byref(big._st), C.byref(io), 4, 1, big._stream()) == _lib.EINVAL
+    finally:
+        torch.cuda.synchronize()
+        L.mrsim_host_free(h)
