@@ -401,8 +401,14 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
 #pragma unroll
                 for (int jj = 0; jj < 8; jj += 2) {
                     const int q = 8 * s + jj;
-                    const act_f32x2 v = {act_relu(acc1[q / 16][q % 16]), act_relu(acc1[(q + 1) / 16][(q + 1) % 16])};
-                    const act_bf16x2 t = __builtin_convertvector(v, act_bf16x2);
+                    // ReLU AFTER the rounding, on both halves at once: a bf16 is sign-magnitude, so as an int16 a negative value
+                    // (or -0) is < 0 and max(., 0) is the ReLU -- v_pk_max_i16 instead of two v_max_f32 in front of the conversion.
+                    // Same bits: rounding to nearest keeps the sign, and a value that rounds to -0 becomes +0 either way.
+                    const act_f32x2 v = {acc1[q / 16][q % 16], acc1[(q + 1) / 16][(q + 1) % 16]};
+                    typedef short act_s16x2 __attribute__((ext_vector_type(2)));
+                    const act_s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(act_s16x2, __builtin_convertvector(v, act_bf16x2)),
+                                                                  (act_s16x2){0, 0});
+                    const act_bf16x2 t = __builtin_bit_cast(act_bf16x2, r);
                     bp[jj] = t[0]; bp[jj + 1] = t[1];
                 }
 #pragma unroll
