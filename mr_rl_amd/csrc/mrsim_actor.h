@@ -44,7 +44,8 @@ constexpr int kActHidden = 64;
 //               keeps f32-class accuracy (tests: <= 5e-6 of the action bound against the F32 result and against the oracle's emulation of the same
 //               splits, <= 1e-5 against PyTorch fp32) at 6/16 of the f32-MFMA cycles, on the matrix cores proper, which
 //               DO run beside the vector unit.
-//   kActBf16    plain bf16 operands (the first term alone), one MFMA per k-step and row tile, f32 accumulation: what bf16 inference
+//   kActBf16    plain bf16 operands (the first term alone), one MFMA per k-step and row tile, f32 accumulation, the OUTPUT layer
+//               included (four more MFMAs per column tile instead of 32 v_max + 64 fma on the vector unit): what bf16 inference
 //               is -- 1e-2-class accuracy of the action (tests: <= 6e-2 of the bound against PyTorch fp32 on nets whose output layer
 //               saturates, 1e-4 on freshly initialised ones) for exploration-grade collection at twice the bf16x3 rate.
 enum : int { kActOff = 0, kActF32 = 1, kActBf16x3 = 2, kActBf16 = 3 };
@@ -76,11 +77,15 @@ template <> struct ActLds<kActBf16x3> {   // A1bf: [m 2][rt 2][lane 64][8 bf16],
 static_assert(ActLds<kActBf16x3>::A2bf % 4 == 0, "ds_read_b128 alignment");
 // plain bf16: layer 1 runs on the bf16 matrix cores as well (below), so its A operands are a bf16 image built while staging
 // (512 floats: [rt 2][lane 64][8 bf16]) in place of the 384 floats of f32 operands
+// ... and so does the output layer: rows 0 and 1 of its 32-row A tile carry W3, the other 30 rows are zero, so the operands are a
+// compact table built while staging from the f32 W3 block -- [k-step s 4][slot 5][8 bf16]: slot 2 h + i = row i of lane half h,
+// slot 4 = eight zeros, which every lane of rows 2..31 reads (80 floats; a full [s][lane] image would be 4 KiB and cost the
+// goal-table kernels their second block per compute unit)
 template <> struct ActLds<kActBf16> {
     static constexpr int A1 = 0, A1bf = 0, A2 = 0, C1 = 512, C2 = C1 + 64, W3 = C2 + 64, Tail = W3 + 128, A2bf = Tail + 8,
-                         Floats = A2bf + kActA2bfFloats;
+                         A3bf = A2bf + kActA2bfFloats, Floats = A3bf + 4 * 5 * 4;
 };
-static_assert(ActLds<kActBf16>::A2bf % 4 == 0, "ds_read_b128 alignment");
+static_assert(ActLds<kActBf16>::A2bf % 4 == 0 && ActLds<kActBf16>::A3bf % 4 == 0, "ds_read_b128 alignment");
 // Layer 1 of the plain-bf16 arithmetic: ONE v_mfma_f32_32x32x16_bf16 per (row tile, column tile) instead of three f32 MFMAs.
 // Its 16 k-slots hold the five inputs as three bf16 terms each (hi, mid, lo: the input keeps its 24 bits) against the bf16-rounded
 // weight of that input, repeated per term:  slot -> input  0 1 2 3 4 4 0 1 | 2 3 4 - 0 1 2 3   (terms: hi x5, lo of 4, mid 0 1 |
@@ -162,6 +167,19 @@ __device__ __forceinline__ void actor_stage_blob(const float* __restrict__ blob,
             }
             const bf2 t = __builtin_convertvector(w, bf2);
             a1[d] = __builtin_bit_cast(uint32_t, t);
+        }
+        // output-layer A operands: lane (i, h) of k-step s holds W3[i][kperm(8 s + jj, h)], jj = 0..7, for the two output rows
+        // i = 0, 1 (the f32 block stores W3[o][kperm(q, h)] at [h][o][q]) -- slot 2 h + i of the table; slot 4 is the zero row
+        uint32_t* __restrict__ a3 = reinterpret_cast<uint32_t*>(s_blob + L::A3bf);
+        for (unsigned d = tid; d < 4u * 5u * 4u; d += nthreads) {
+            const unsigned sx = d / 20u, slot = (d >> 2) % 5u, pair = d & 3u;
+            f2 w = {0.0f, 0.0f};
+            if (slot < 4u) {
+                w[0] = blob[kActW3 + slot * 32u + 8u * sx + 2u * pair];          // ([h][o][q] with slot = 2 h + o)
+                w[1] = blob[kActW3 + slot * 32u + 8u * sx + 2u * pair + 1u];
+            }
+            const bf2 t = __builtin_convertvector(w, bf2);
+            a3[d] = __builtin_bit_cast(uint32_t, t);
         }
         act_copy4(blob + kActC1, s_blob + L::C1, kActF32Floats - kActC1, tid, nthreads);      // biases, output layer, tail
         act_copy4(blob + kActA2bf, s_blob + L::A2bf, kActA2bfFloats, tid, nthreads);          // layer-2 bf16 terms
@@ -455,8 +473,34 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
                 }
             }
         }
-        // output layer on the vector unit: this lane's 32 features of env (32 ct + j), two partial sums per output
         float p0 = 0.0f, p1 = 0.0f;
+        if constexpr (MODE == kActBf16) {
+            // output layer on the matrix cores too: out[o][env] = sum_f W3[o][f] relu(h2[f][env]) as four MFMAs of a 32-row tile whose
+            // rows 0, 1 are W3 (bf16) -- the activations rounded once, as between layers 1 and 2.  Row o of the result sits in
+            // register o of the lanes of half 0 (half 1 holds rows 4, 5: zeros), i.e. exactly the "partial sums per half" the
+            // epilogue below adds.  64 v_max + 128 fma per wave and step become 32 conversions + 32 packed max + 8 MFMAs.
+            // (The first MFMA's C is the inline constant 0: the accumulator is born there.)
+            const unsigned a3slot = (lane & 31u) < 2u ? 2u * h + (lane & 31u) : 4u;   // rows 2..31 of the tile: the zero row
+            act_f32x16 acc3 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                act_bf16x8 bp;
+#pragma unroll
+                for (int jj = 0; jj < 8; jj += 2) {
+                    const int q = 8 * s + jj;
+                    const act_f32x2 v = {acc2[q / 16][q % 16], acc2[(q + 1) / 16][(q + 1) % 16]};
+                    typedef short act_s16x2 __attribute__((ext_vector_type(2)));
+                    const act_s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(act_s16x2, __builtin_convertvector(v, act_bf16x2)),
+                                                                  (act_s16x2){0, 0});
+                    const act_bf16x2 t = __builtin_bit_cast(act_bf16x2, r);
+                    bp[jj] = t[0]; bp[jj + 1] = t[1];
+                }
+                const act_bf16x8 ap = *reinterpret_cast<const act_bf16x8*>(sA + L::A3bf + (s * 5 + a3slot) * 4);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bp, acc3, 0, 0, 0);
+            }
+            p0 = acc3[0]; p1 = acc3[1];
+        } else {
+        // output layer on the vector unit: this lane's 32 features of env (32 ct + j), two partial sums per output
 #pragma unroll
         for (int q4 = 0; q4 < 8; ++q4) {
             const act_f32x4 w0 = *reinterpret_cast<const act_f32x4*>(sA + L::W3 + (h * 2 + 0) * 32 + q4 * 4);
@@ -468,6 +512,7 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
                 p0 = __builtin_fmaf(w0[j], hq, p0);
                 p1 = __builtin_fmaf(w1[j], hq, p1);
             }
+        }
         }
         if (ct == 0) { part[0][0] = p0; part[0][1] = p1; }
         else { part[1][0] = p0; part[1][1] = p1; }

@@ -757,6 +757,25 @@ void orc_actor_forward(const OrcActor* a, const float obs[5], float act[2]) {
             h2[f] = acc > 0.0f ? acc : 0.0f;
         }
     }
+    if (a->math == 2) {
+        /* plain bf16: the output layer runs on the bf16 matrix cores as well -- W3 and relu(h2) rounded to bf16 once, k-step s of
+         * v_mfma_f32_32x32x16_bf16 sums the 16 features kperm(8 s + jj, h) exactly and rounds once into the f32 accumulator */
+        for (int o = 0; o < 2; ++o) {
+            float acc = 0.0f;
+            for (int s = 0; s < 4; ++s) {
+                double sum = 0.0;
+                for (int h = 0; h < 2; ++h)
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int k = act_kperm(8 * s + jj, h);
+                        sum += (double)bf16_round(a->w3[o * 64 + k]) * (double)bf16_round(h2[k]);
+                    }
+                acc = (float)((double)acc + sum);
+            }
+            const float pre = (acc + 0.0f) + a->b3[o];
+            act[o] = orc_spec_tanhf(pre) * a->bound[o];
+        }
+        return;
+    }
     for (int o = 0; o < 2; ++o) {                               /* fully_connected 2, tanh, * action_bound  :130-137 */
         float p[2] = {0.0f, 0.0f};
         for (int h = 0; h < 2; ++h)

@@ -205,6 +205,16 @@ def test_oracle_bf16_arithmetics_against_a_numpy_emulation():
         h2 = np.maximum(acc, 0)
         out = np.zeros((len(obs), 2), np.float32)
         for o in range(2):
+            if math_name == "bf16":
+                # plain bf16: the output layer on the bf16 matrix cores as well -- W3 and relu(h2) rounded once, four k-steps of 16
+                # features, each summed exactly and rounded once into the f32 accumulator (which starts at 0); the bias afterwards
+                a3, w3b, h2b = np.zeros(len(obs), np.float32), _bf16(w["w3"][o].astype(np.float32)), _bf16(h2)
+                for s in range(4):
+                    ks = [kperm(8 * s + jj, h) for h in range(2) for jj in range(8)]
+                    a3 = (a3.astype(np.float64) + h2b[:, ks].astype(np.float64) @ w3b[ks].astype(np.float64)).astype(np.float32)
+                pre = (a3 + np.float32(0)) + np.float32(w["b3"][o])
+                out[:, o] = [np.float32(L.orc_spec_tanhf(float(x))) * np.float32(w["action_bound"][o]) for x in pre]
+                continue
             p = np.zeros((len(obs), 2), np.float32)
             for h in range(2):
                 for q in range(32):
