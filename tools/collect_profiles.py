@@ -324,10 +324,10 @@ d1dur = d1dur[50:]
 c1a, _, grid_1, f1a = counters("pmc_actor_b1_a", ACT1, 0.0)
 w1 = grid_1 / 64
 avg1 = sum(d1dur) / len(d1dur)
-flops1 = w1 * T * 20 * 32 * 32 * 16 * 2     # 16 (64 x 64 layer) + 4 (layer 1) bf16 MFMAs per wave-step
+flops1 = w1 * T * 28 * 32 * 32 * 16 * 2     # 16 (64 x 64 layer) + 4 (layer 1) + 8 (output layer, 2 of its 32 rows used) bf16 MFMAs per wave-step
 files["pmc_actor_bf16.json"] = json.dumps({
     "what": "the fused actor rollout with MrsimActor.math = BF16 (tools/actor_probe.py --math bf16): kernel trace durations and SQ "
-            "counters per wave and env step; 20 bf16 MFMAs per wave-step, no f32 MFMA",
+            "counters per wave and env step; 28 bf16 MFMAs per wave-step (all three layers), no f32 MFMA",
     **stamp, "kernel": "mr_rollout_actor_fl_kernel<RK45,fast,nominal,DDPG|carry64|actor|OU|bf16>, 512-thread blocks", "N": N, "T": T,
     "avg_kernel_us": round(avg1, 2), "median_kernel_us": round(sorted(d1dur)[len(d1dur) // 2], 2), "dispatches_timed": len(d1dur),
     "in_kernel_env_steps_per_s": round(N * T / (avg1 * 1e-6), 1),
