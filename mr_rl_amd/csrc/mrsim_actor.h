@@ -225,6 +225,14 @@ __device__ __forceinline__ float spec_tanhf(float x) {
     return x < 0.0f ? -r : r;
 }
 
+// tanh for the plain-bf16 arithmetic: 1 - 2 / (exp(2x) + 1) on the hardware's exp2 and reciprocal (1 ulp each), branch-free, six
+// instructions instead of the specified routine's ~42 per value.  Absolute error ~1e-7 -- four orders below what rounding the
+// operands to bf16 does to the action; +-1 at the ends (exp2 -> inf / 0).  The exact arithmetics keep spec_tanhf (bitwise vs the oracle).
+__device__ __forceinline__ float fast_tanhf(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // exp(2 x)
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
 __device__ __forceinline__ void lds_load16(const float* __restrict__ p, act_f32x16& v) {
     const act_f32x4* __restrict__ q = reinterpret_cast<const act_f32x4*>(p);
     const act_f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
@@ -523,7 +531,7 @@ __device__ __forceinline__ void actor_forward(const float* __restrict__ sA, cons
     for (int o = 0; o < 2; ++o) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0][o]), __float_as_uint(part[1][o]), false, false);
         const float pre = (__uint_as_float(r[0]) + __uint_as_float(r[1])) + sA[L::Tail + o];
-        a[o] = spec_tanhf(pre) * sA[L::Tail + 2 + o];
+        a[o] = (MODE == kActBf16 ? fast_tanhf(pre) : spec_tanhf(pre)) * sA[L::Tail + 2 + o];
     }
 }
 
