@@ -4,7 +4,8 @@
 // (51 steps, reward 10 per step, done by timeout: MR_env.py:62,89,136-152).  Then the DDPG collection loop of
 // RL/MR_ddpg.py:270-311 with the actor on the device (ABI 3): fold a batch norm, pack the network, upload the block, and
 // compare one episode as 51 x (mrsim_actor_forward -> mrsim_step) with the same episode as one mrsim_rollout whose policy
-// source is the in-kernel actor -- actions and positions must agree bitwise.
+// source is the in-kernel actor -- actions and positions must agree bitwise.  Then the step kernel as the writer of a replay ring
+// (MrsimStepIO.replay, ABI 5) and one env driven from the host on a pinned record whose step word the host polls (done_word).
 //
 // Build: make -C mr_rl_amd/csrc demo      Run: examples/abi_demo [n_envs]
 #include <hip/hip_runtime.h>
@@ -179,12 +180,81 @@ int main(int argc, char** argv) {
         if (mrsim_rollout(&p, n, 0, &b.st, &rb, seed, 200, stream) != MRSIM_EINVAL) act_same = -1;
         std::printf("actor in the loop: rollout(actor)==51 x (actor_forward -> step) (bitwise): %lld  actions in range: %lld\n",
                     (long long)act_same, (long long)act_moved);
+        // (4) RL/MR_ddpg.py:277-282 in ONE launch per env step: policy, noise, env.step AND replay_buffer.add -- the step kernel writes
+        // its transitions into a device ring itself (MrsimStepIO.replay).  Three steps of n envs into a ring of 4 n rows: row i of
+        // the first step must hold the reset observation of env i as `state`, the last n rows the last actions.
+        const int64_t cap = 4 * n;
+        float *rs = nullptr, *ra = nullptr, *rr = nullptr, *rd = nullptr, *rs2 = nullptr, *ended = nullptr;
+        HIP_OK(hipMalloc(&rs, cap * 5 * sizeof(float))); HIP_OK(hipMalloc(&rs2, cap * 5 * sizeof(float)));
+        HIP_OK(hipMalloc(&ra, cap * 2 * sizeof(float))); HIP_OK(hipMalloc(&rr, cap * sizeof(float)));
+        HIP_OK(hipMalloc(&rd, cap * sizeof(float))); HIP_OK(hipMalloc(&ended, 2 * sizeof(float)));
+        HIP_OK(hipMemset(ended, 0, 2 * sizeof(float)));
+        HIP_OK(hipMemsetAsync(ou_a, 0, n * 2 * sizeof(float), stream));
+        SIM_OK(mrsim_reset(&p, n, 0, &a.st, nullptr, nullptr, nullptr, a.obs, 0, seed, 300, stream));
+        std::vector<float> obs0(5 * n), ring_s(5 * n), ring_a(2 * n), ring_r(n);
+        HIP_OK(hipMemcpyAsync(obs0.data(), a.obs, 5 * n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        MrsimReplaySink sink;
+        std::memset(&sink, 0, sizeof(sink));
+        sink.s = rs; sink.a = ra; sink.r = rr; sink.done = rd; sink.s2 = rs2; sink.ended2 = ended; sink.capacity = (int32_t)cap;
+        for (int k = 0; k < 5; ++k) sink.obs_scale[k] = 1.0f;
+        MrsimStepIO ic;
+        std::memset(&ic, 0, sizeof(ic));
+        ic.obs = a.obs; ic.rew = a.rew; ic.done = a.done; ic.actions_out = act_a; ic.actor = &actor_a; ic.replay = &sink;
+        for (int t = 1; t <= 3; ++t) {
+            sink.head = (int32_t)((t - 1) * n);
+            SIM_OK(mrsim_step(&p, n, 0, &a.st, &ic, seed, 300 + (uint64_t)t, stream));
+        }
+        HIP_OK(hipMemcpyAsync(ring_s.data(), rs, 5 * n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(ring_a.data(), ra + 2 * 2 * n, 2 * n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(ring_r.data(), rr + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(last_a.data(), act_a, 2 * n * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        int64_t ring_ok = 0;
+        for (int64_t i = 0; i < n; ++i)
+            ring_ok += std::memcmp(&ring_s[5 * i], &obs0[5 * i], 5 * sizeof(float)) == 0 &&
+                       std::memcmp(&ring_a[2 * i], &last_a[2 * i], 2 * sizeof(float)) == 0 && ring_r[i] == 10.0f;
+        ic.actor = nullptr;     // the sink stores the observation the kernel's OWN policy saw: without an actor it is an argument error
+        if (mrsim_step(&p, n, 0, &a.st, &ic, seed, 400, stream) != MRSIM_EINVAL) ring_ok = -1;
+        std::printf("replay ring written by the step kernel: rows as expected: %lld\n", (long long)ring_ok);
+        if (ring_ok != n) act_same = -1;
+    }
+    // (5) one env driven from the host (the drop-in MR_Env.step): state, action and outputs in ONE pinned block, the kernel stores a
+    // step word after its outputs and the host polls it -- no copy call, no stream wait
+    int host_ok = 0;
+    {
+        void *hp = nullptr, *dp = nullptr;
+        SIM_OK(mrsim_host_alloc(192, &hp, &dp));
+        char* h = static_cast<char*>(hp);
+        char* d = static_cast<char*>(dp);
+        reinterpret_cast<float*>(h + 16)[2] = 1.0f;                                   // aux: h_abs / dt
+        reinterpret_cast<double*>(h + 144)[0] = 110.0; reinterpret_cast<double*>(h + 144)[1] = 115.0;   // init_xy
+        MrsimState s1 = {reinterpret_cast<double*>(d), reinterpret_cast<float*>(d + 16), reinterpret_cast<float*>(d + 32)};
+        SIM_OK(mrsim_reset(&p, 1, 0, &s1, nullptr, reinterpret_cast<double*>(d + 144), nullptr, reinterpret_cast<float*>(d + 64), 0, seed, 500, stream));
+        SIM_OK(mrsim_stream_synchronize(stream));
+        MrsimStepIO i1;
+        std::memset(&i1, 0, sizeof(i1));
+        i1.actions = reinterpret_cast<float*>(d + 48); i1.obs = reinterpret_cast<float*>(d + 64); i1.rew = reinterpret_cast<float*>(d + 96);
+        i1.done = reinterpret_cast<uint8_t*>(d + 100); i1.done_word = reinterpret_cast<int32_t*>(d + 160);
+        int polled = 0;
+        for (int k = 1; k <= 20; ++k) {
+            reinterpret_cast<float*>(h + 48)[0] = 4.0f; reinterpret_cast<float*>(h + 48)[1] = 0.785398f;      // the action, written by the host
+            i1.done_value = k;
+            SIM_OK(mrsim_step(&p, 1, 0, &s1, &i1, seed, 500 + (uint64_t)k, stream));
+            polled += mrsim_host_wait_word(reinterpret_cast<const int32_t*>(h + 160), k, 2000000) == MRSIM_OK;
+        }
+        const float* ob = reinterpret_cast<const float*>(h + 64);
+        const int32_t counter = reinterpret_cast<const int32_t*>(h + 16)[3];
+        host_ok = polled == 20 && counter == 20 && ob[0] > 110.0f && ob[0] < 116.0f && reinterpret_cast<const float*>(h + 96)[0] == 10.0f;
+        std::printf("one env on a host record, 20 steps polled on the record's step word: %s (x = %.4f, counter = %d)\n", host_ok ? "ok" : "FAIL",
+                    ob[0], counter);
+        SIM_OK(mrsim_stream_synchronize(stream));
+        SIM_OK(mrsim_host_free(hp));
     }
     // error behaviour of the boundary: bad arguments come back as codes, never as exceptions
     const bool errs = mrsim_step(nullptr, n, 0, &a.st, &io, seed, 0, stream) == MRSIM_EINVAL &&
                       mrsim_step(&p, -1, 0, &a.st, &io, seed, 0, stream) == MRSIM_EINVAL &&
                       mrsim_random_policy(&p, n, 0, a.rew + 1, seed, 0, stream) == MRSIM_EALIGN;
-    const bool ok = n_done == n && done_before_end == 0 && n_ret == n && n_same == n && errs && act_same == n && act_moved == n;
+    const bool ok = n_done == n && done_before_end == 0 && n_ret == n && n_same == n && errs && act_same == n && act_moved == n && host_ok;
     std::printf(ok ? "ABI_DEMO_OK\n" : "ABI_DEMO_FAIL\n");
     return ok ? 0 : 1;
 }

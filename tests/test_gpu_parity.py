@@ -659,12 +659,14 @@ def test_nan_action_terminates_and_raises_status():
 def test_c_abi_demo_program():
     """The C ABI is usable without Python or torch: examples/abi_demo.cpp (HIP runtime buffers only) runs one episode
     through mrsim_reset/mrsim_step and through one mrsim_rollout launch and checks episode shape, bitwise agreement
-    of the two paths and the error codes."""
+    of the two paths and the error codes; the actor in the loop; the step kernel writing a replay ring (MrsimStepIO.replay); one env
+    on a pinned host record polled on its step word (done_word / mrsim_host_wait_word)."""
     import subprocess
     exe = os.path.join(ROOT, "examples", "abi_demo")
     assert os.path.exists(exe), "build it with make -C mr_rl_amd/csrc demo"
     r = subprocess.run([exe, "5000"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ABI_DEMO_OK" in r.stdout, (r.stdout, r.stderr)
+    assert "rows as expected: 5000" in r.stdout and "polled on the record's step word: ok" in r.stdout, r.stdout
 
 
 def test_event_attached_launch_times_the_kernel_without_blocking():
